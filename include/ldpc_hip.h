@@ -1,0 +1,102 @@
+/*
+ * ldpc_hip.h -- C ABI of libldpc_hip.so: MI355X (gfx950) belief-propagation LDPC decoding.
+ *
+ * This is the drop-in boundary for the BP hot path of thadikari/ldpc_decoders.  The upstream code is pure
+ * Python on this path; its own FFI precedent is the ctypes binding of the ADMM projection
+ * (src/parity_polytope/exact.py:12-21,49-53 -> extern "C" proj_vec/proj_csr, projection.cpp:252,266):
+ * extern "C", caller-allocated buffers, plain pointers and sizes.  The entry points below follow that
+ * pattern; each cites the upstream interface it replaces.  INTEGRATION.md shows the ctypes stub a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative LDPC_E_* code; ldpc_last_error() gives the text
+ *     (thread-local).  Nothing throws across the boundary.
+ *   - "dev" pointers are device (HBM) addresses on the handle's GPU; "host" pointers are ordinary memory.
+ *   - frames are rows: priors / y / xhat are [B, n] row-major, exactly what numpy hands over.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Work is enqueued on it; calls may
+ *     synchronise that stream internally (early-termination polling) but never the device.
+ *   - handles are not thread-safe: one decoder per host thread / stream.
+ */
+#ifndef LDPC_HIP_H
+#define LDPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ldpc_code_s* ldpc_code_t;
+typedef struct ldpc_decoder_s* ldpc_decoder_t;
+
+enum { LDPC_ALG_MSA = 0, LDPC_ALG_SPA = 1, LDPC_ALG_BEC = 2 };      /* decoder selector: src/utils.py:16, main.py:12 */
+enum { LDPC_DTYPE_F32 = 0, LDPC_DTYPE_F64 = 1 };                     /* message arithmetic                             */
+enum { LDPC_BACKEND_AUTO = 0, LDPC_BACKEND_STREAM = 1, LDPC_BACKEND_FUSED = 2 };
+enum { LDPC_CH_BIAWGN = 0, LDPC_CH_BSC = 1, LDPC_CH_BEC = 2 };       /* channel selector: src/models.py:3               */
+enum { LDPC_FLAG_NO_EARLY_EXIT = 1 };                                /* NOT reference behaviour: run exactly max_iter   */
+enum { LDPC_E_ARG = -1, LDPC_E_HIP = -2, LDPC_E_GRAPH = -3, LDPC_E_UNSUPPORTED = -4, LDPC_E_NOMEM = -5 };
+
+/* counters written by ldpc_count_errors / ldpc_simulate (int64 each) */
+enum { LDPC_CNT_TOT = 0, LDPC_CNT_WEC = 1, LDPC_CNT_BEC = 2, LDPC_CNT_ITER_SUM = 3, LDPC_CNT_HIST0 = 4 };
+
+const char* ldpc_last_error(void);
+int ldpc_abi_version(void);
+int ldpc_device_count(int* count);
+
+/* Tanner graph from the row-major edge list of H: edge k = (edge_chk[k], edge_var[k]) sorted by check, then
+ * variable -- the order of `xx, yy = np.where(parity_mtx)` in BPA.__init__ (src/bpa.py:9-15) and bec.SPA.__init__
+ * (src/bec.py:77).  Host pointers; the graph is copied to `device` once (CSR + CSC index lists in HBM). */
+int ldpc_code_create(int device, int32_t m, int32_t n, int64_t E, const int32_t* edge_chk, const int32_t* edge_var,
+                     ldpc_code_t* out);
+int ldpc_code_destroy(ldpc_code_t code);
+int ldpc_code_info(ldpc_code_t code, int32_t* m, int32_t* n, int64_t* E, int32_t* max_dc, int32_t* max_dv);
+
+/* Decoder = graph + algorithm + arithmetic + workspace.  Replaces the constructors bpa.SPA / bpa.MSA
+ * (src/bpa.py:66-84) and bec.SPA / bec.MSA (src/bec.py:70-81,125). */
+int ldpc_decoder_create(ldpc_code_t code, int alg, int dtype, int backend, ldpc_decoder_t* out);
+int ldpc_decoder_destroy(ldpc_decoder_t dec);
+/* backend actually used by the last decode (LDPC_BACKEND_*) and the number of sweeps the batch ran */
+int ldpc_decoder_last_stats(ldpc_decoder_t dec, int* backend, int* sweeps);
+
+/* Batched BPA.decode(y, priors) (src/bpa.py:17-63) / bec.SPA.decode(y) (src/bec.py:83-122).
+ *   priors_dev  [B,n] float or double per `dtype` (ignored for LDPC_ALG_BEC)
+ *   y0_dev      [B,n] uint8 or NULL: hard received word checked at iteration 0 (src/bpa.py:20,29: BSC), or
+ *               the received symbols {0,1,2} for LDPC_ALG_BEC (required)
+ *   max_iter    sweep cap; <= 0 means "until every frame has left" as upstream (src/bpa.py:28), bounded at 100000
+ *   xhat_dev    [B,n] uint8 out: decisions in {0,1} ({0,1,2} for BEC, 2 = still erased)
+ *   iters_dev   [B]  int32 out: sweeps executed by each frame (0 = left at the iteration-0 check, x_hat = y0) */
+int ldpc_decode(ldpc_decoder_t dec, const void* priors_dev, const uint8_t* y0_dev, int64_t B, int32_t max_iter,
+                uint32_t flags, uint8_t* xhat_dev, int32_t* iters_dev, void* stream);
+/* Same on the streaming backend, additionally returning the soft output: marginals_dev [B,n] (`dtype`) = the
+ * marginal LLRs (prior + sum of check messages, src/bpa.py:35) of each frame's LAST executed sweep (0 where a frame
+ * never swept).  LLR decoders only; B <= 2^17. */
+int ldpc_decode_soft(ldpc_decoder_t dec, const void* priors_dev, const uint8_t* y0_dev, int64_t B, int32_t max_iter,
+                     uint32_t flags, uint8_t* xhat_dev, int32_t* iters_dev, void* marginals_dev, void* stream);
+/* Same with host buffers (numpy ndpointer style, as exact.proj_csr); copies in, decodes, copies out, synchronises. */
+int ldpc_decode_host(ldpc_decoder_t dec, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
+                     uint8_t* xhat, int32_t* iters);
+
+/* Channel.send + LLR for frames [frame0, frame0+B) of the all-`codeword` word, Philox4x32-10 keyed by
+ * (seed, stream_id, global frame index) -- biawgn.Channel.send/LLR.decode (src/biawgn.py:13-28),
+ * bsc (src/bsc.py:11-25), bec.Channel.send (src/bec.py:11-18).  priors_dev [B,n] (`dtype`; NULL for BEC),
+ * y_dev [B,n] uint8 (BSC: received bits, BEC: symbols; may be NULL for BI-AWGN). */
+int ldpc_channel(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0,
+                 int64_t B, int32_t n, void* priors_dev, uint8_t* y_dev, void* stream);
+
+/* Monte-Carlo counters of main.test (src/main.py:41-45), ACCUMULATED into counters_dev (int64[4 + hist_bins]):
+ * tot += B, wec += #frames with errors, bec += bit errors, iter_sum += sum(iters), hist[min(iters, bins-1)] += 1.
+ * `sent_dev` is the transmitted word [n] or NULL for the all-`codeword` word; iters_dev may be NULL. */
+int ldpc_count_errors(const uint8_t* xhat_dev, const uint8_t* sent_dev, int codeword, const int32_t* iters_dev, int64_t B,
+                      int32_t n, int32_t hist_bins, int64_t* counters_dev, void* stream);
+
+/* One pass of the whole hot path for frames [frame0, frame0+B): channel -> LLR -> decode -> count, everything on
+ * the device; counters accumulate as in ldpc_count_errors.  This is the body of `while wec < min_wec`
+ * (src/main.py:37-45) for B frames at once. */
+int ldpc_simulate(ldpc_decoder_t dec, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id,
+                  uint64_t frame0, int64_t B, int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters_dev,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_HIP_H */

@@ -1,0 +1,160 @@
+"""Device-side handles: Tanner graph in HBM and decoder workspaces (thin wrappers over the C ABI)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .codes import Code
+
+
+def as_code(obj):
+    """Accept a ``codes.Code`` or a dense parity matrix (the reference passes ``code.parity_mtx``, src/biawgn.py:35)."""
+    if isinstance(obj, Code):
+        return obj
+    if hasattr(obj, "edge_chk") and hasattr(obj, "edge_var"):
+        return Code.from_edges(obj.m, obj.n, obj.edge_chk, obj.edge_var)
+    return Code(None, np.asarray(obj))
+
+
+def current_device():
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            return torch.cuda.current_device()
+    except ImportError:
+        pass
+    return 0
+
+
+class CodeHandle:
+    def __init__(self, code, device):
+        lib = _lib.load()
+        self.code, self.device = code, device
+        h = ctypes.c_void_p()
+        chk = np.ascontiguousarray(code.edge_chk, dtype=np.int32)
+        var = np.ascontiguousarray(code.edge_var, dtype=np.int32)
+        _lib.check(lib.ldpc_code_create(device, code.m, code.n, code.E, chk.ctypes.data, var.ctypes.data, ctypes.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.load().ldpc_code_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def code_handle(code, device=None):
+    device = current_device() if device is None else device
+    hd = code._handles.get(device)
+    if hd is None:
+        hd = code._handles[device] = CodeHandle(code, device)
+    return hd
+
+
+class DecoderHandle:
+    """One (graph, algorithm, arithmetic, backend) decoder with its HBM workspace."""
+
+    def __init__(self, code, alg, precision="f32", backend="auto", device=None):
+        lib = _lib.load()
+        self.code_handle = code_handle(code, device)
+        self.code, self.alg, self.precision, self.backend = code, alg, precision, backend
+        self.np_dtype = np.float64 if precision == "f64" else np.float32
+        h = ctypes.c_void_p()
+        _lib.check(lib.ldpc_decoder_create(self.code_handle.h, _lib.ALG[alg], _lib.DTYPE[precision], _lib.BACKEND[backend],
+                                           ctypes.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.load().ldpc_decoder_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- host (numpy) buffers
+    def decode_host(self, priors, y0, max_iter, flags=0):
+        lib = _lib.load()
+        n = self.code.n
+        if self.alg == "BEC":
+            y0 = np.ascontiguousarray(np.atleast_2d(y0), dtype=np.uint8)
+            B, pri_ptr = y0.shape[0], None
+        else:
+            priors = np.ascontiguousarray(np.atleast_2d(priors), dtype=self.np_dtype)
+            B, pri_ptr = priors.shape[0], priors.ctypes.data
+            if y0 is not None:
+                y0 = np.ascontiguousarray(np.atleast_2d(y0), dtype=np.uint8)
+        if (priors is not None and self.alg != "BEC" and priors.shape[1] != n) or (y0 is not None and y0.shape[1] != n):
+            raise ValueError("frames must have n=%d entries" % n)
+        xhat = np.empty((B, n), dtype=np.uint8)
+        iters = np.empty(B, dtype=np.int32)
+        _lib.check(lib.ldpc_decode_host(self.h, pri_ptr, None if y0 is None else y0.ctypes.data, B, int(max_iter), flags,
+                                        xhat.ctypes.data, iters.ctypes.data))
+        return xhat, iters
+
+    # ---- device (torch) buffers: no copies, current torch stream
+    def decode_device(self, priors, y0, max_iter, flags=0, xhat=None, iters=None):
+        import torch
+
+        lib = _lib.load()
+        n = self.code.n
+        ref = y0 if priors is None else priors
+        B = ref.shape[0]
+        if priors is not None:
+            want = torch.float64 if self.precision == "f64" else torch.float32
+            if priors.dtype != want or not priors.is_contiguous() or not priors.is_cuda:
+                raise ValueError("priors must be a contiguous CUDA tensor of dtype %s" % want)
+        if y0 is not None and (y0.dtype != torch.uint8 or not y0.is_contiguous() or not y0.is_cuda):
+            raise ValueError("y0 must be a contiguous CUDA uint8 tensor")
+        if xhat is None:
+            xhat = torch.empty((B, n), dtype=torch.uint8, device=ref.device)
+        if iters is None:
+            iters = torch.empty((B,), dtype=torch.int32, device=ref.device)
+        st = torch.cuda.current_stream(ref.device).cuda_stream
+        _lib.check(lib.ldpc_decode(self.h, None if priors is None else priors.data_ptr(), None if y0 is None else y0.data_ptr(),
+                                   B, int(max_iter), flags, xhat.data_ptr(), iters.data_ptr(), st))
+        return xhat, iters
+
+    def decode_soft_device(self, priors, y0, max_iter, flags=0):
+        """Streaming backend with soft output: returns (xhat, iters, marginals) CUDA tensors."""
+        import torch
+
+        B, n = priors.shape
+        xhat = torch.empty((B, n), dtype=torch.uint8, device=priors.device)
+        iters = torch.empty((B,), dtype=torch.int32, device=priors.device)
+        marg = torch.zeros_like(priors)
+        st = torch.cuda.current_stream(priors.device).cuda_stream
+        _lib.check(_lib.load().ldpc_decode_soft(self.h, priors.data_ptr(), None if y0 is None else y0.data_ptr(), B, int(max_iter),
+                                                flags, xhat.data_ptr(), iters.data_ptr(), marg.data_ptr(), st))
+        return xhat, iters, marg
+
+    def channel_device(self, channel, param, codeword, seed, stream_id, frame0, B):
+        """Device channel + LLR kernels only: returns (priors or None, y or None) CUDA tensors for frames [frame0, frame0+B)."""
+        import torch
+
+        n = self.code.n
+        dt = torch.float64 if self.precision == "f64" else torch.float32
+        pri = None if channel == "bec" else torch.empty((B, n), dtype=dt, device="cuda")
+        y = None if channel == "biawgn" else torch.empty((B, n), dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.load().ldpc_channel(_lib.CHANNEL[channel], _lib.DTYPE[self.precision], float(param), int(codeword), int(seed),
+                                            int(stream_id), int(frame0), int(B), n, None if pri is None else pri.data_ptr(),
+                                            None if y is None else y.data_ptr(), st))
+        return pri, y
+
+    def simulate(self, channel, param, codeword, seed, stream_id, frame0, B, max_iter, counters, flags=0, hist_bins=0):
+        """channel -> LLR -> decode -> count for frames [frame0, frame0+B) entirely on the device; ``counters`` is a CUDA
+        int64 tensor of 4 + hist_bins entries that is ACCUMULATED into."""
+        import torch
+
+        st = torch.cuda.current_stream(counters.device).cuda_stream
+        _lib.check(_lib.load().ldpc_simulate(self.h, _lib.CHANNEL[channel], float(param), int(codeword), int(seed), int(stream_id),
+                                             int(frame0), int(B), int(max_iter), flags, hist_bins, counters.data_ptr(), st))
+
+    def last_stats(self):
+        b, s = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.load().ldpc_decoder_last_stats(self.h, ctypes.byref(b), ctypes.byref(s)))
+        return _lib.BACKEND_NAME.get(b.value, "?"), s.value

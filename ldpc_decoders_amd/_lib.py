@@ -1,0 +1,75 @@
+"""ctypes binding of libldpc_hip.so (C ABI: include/ldpc_hip.h).
+
+Mirrors the upstream pattern for native code (``src/parity_polytope/exact.py:12-21``: lazy
+``ctypes.cdll.LoadLibrary`` + typed argument lists).  There is deliberately NO fallback: if the HIP
+library is missing or no GPU is usable, the product path raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libldpc_hip.so")
+
+ALG = {"MSA": 0, "SPA": 1, "BEC": 2}
+DTYPE = {"f32": 0, "f64": 1}
+BACKEND = {"auto": 0, "stream": 1, "fused": 2}
+BACKEND_NAME = {v: k for k, v in BACKEND.items()}
+CHANNEL = {"biawgn": 0, "bsc": 1, "bec": 2}
+FLAG_NO_EARLY_EXIT = 1
+CNT_TOT, CNT_WEC, CNT_BEC, CNT_ITER_SUM, CNT_HIST0 = 0, 1, 2, 3, 4
+
+_c = ctypes
+_P = ctypes.c_void_p
+SIGNATURES = {
+    "ldpc_last_error": (_c.c_char_p, []),
+    "ldpc_abi_version": (_c.c_int, []),
+    "ldpc_device_count": (_c.c_int, [_c.POINTER(_c.c_int)]),
+    "ldpc_code_create": (_c.c_int, [_c.c_int, _c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.POINTER(_P)]),
+    "ldpc_code_destroy": (_c.c_int, [_P]),
+    "ldpc_code_info": (_c.c_int, [_P, _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int64),
+                                  _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32)]),
+    "ldpc_decoder_create": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_P)]),
+    "ldpc_decoder_destroy": (_c.c_int, [_P]),
+    "ldpc_decoder_last_stats": (_c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    "ldpc_decode": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P, _P]),
+    "ldpc_decode_soft": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P, _P, _P]),
+    "ldpc_decode_host": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P]),
+    "ldpc_channel": (_c.c_int, [_c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_int64,
+                                _c.c_int32, _P, _P, _P]),
+    "ldpc_count_errors": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int32, _c.c_int32, _P, _P]),
+    "ldpc_simulate": (_c.c_int, [_P, _c.c_int, _c.c_double, _c.c_int, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_int64,
+                                 _c.c_int32, _c.c_uint32, _c.c_int32, _P, _P]),
+}
+
+_lib = None
+
+
+class LdpcHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built -- there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LdpcHipError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(or `make -C ldpc_decoders_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here == ABI mismatch with include/ldpc_hip.h
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().ldpc_last_error()
+        raise LdpcHipError("libldpc_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(load().ldpc_device_count(ctypes.byref(n)))
+    return n.value

@@ -1,0 +1,200 @@
+"""Code store: parity-check matrices as sparse row-major edge lists.
+
+Host-side mirror of the reference's ``src/codes.py`` for the BP hot path: same names
+(``Code``, ``get_code``, ``get_code_names``, ``load_parity_mtx``, ``save_parity_mtx``, ``rand_reg_ldpc``), same
+built-in toy codes (src/codes.py:27-66), same text format and loader semantics (src/codes.py:93-105) -- but H is
+never held dense (the reference's dense int64 H is 16.8 GB at n = 64 800): a code is its edge list
+``(edge_chk[k], edge_var[k])`` in the order of ``np.where(H)``.  ``parity_mtx`` is still offered (built lazily) so
+that code written against the reference keeps working for small codes.
+"""
+import itertools
+import os
+
+import numpy as np
+
+file_codes_dir_string = "FILE_CODES_DIR"
+
+
+def _file_codes_dir():
+    # src/codes.py:68-70: env var or ./data/codes relative to the working directory
+    return os.path.abspath(os.environ.get(file_codes_dir_string, os.path.join("data", "codes")))
+
+
+class Code:
+    """A binary linear block code given by its parity checks (and optionally generator rows).
+
+    reference: ``codes.Code`` (src/codes.py:8-24).  Accepts either dense matrices (reference signature
+    ``Code(gen_mtx, parity_mtx)``) or, via :meth:`from_edges` / :meth:`from_rows`, sparse descriptions.
+    """
+
+    def __init__(self, gen_mtx=None, parity_mtx=None):
+        self.gen_mtx = None if gen_mtx is None else np.asarray(gen_mtx, dtype=np.int64)
+        self._dense = None
+        self._cb = None
+        self._handles = {}
+        if parity_mtx is not None:
+            H = np.asarray(parity_mtx)
+            chk, var = np.nonzero(H)
+            self._set_edges(H.shape[0], H.shape[1], chk, var)
+
+    def _set_edges(self, m, n, chk, var):
+        chk = np.ascontiguousarray(chk, dtype=np.int32)
+        var = np.ascontiguousarray(var, dtype=np.int32)
+        order = np.lexsort((var, chk))
+        chk, var = chk[order], var[order]
+        if len(chk) > 1:
+            dup = (np.diff(chk) == 0) & (np.diff(var) == 0)
+            if dup.any():
+                keep = np.r_[True, ~dup]
+                chk, var = chk[keep], var[keep]
+        self.m, self.n, self.E = int(m), int(n), int(len(chk))
+        self.edge_chk, self.edge_var = np.ascontiguousarray(chk), np.ascontiguousarray(var)
+        return self
+
+    @classmethod
+    def from_edges(cls, m, n, chk, var, gen_mtx=None):
+        return cls(gen_mtx)._set_edges(m, n, chk, var)
+
+    @classmethod
+    def from_rows(cls, n, rows, gen_rows=None):
+        """rows: iterable of iterables with the variable indices (0-based) of each check."""
+        chk = [c for c, r in enumerate(rows) for _ in r]
+        var = [v for r in rows for v in r]
+        gen = None
+        if gen_rows is not None:
+            gen = np.zeros((len(gen_rows), n), dtype=np.int64)
+            for i, r in enumerate(gen_rows):
+                gen[i, list(r)] = 1
+        return cls(gen)._set_edges(len(rows), n, chk, var)
+
+    # ---- reference-compatible surface
+    @property
+    def parity_mtx(self):
+        if self._dense is None:
+            if self.m * self.n > 1 << 28:
+                raise MemoryError("dense H of %dx%d refused; use the edge list (edge_chk, edge_var)" % (self.m, self.n))
+            H = np.zeros((self.m, self.n), dtype=np.int64)
+            H[self.edge_chk, self.edge_var] = 1
+            self._dense = H
+        return self._dense
+
+    @property
+    def cb(self):
+        """Code book, all 2^k words (small codes only; reference builds it eagerly, src/codes.py:12-19)."""
+        if self._cb is None:
+            if self.gen_mtx is None:
+                raise AttributeError("code has no generator matrix, hence no code book")
+            k = self.gen_mtx.shape[0]
+            msgs = np.array(list(itertools.product((0, 1), repeat=k)), dtype=np.int64)
+            cb = (msgs @ self.gen_mtx) % 2
+            assert self.syndrome(cb).sum() == 0 and cb[0].sum() == 0
+            self._cb = cb
+        return self._cb
+
+    def syndrome(self, words):
+        """(H @ words^T) mod 2 without a dense H; words [..., n] -> [..., m]."""
+        w = np.asarray(words)
+        s = np.zeros(w.shape[:-1] + (self.m,), dtype=np.int64)
+        np.add.at(s, (Ellipsis, self.edge_chk), w[..., self.edge_var].astype(np.int64))
+        return s % 2
+
+    def get_n(self):
+        return self.n
+
+    def get_k(self):
+        return self.n - self.m
+
+    def row_degrees(self):
+        return np.bincount(self.edge_chk, minlength=self.m)
+
+    def col_degrees(self):
+        return np.bincount(self.edge_var, minlength=self.n)
+
+
+# Built-in toy codes (the matrices of src/codes.py:27-66, written as row supports).
+_BUILTIN = {
+    "4_2_test": (5, [(0, 1), (1, 2, 3), (3, 4)], [(0, 1, 2), (2, 3, 4)]),
+    "6_2_3_ldpc": (6, [(0, 1, 2), (3, 4, 5), (2, 3, 5), (0, 1, 4)], [(3, 5), (0, 2, 3, 4), (0, 1)]),
+    "7_4_hamming": (7, [(3, 4, 5, 6), (1, 2, 5, 6), (0, 2, 4, 6)], [(0, 1, 2), (0, 3, 4), (1, 3, 5), (0, 1, 3, 6)]),
+    "12_3_4_ldpc": (12,
+                    [(2, 5, 6, 7), (0, 1, 4, 11), (3, 8, 9, 10), (1, 5, 6, 9), (0, 2, 7, 10), (3, 4, 8, 11), (0, 3, 4, 6),
+                     (5, 7, 10, 11), (1, 2, 8, 9)],
+                    [(4, 5, 6, 11), (3, 6, 7, 8, 9, 10), (2, 5, 9, 10), (1, 5, 7, 8, 10, 11), (0, 6, 7, 8, 9, 11)]),
+}
+
+
+def get_file_code_map():
+    d = _file_codes_dir()
+    files = next(os.walk(d), ((), (), ()))[2]
+    return {os.path.splitext(f)[0]: os.path.join(d, f) for f in files}
+
+
+def get_code_names():
+    return list(_BUILTIN.keys()) + list(get_file_code_map().keys())
+
+
+def get_code(name):
+    """reference: ``codes.get_code`` (src/codes.py:84-90): files shadow built-ins."""
+    files = get_file_code_map()
+    if name in files:
+        return load_parity_mtx(files[name])
+    n, rows, gen_rows = _BUILTIN[name]
+    return Code.from_rows(n, rows, gen_rows)
+
+
+def parse_parity_text(text):
+    """Text -> Code with the loader semantics of src/codes.py:93-105.
+
+    One check per non-blank line, whitespace-separated variable numbers; the index base is the global minimum,
+    which must be 0 or 1; ``n = max + (0 if base == 1 else 1)``.  Quirk kept for bit-compatibility: every entry is
+    written to column ``var - 1`` whatever the base, so in a 0-based file variable 0 lands in the LAST column.
+    """
+    rows = [[int(t) for t in line.split()] for line in text.splitlines() if line.split()]
+    if not rows:
+        raise Exception("empty parity file")
+    lo = min(min(r) for r in rows)
+    hi = max(max(r) for r in rows)
+    if lo not in (0, 1):
+        raise Exception("Minimum index is not 0 or 1.")
+    n = hi + (0 if lo == 1 else 1)
+    chk = np.repeat(np.arange(len(rows)), [len(r) for r in rows])
+    var = (np.concatenate([np.asarray(r, dtype=np.int64) for r in rows]) - 1) % n
+    return Code.from_edges(len(rows), n, chk, var)
+
+
+def load_parity_mtx(file_path):
+    with open(file_path, "r") as fp:
+        return parse_parity_text(fp.read())
+
+
+def save_parity_mtx(code, code_name, directory=None):
+    """reference: ``codes.save_parity_mtx`` (src/codes.py:131-136): 1-based indices, one check per line."""
+    if not isinstance(code, Code):
+        code = Code(None, code)
+    directory = directory or _file_codes_dir()
+    os.makedirs(directory, exist_ok=True)
+    path = os.path.join(directory, "%s.txt" % code_name)
+    starts = np.r_[0, np.cumsum(code.row_degrees())]
+    with open(path, "w") as fp:
+        for c in range(code.m):
+            fp.write(" ".join(str(v + 1) for v in code.edge_var[starts[c]:starts[c + 1]]) + "\n")
+    return path
+
+
+def rand_reg_ldpc(n, l, r, rng=None):
+    """Random (l, r)-regular code, same ensemble as ``codes.rand_reg_ldpc`` (src/codes.py:108-120): every check
+    takes the r currently least-loaded variables, ties broken uniformly at random.  Sparse: O(m n log n) -> O(m n)
+    via a random-keyed partial sort, no dense H."""
+    rng = rng or np.random
+    m = int(n * l / r)
+    deg = np.zeros(n, dtype=np.int64)
+    chk, var = [], []
+    for i in range(m):
+        key = deg + rng.random_sample(n)  # integer part orders by load, fractional part breaks ties at random
+        pick = np.argpartition(key, r - 1)[:r]
+        deg[pick] += 1
+        chk += [i] * r
+        var += sorted(int(v) for v in pick)
+    code = Code.from_edges(m, n, chk, var)
+    assert (code.col_degrees() == l).all() and (code.row_degrees() == r).all()
+    return code

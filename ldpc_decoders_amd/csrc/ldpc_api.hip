@@ -1,0 +1,345 @@
+// extern "C" surface of libldpc_hip.so (declared in include/ldpc_hip.h).
+#include <cstring>
+#include <new>
+
+#include "../../include/ldpc_hip.h"
+#include "ldpc_common.hpp"
+
+namespace ldpc {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const char* last_error() { return g_err.c_str(); }
+
+int DevBuf::reserve(size_t need) {
+    if (need <= bytes) return LDPC_OK;
+    if (p) {
+        LDPC_HIP_TRY(hipFree(p));
+        p = nullptr;
+        bytes = 0;
+    }
+    const size_t want = need + need / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        return LDPC_E_NOMEM;
+    }
+    bytes = want;
+    return LDPC_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+namespace {
+template <typename T>
+int upload(const std::vector<T>& h, T** d) {
+    LDPC_HIP_TRY(hipMalloc((void**)d, (h.size() + 1) * sizeof(T)));
+    LDPC_HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return LDPC_OK;
+}
+
+int pick_backend(Decoder* d) {
+    if (d->backend == BK_STREAM) return BK_STREAM;
+    if (fused_supported(d)) return BK_FUSED;
+    if (d->backend == BK_FUSED) {
+        set_error("fused backend does not support this (code, algorithm, dtype); use LDPC_BACKEND_AUTO or _STREAM");
+        return LDPC_E_UNSUPPORTED;
+    }
+    return BK_STREAM;
+}
+}  // namespace
+}  // namespace ldpc
+
+using namespace ldpc;
+
+extern "C" {
+
+const char* ldpc_last_error(void) { return last_error(); }
+int ldpc_abi_version(void) { return 1; }
+
+int ldpc_device_count(int* count) {
+    if (!count) return LDPC_E_ARG;
+    LDPC_HIP_TRY(hipGetDeviceCount(count));
+    return LDPC_OK;
+}
+
+int ldpc_code_create(int device, int32_t m, int32_t n, int64_t E, const int32_t* chk, const int32_t* var, ldpc_code_t* out) {
+    if (!out || !chk || !var || m <= 0 || n <= 0 || E <= 0 || E > (int64_t)1 << 30) {
+        set_error("ldpc_code_create: bad arguments (m=%d n=%d E=%lld)", m, n, (long long)E);
+        return LDPC_E_ARG;
+    }
+    Code* c = new (std::nothrow) Code();
+    if (!c) return LDPC_E_NOMEM;
+    c->device = device;
+    c->m = m;
+    c->n = n;
+    c->E = E;
+    c->row_ptr.assign((size_t)m + 1, 0);
+    c->col_ptr.assign((size_t)n + 1, 0);
+    c->edge_var.assign(var, var + E);
+    c->edge_chk.assign(chk, chk + E);
+    for (int64_t k = 0; k < E; ++k) {
+        if (chk[k] < 0 || chk[k] >= m || var[k] < 0 || var[k] >= n) {
+            set_error("edge %lld = (%d,%d) outside a %dx%d matrix", (long long)k, chk[k], var[k], m, n);
+            delete c;
+            return LDPC_E_GRAPH;
+        }
+        if (k && (chk[k] < chk[k - 1] || (chk[k] == chk[k - 1] && var[k] <= var[k - 1]))) {
+            set_error("edge list must be strictly row-major sorted (np.where order); violated at edge %lld", (long long)k);
+            delete c;
+            return LDPC_E_GRAPH;
+        }
+        c->row_ptr[chk[k] + 1]++;
+        c->col_ptr[var[k] + 1]++;
+    }
+    c->max_dc = c->max_dv = 0;
+    c->min_dc = c->min_dv = INT32_MAX;
+    for (int i = 0; i < m; ++i) {
+        const int d = c->row_ptr[i + 1];
+        c->max_dc = d > c->max_dc ? d : c->max_dc;
+        c->min_dc = d < c->min_dc ? d : c->min_dc;
+        c->row_ptr[i + 1] += c->row_ptr[i];
+    }
+    for (int i = 0; i < n; ++i) {
+        const int d = c->col_ptr[i + 1];
+        c->max_dv = d > c->max_dv ? d : c->max_dv;
+        c->min_dv = d < c->min_dv ? d : c->min_dv;
+        c->col_ptr[i + 1] += c->col_ptr[i];
+    }
+    c->col_edge.assign((size_t)E, 0);
+    {
+        std::vector<int32_t> fill(c->col_ptr.begin(), c->col_ptr.end() - 1);
+        for (int64_t k = 0; k < E; ++k) c->col_edge[fill[var[k]]++] = (int32_t)k;  // ascending edge order per variable
+    }
+    int rc = LDPC_OK;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        set_error("hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+        delete c;
+        return LDPC_E_HIP;
+    }
+    if ((rc = upload(c->row_ptr, &c->d_row_ptr)) || (rc = upload(c->edge_var, &c->d_edge_var)) ||
+        (rc = upload(c->edge_chk, &c->d_edge_chk)) || (rc = upload(c->col_ptr, &c->d_col_ptr)) ||
+        (rc = upload(c->col_edge, &c->d_col_edge))) {
+        ldpc_code_destroy((ldpc_code_t)c);
+        return rc;
+    }
+    *out = (ldpc_code_t)c;
+    return LDPC_OK;
+}
+
+int ldpc_code_destroy(ldpc_code_t h) {
+    Code* c = (Code*)h;
+    if (!c) return LDPC_OK;
+    (void)hipSetDevice(c->device);
+    for (int32_t* p : {c->d_row_ptr, c->d_edge_var, c->d_edge_chk, c->d_col_ptr, c->d_col_edge})
+        if (p) (void)hipFree(p);
+    delete c;
+    return LDPC_OK;
+}
+
+int ldpc_code_info(ldpc_code_t h, int32_t* m, int32_t* n, int64_t* E, int32_t* max_dc, int32_t* max_dv) {
+    Code* c = (Code*)h;
+    if (!c) return LDPC_E_ARG;
+    if (m) *m = c->m;
+    if (n) *n = c->n;
+    if (E) *E = c->E;
+    if (max_dc) *max_dc = c->max_dc;
+    if (max_dv) *max_dv = c->max_dv;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_create(ldpc_code_t code, int alg, int dtype, int backend, ldpc_decoder_t* out) {
+    if (!code || !out || alg < 0 || alg > 2 || dtype < 0 || dtype > 1 || backend < 0 || backend > 2) {
+        set_error("ldpc_decoder_create: bad arguments (alg=%d dtype=%d backend=%d)", alg, dtype, backend);
+        return LDPC_E_ARG;
+    }
+    Decoder* d = new (std::nothrow) Decoder();
+    if (!d) return LDPC_E_NOMEM;
+    d->code = (Code*)code;
+    d->alg = alg;
+    d->dtype = dtype;
+    d->backend = backend;
+    (void)hipSetDevice(d->code->device);
+    hipError_t e = hipHostMalloc(&d->pinned, 4096, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
+        delete d;
+        return LDPC_E_HIP;
+    }
+    int rc = fused_plan_create(d);
+    if (rc) {
+        ldpc_decoder_destroy((ldpc_decoder_t)d);
+        return rc;
+    }
+    if (backend == BK_FUSED && !fused_supported(d)) {
+        set_error("fused backend does not support this (code, algorithm, dtype)");
+        ldpc_decoder_destroy((ldpc_decoder_t)d);
+        return LDPC_E_UNSUPPORTED;
+    }
+    *out = (ldpc_decoder_t)d;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_destroy(ldpc_decoder_t h) {
+    Decoder* d = (Decoder*)h;
+    if (!d) return LDPC_OK;
+    (void)hipSetDevice(d->code->device);
+    fused_plan_destroy(d);
+    for (DevBuf* b : {&d->msg, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->h_in, &d->h_y0, &d->h_out,
+                      &d->h_iters})
+        b->release();
+    if (d->pinned) (void)hipHostFree(d->pinned);
+    delete d;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_last_stats(ldpc_decoder_t h, int* backend, int* sweeps) {
+    Decoder* d = (Decoder*)h;
+    if (!d) return LDPC_E_ARG;
+    if (backend) *backend = d->last_backend;
+    if (sweeps) *sweeps = d->last_sweeps;
+    return LDPC_OK;
+}
+
+int ldpc_decode(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
+                uint8_t* xhat, int32_t* iters, void* stream) {
+    Decoder* d = (Decoder*)h;
+    if (!d || !xhat || !iters || B < 0) {
+        set_error("ldpc_decode: bad arguments");
+        return LDPC_E_ARG;
+    }
+    LDPC_HIP_TRY(hipSetDevice(d->code->device));
+    const int bk = pick_backend(d);
+    if (bk < 0) return bk;
+    hipStream_t st = (hipStream_t)stream;
+    // bound the workspace: at most 2^17 frames per pass through a backend
+    const int64_t step = (int64_t)1 << 17;
+    const size_t esz = d->dtype == DT_F64 ? 8 : 4;
+    int sweeps = 0;
+    for (int64_t b0 = 0; b0 < B; b0 += step) {
+        const int64_t nb = (B - b0) < step ? (B - b0) : step;
+        const void* p = priors ? (const char*)priors + (size_t)b0 * d->code->n * esz : nullptr;
+        const uint8_t* y = y0 ? y0 + (size_t)b0 * d->code->n : nullptr;
+        int rc = bk == BK_FUSED ? fused_decode(d, p, y, nb, max_iter, flags, xhat + (size_t)b0 * d->code->n, iters + b0, st)
+                                : stream_decode(d, p, y, nb, max_iter, flags, xhat + (size_t)b0 * d->code->n, iters + b0, nullptr, st);
+        if (rc) return rc;
+        sweeps = d->last_sweeps > sweeps ? d->last_sweeps : sweeps;
+    }
+    d->last_sweeps = sweeps;
+    return LDPC_OK;
+}
+
+int ldpc_decode_soft(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
+                     uint8_t* xhat, int32_t* iters, void* marginals, void* stream) {
+    Decoder* d = (Decoder*)h;
+    if (!d || !xhat || !iters || !marginals || B < 0 || B > ((int64_t)1 << 17) || d->alg == ALG_BEC) {
+        set_error("ldpc_decode_soft: bad arguments (LLR decoders only, at most 2^17 frames per call)");
+        return LDPC_E_ARG;
+    }
+    LDPC_HIP_TRY(hipSetDevice(d->code->device));
+    return stream_decode(d, priors, y0, B, max_iter, flags, xhat, iters, marginals, (hipStream_t)stream);
+}
+
+int ldpc_decode_host(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
+                     uint8_t* xhat, int32_t* iters) {
+    Decoder* d = (Decoder*)h;
+    if (!d || !xhat || !iters || B < 0) {
+        set_error("ldpc_decode_host: bad arguments");
+        return LDPC_E_ARG;
+    }
+    if (B == 0) return LDPC_OK;
+    LDPC_HIP_TRY(hipSetDevice(d->code->device));
+    const size_t n = (size_t)d->code->n, esz = d->dtype == DT_F64 ? 8 : 4;
+    void* dp = nullptr;
+    uint8_t* dy = nullptr;
+    if (d->alg != ALG_BEC) {
+        if (!priors) {
+            set_error("ldpc_decode_host: priors is null");
+            return LDPC_E_ARG;
+        }
+        LDPC_TRY(d->h_in.reserve((size_t)B * n * esz));
+        dp = d->h_in.p;
+        LDPC_HIP_TRY(hipMemcpyAsync(dp, priors, (size_t)B * n * esz, hipMemcpyHostToDevice, nullptr));
+    }
+    if (y0) {
+        LDPC_TRY(d->h_y0.reserve((size_t)B * n));
+        dy = (uint8_t*)d->h_y0.p;
+        LDPC_HIP_TRY(hipMemcpyAsync(dy, y0, (size_t)B * n, hipMemcpyHostToDevice, nullptr));
+    }
+    LDPC_TRY(d->h_out.reserve((size_t)B * n));
+    LDPC_TRY(d->h_iters.reserve((size_t)B * sizeof(int32_t)));
+    LDPC_TRY(ldpc_decode(h, dp, dy, B, max_iter, flags, (uint8_t*)d->h_out.p, (int32_t*)d->h_iters.p, nullptr));
+    LDPC_HIP_TRY(hipMemcpyAsync(xhat, d->h_out.p, (size_t)B * n, hipMemcpyDeviceToHost, nullptr));
+    LDPC_HIP_TRY(hipMemcpyAsync(iters, d->h_iters.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
+    LDPC_HIP_TRY(hipStreamSynchronize(nullptr));
+    return LDPC_OK;
+}
+
+int ldpc_channel(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0,
+                 int64_t B, int32_t n, void* priors, uint8_t* y, void* stream) {
+    if (B < 0 || n <= 0 || dtype < 0 || dtype > 1) {
+        set_error("ldpc_channel: bad arguments");
+        return LDPC_E_ARG;
+    }
+    return channel_generate(channel, dtype, param, codeword, seed, stream_id, frame0, B, n, priors, y, (hipStream_t)stream);
+}
+
+int ldpc_count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const int32_t* iters, int64_t B, int32_t n,
+                      int32_t hist_bins, int64_t* counters, void* stream) {
+    if (!xhat || !counters || B < 0 || n <= 0 || hist_bins < 0) {
+        set_error("ldpc_count_errors: bad arguments");
+        return LDPC_E_ARG;
+    }
+    return count_errors(xhat, sent, codeword, iters, B, n, hist_bins, counters, (hipStream_t)stream);
+}
+
+int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id,
+                  uint64_t frame0, int64_t B, int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters,
+                  void* stream) {
+    Decoder* d = (Decoder*)h;
+    if (!d || !counters || B < 0) {
+        set_error("ldpc_simulate: bad arguments");
+        return LDPC_E_ARG;
+    }
+    if ((channel == CH_BEC) != (d->alg == ALG_BEC)) {
+        set_error("ldpc_simulate: the erasure channel pairs with LDPC_ALG_BEC decoders (and only with them)");
+        return LDPC_E_ARG;
+    }
+    if (B == 0) return LDPC_OK;
+    LDPC_HIP_TRY(hipSetDevice(d->code->device));
+    const size_t n = (size_t)d->code->n, esz = d->dtype == DT_F64 ? 8 : 4;
+    hipStream_t st = (hipStream_t)stream;
+    // bounded staging: priors for at most 2^17 frames at a time
+    const int64_t step = (int64_t)1 << 17;
+    const int64_t cap = B < step ? B : step;
+    if (channel != CH_BEC) LDPC_TRY(d->h_in.reserve((size_t)cap * n * esz));
+    LDPC_TRY(d->h_y0.reserve((size_t)cap * n));
+    LDPC_TRY(d->h_out.reserve((size_t)cap * n));
+    LDPC_TRY(d->h_iters.reserve((size_t)cap * sizeof(int32_t)));
+    for (int64_t b0 = 0; b0 < B; b0 += step) {
+        const int64_t nb = (B - b0) < step ? (B - b0) : step;
+        void* pri = channel == CH_BEC ? nullptr : d->h_in.p;
+        uint8_t* y = channel == CH_BIAWGN ? nullptr : (uint8_t*)d->h_y0.p;
+        LDPC_TRY(channel_generate(channel, d->dtype, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, (int32_t)n, pri,
+                                  y, st));
+        LDPC_TRY(ldpc_decode(h, pri, y, nb, max_iter, flags, (uint8_t*)d->h_out.p, (int32_t*)d->h_iters.p, stream));
+        LDPC_TRY(count_errors((uint8_t*)d->h_out.p, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters,
+                              st));
+    }
+    return LDPC_OK;
+}
+
+}  // extern "C"

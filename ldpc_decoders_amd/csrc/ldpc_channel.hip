@@ -1,0 +1,193 @@
+// Channel + LLR kernels and the error counters of the Monte-Carlo loop.
+//
+// Reference statements (thadikari/ldpc_decoders):
+//   BI-AWGN  sigma^2 = 10^(-snr/10); y = (2x-1) + N(0, sigma); prior = -2y/sigma^2 ...... src/biawgn.py:10-28
+//   BSC      y = (x + [u < p]) mod 2; prior = (log(1-p) - log(p)) * (1 - 2y) ............ src/bsc.py:11-25
+//   BEC      y = 2 where u < p else x .................................................. src/bec.py:11-18
+//   counters errors = #(x != x_hat); wec += errors > 0; bec += errors; tot += 1 ........ src/main.py:41-45
+// The reference draws from numpy's global MT19937; the device draws from Philox keyed by the global frame
+// index (ldpc_rng.hpp) -- host-generated noise is used wherever bit parity with the reference is claimed.
+#include "ldpc_common.hpp"
+#include "ldpc_rng.hpp"
+
+namespace ldpc {
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, T& z0, T& z1);
+
+template <>
+__device__ __forceinline__ void box_muller<float>(uint32_t wa, uint32_t wb, float& z0, float& z1) {
+    // u = (w + 0.5) / 2^32 in (0,1); radius from the full 32 bits (tail to 6.7 sigma), angle from 32 bits
+    const float u1 = fmaf((float)wa, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    const float u2 = fmaf((float)wb, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    const float r = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincospif(2.0f * u2, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+template <>
+__device__ __forceinline__ void box_muller<double>(uint32_t wa, uint32_t wb, double& z0, double& z1) {
+    const double u1 = ((double)wa + 0.5) * 2.3283064365386963e-10;
+    const double u2 = ((double)wb + 0.5) * 2.3283064365386963e-10;
+    const double r = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+// one thread = 4 consecutive variables of one frame (one Philox block)
+template <typename T>
+__global__ __launch_bounds__(256) void k_biawgn(double sigma, double inv_var2, int codeword, uint64_t seed, uint32_t stream,
+                                                uint64_t frame0, int64_t B, int n, int blocks_per_frame, T* __restrict__ priors) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t f = gid / blocks_per_frame;
+    const int j = (int)(gid - f * blocks_per_frame);
+    if (f >= B) return;
+    const Philox4 p = philox_word_block(seed, stream, frame0 + (uint64_t)f, (uint32_t)j);
+    T z[4];
+    box_muller<T>(p.w[0], p.w[1], z[0], z[1]);
+    box_muller<T>(p.w[2], p.w[3], z[2], z[3]);
+    const T mean = (T)(2 * codeword - 1), sg = (T)sigma, k = (T)inv_var2;
+    T out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const T y = mean + sg * z[q];
+        out[q] = -(k * y);  // -2y/sigma^2 with k = 2/sigma^2
+    }
+    T* dst = priors + f * n + 4 * j;
+    if ((n & 3) == 0) {
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+        } else {
+            *reinterpret_cast<double2*>(dst) = make_double2(out[0], out[1]);
+            *reinterpret_cast<double2*>(dst + 2) = make_double2(out[2], out[3]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (4 * j + q < n) dst[q] = out[q];
+    }
+}
+
+// BSC / BEC: one word per variable; event <=> (w + 0.5) * 2^-32 < p <=> w < thr
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void k_discrete(uint64_t thr, double llr, int codeword, uint64_t seed, uint32_t stream,
+                                                  uint64_t frame0, int64_t B, int n, int blocks_per_frame,
+                                                  T* __restrict__ priors, uint8_t* __restrict__ y) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t f = gid / blocks_per_frame;
+    const int j = (int)(gid - f * blocks_per_frame);
+    if (f >= B) return;
+    const Philox4 p = philox_word_block(seed, stream, frame0 + (uint64_t)f, (uint32_t)j);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int v = 4 * j + q;
+        if (v < n) {
+            const bool hit = (uint64_t)p.w[q] < thr;
+            uint8_t s;
+            if constexpr (CH == CH_BSC) {
+                s = (uint8_t)(codeword ^ (hit ? 1 : 0));
+                if (priors) priors[f * n + v] = (T)llr * (T)(1 - 2 * (int)s);
+            } else {
+                s = hit ? (uint8_t)2 : (uint8_t)codeword;
+            }
+            y[f * n + v] = s;
+        }
+    }
+}
+
+// one wavefront per frame
+__global__ __launch_bounds__(256) void k_count(const uint8_t* __restrict__ xhat, const uint8_t* __restrict__ sent, int codeword,
+                                               const int32_t* __restrict__ iters, int64_t B, int n, int hist_bins,
+                                               unsigned long long* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= B) return;
+    int err = 0;
+    for (int v = lane; v < n; v += 64) {
+        const uint8_t want = sent ? sent[v] : (uint8_t)codeword;
+        err += xhat[f * n + v] != want;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) err += __shfl_xor(err, off, 64);
+    if (lane == 0) {
+        atomicAdd(&counters[0], 1ull);
+        if (err) {
+            atomicAdd(&counters[1], 1ull);
+            atomicAdd(&counters[2], (unsigned long long)err);
+        }
+        if (iters) {
+            const int it = iters[f];
+            atomicAdd(&counters[3], (unsigned long long)it);
+            if (hist_bins > 0) atomicAdd(&counters[4 + (it < hist_bins ? it : hist_bins - 1)], 1ull);
+        }
+    }
+}
+
+}  // namespace
+
+int channel_generate(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0,
+                     int64_t B, int32_t n, void* priors, uint8_t* y, hipStream_t st) {
+    if (B <= 0) return LDPC_OK;
+    if (codeword != 0 && codeword != 1) {
+        set_error("device channel kernels send the all-zero (0) or all-one (1) word; got codeword=%d", codeword);
+        return LDPC_E_ARG;
+    }
+    const int bpf = (n + 3) / 4;
+    const int64_t threads = B * bpf;
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    if (channel == CH_BIAWGN) {
+        if (!priors) {
+            set_error("biawgn channel needs a priors output buffer");
+            return LDPC_E_ARG;
+        }
+        const double var = pow(10.0, -param / 10.0);  // src/biawgn.py:10
+        const double sigma = sqrt(var), k = 2.0 / var;
+        if (dtype == DT_F64)
+            hipLaunchKernelGGL(k_biawgn<double>, grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors);
+        else
+            hipLaunchKernelGGL(k_biawgn<float>, grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors);
+    } else if (channel == CH_BSC || channel == CH_BEC) {
+        if (!y) {
+            set_error("discrete channels need the y output buffer");
+            return LDPC_E_ARG;
+        }
+        if (!(param >= 0.0 && param <= 1.0)) {
+            set_error("channel probability %g outside [0,1]", param);
+            return LDPC_E_ARG;
+        }
+        // (w + 0.5) * 2^-32 < p  <=>  w < ceil(p * 2^32 - 0.5)
+        double t = ceil(param * 4294967296.0 - 0.5);
+        if (t < 0) t = 0;
+        const uint64_t thr = (uint64_t)t;
+        const double llr = log(1.0 - param) - log(param);  // src/bsc.py:21
+        if (channel == CH_BSC) {
+            if (dtype == DT_F64)
+                hipLaunchKernelGGL((k_discrete<double, CH_BSC>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, y);
+            else
+                hipLaunchKernelGGL((k_discrete<float, CH_BSC>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, y);
+        } else {
+            hipLaunchKernelGGL((k_discrete<float, CH_BEC>), grid, block, 0, st, thr, 0.0, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)nullptr, y);
+        }
+    } else {
+        set_error("unknown channel id %d", channel);
+        return LDPC_E_ARG;
+    }
+    LDPC_HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+int count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const int32_t* iters, int64_t B, int32_t n,
+                 int32_t hist_bins, int64_t* counters, hipStream_t st) {
+    if (B <= 0) return LDPC_OK;
+    hipLaunchKernelGGL(k_count, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, xhat, sent, codeword, iters, B, n, hist_bins,
+                       (unsigned long long*)counters);
+    LDPC_HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+}  // namespace ldpc

@@ -1,0 +1,112 @@
+// Shared declarations of the gfx950 LDPC belief-propagation library (libldpc_hip.so).
+//
+// Data model:
+//   * H is flattened once into a row-major edge list (edge k = (chk[k], var[k]), the order of
+//     np.where(H) used by the reference, src/bpa.py:12) + CSR row pointers + CSC lists, resident in HBM.
+//   * Frames are processed in TILES of 64: one wavefront lane <-> one frame, so every H index is
+//     wave-uniform (scalar loads) and every message access is one contiguous 64-element line.
+//   * Streaming backend: per tile, messages live in HBM as msg[tile][edge][64]; one array is updated
+//     in place by the check pass (v2c -> c2v) and the variable pass (c2v -> v2c).
+//   * Fused backend (regular codes whose state fits the LDS): one wavefront owns one frame for all
+//     iterations; messages never leave the CU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/ldpc_hip.h"
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace ldpc {
+
+enum Alg : int { ALG_MSA = 0, ALG_SPA = 1, ALG_BEC = 2 };
+enum DType : int { DT_F32 = 0, DT_F64 = 1 };
+enum Backend : int { BK_AUTO = 0, BK_STREAM = 1, BK_FUSED = 2 };
+enum Channel : int { CH_BIAWGN = 0, CH_BSC = 1, CH_BEC = 2 };
+
+constexpr int TILE = 64;  // frames per tile == wavefront width on gfx950
+
+// error codes returned over the C ABI come from include/ldpc_hip.h (LDPC_E_*); 0 == success
+constexpr int LDPC_OK = 0;
+
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define LDPC_HIP_TRY(expr)                                                                          \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            ::ldpc::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return LDPC_E_HIP;                                                              \
+        }                                                                                           \
+    } while (0)
+
+#define LDPC_TRY(expr)            \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// Tanner graph resident on one device.
+struct Code {
+    int device = 0;
+    int32_t m = 0, n = 0;
+    int64_t E = 0;
+    int32_t max_dc = 0, min_dc = 0, max_dv = 0, min_dv = 0;
+    // device arrays
+    int32_t* d_row_ptr = nullptr;   // [m+1]
+    int32_t* d_edge_var = nullptr;  // [E]  variable of edge k (row-major edge order)
+    int32_t* d_edge_chk = nullptr;  // [E]
+    int32_t* d_col_ptr = nullptr;   // [n+1]
+    int32_t* d_col_edge = nullptr;  // [E]  edges of variable v in ascending edge order
+    // host mirrors
+    std::vector<int32_t> row_ptr, edge_var, edge_chk, col_ptr, col_edge;
+};
+
+// Growable device buffer owned by a decoder (workspace is kept between calls).
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need);
+    void release();
+};
+
+struct FusedPlan;  // ldpc_fused.hip
+
+struct Decoder {
+    Code* code = nullptr;
+    int alg = ALG_MSA, dtype = DT_F32, backend = BK_AUTO;
+    // streaming workspace
+    DevBuf msg, prior, xbits, xera, live, flags, scratch;
+    // fused backend
+    FusedPlan* fused = nullptr;
+    // staging used by the *_host entry points
+    DevBuf h_in, h_y0, h_out, h_iters;
+    void* pinned = nullptr;  // small page-locked host block (polling word, counters)
+    // statistics of the last decode call
+    int last_sweeps = 0;
+    int last_backend = BK_STREAM;
+};
+
+// ---- backends (each returns an LDPC_* code) -------------------------------------------------------
+int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
+                  uint8_t* xhat, int32_t* iters, void* soft_out, hipStream_t st);
+
+int fused_plan_create(Decoder* d);
+void fused_plan_destroy(Decoder* d);
+bool fused_supported(const Decoder* d);
+int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
+                 uint8_t* xhat, int32_t* iters, hipStream_t st);
+
+// ---- channel / counting kernels -------------------------------------------------------------------
+int channel_generate(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id,
+                     uint64_t frame0, int64_t B, int32_t n, void* priors, uint8_t* y, hipStream_t st);
+int count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const int32_t* iters, int64_t B, int32_t n,
+                 int32_t max_iter_hist, int64_t* counters, hipStream_t st);
+
+constexpr uint32_t FLAG_NO_EARLY_EXIT = 1u;  // run exactly max_iter sweeps (NOT reference behaviour; benchmarking aid)
+
+}  // namespace ldpc

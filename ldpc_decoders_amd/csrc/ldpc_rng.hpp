@@ -1,0 +1,39 @@
+// Counter-based RNG for the on-device channel kernels: Philox4x32-10
+// (Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11).
+// Keyed by (seed); counter = (block j within the frame, stream id, global frame index lo, hi), so the
+// noise of a frame depends only on (seed, stream, frame index): results are identical for any sharding
+// of the frame range over GPUs.  oracle/bp_oracle.py::philox4x32 is the bit-exact CPU statement.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ldpc {
+
+struct Philox4 {
+    uint32_t w[4];
+};
+
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                          uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Philox4{{c0, c1, c2, c3}};
+}
+
+// words 4j .. 4j+3 of frame `frame` in stream `stream`
+__host__ __device__ __forceinline__ Philox4 philox_word_block(uint64_t seed, uint32_t stream, uint64_t frame, uint32_t j) {
+    return philox4x32_10(j, stream, (uint32_t)frame, (uint32_t)(frame >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+}  // namespace ldpc

@@ -1,0 +1,532 @@
+// Streaming backend: flooding BP with the message array resident in HBM.
+//
+// Layout per tile of 64 frames (lane == frame):
+//     msg  [tile][E][64]   T     one array, updated IN PLACE: check pass turns v2c into c2v, variable pass back
+//     prior[tile][n][64]   T
+//     xbits[tile][n]       u64   hard decision of variable v for the 64 frames (bit f == frame f)
+//     xera [tile][n]       u64   (erasure decoder only) "still erased" plane
+//     live [tile]          u64   frames that are still iterating
+// Every H index is wave-uniform (scalar loads); every message access is one contiguous 64-element line.
+// Algorithmic HBM traffic per frame-iteration = sizeof(T) * (4E + n)   (SURVEY.md section 8(d)).
+//
+// Reference semantics reproduced (file:line relative to thadikari/ldpc_decoders):
+//   flooding loop, max_iter and syndrome exits, x_hat = (marginal < 0) ...... src/bpa.py:17-63
+//   iteration-0 check of the received word (BSC) ............................ src/bpa.py:20,29
+//   variable update: prior + (((0 + c_a) + c_b) + ...) in ascending edge order  src/bpa.py:35, src/math_utils.py:7
+//   erasure decoder incl. "no change" (stopping set) exit .................... src/bec.py:83-122
+#include "ldpc_cn.hpp"
+#include "ldpc_common.hpp"
+
+namespace ldpc {
+
+namespace {
+
+using u64 = unsigned long long;
+
+__device__ __forceinline__ u64 wave_or(u64 x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)(x & 0xffffffffull), off, 64);
+        const unsigned hi = __shfl_xor((unsigned)(x >> 32), off, 64);
+        x |= ((u64)hi << 32) | lo;
+    }
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// priors [B,n] (frame-major, as numpy hands them over) -> prior tile [n][64]; optional hard word y0 -> planes.
+// BEC: the "prior" is the ternary message {-1,+1,0}[y] (src/bec.py:76,85) and y itself seeds both planes.
+template <typename T, int ALG>
+__global__ __launch_bounds__(256) void k_load_tile(const T* __restrict__ priors, const uint8_t* __restrict__ y0, int64_t B,
+                                                   int n, T* __restrict__ prior_t, u64* __restrict__ xbits,
+                                                   u64* __restrict__ xera, u64* __restrict__ flags) {
+    __shared__ T sp[64][65];
+    __shared__ uint8_t sy[64][68];
+    const int tile = blockIdx.y, v0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int f = ty; f < 64; f += 4) {
+        const int64_t fr = (int64_t)tile * 64 + f;
+        const int v = v0 + tx;
+        T val = T(0);
+        uint8_t yy = 0;
+        if (fr < B && v < n) {
+            if (y0) yy = y0[fr * n + v];
+            if constexpr (ALG == ALG_BEC) {
+                val = (T)(yy == 0 ? -1 : (yy == 1 ? 1 : 0));
+            } else {
+                val = priors[fr * n + v];
+            }
+        }
+        sp[f][tx] = val;
+        sy[f][tx] = yy;
+    }
+    __syncthreads();
+    u64 era_any = 0;
+    for (int vv = ty; vv < 64; vv += 4) {
+        const int v = v0 + vv;
+        if (v < n) {
+            prior_t[((int64_t)tile * n + v) * 64 + tx] = sp[tx][vv];
+            const uint8_t s = sy[tx][vv];
+            if constexpr (ALG == ALG_BEC) {
+                const u64 one = __ballot(s == 1), era = __ballot(s >= 2);
+                if (tx == 0) {
+                    xbits[(int64_t)tile * n + v] = one;
+                    xera[(int64_t)tile * n + v] = era;
+                }
+                era_any |= era;
+            } else if (y0) {
+                const u64 one = __ballot(s != 0);
+                if (tx == 0) xbits[(int64_t)tile * n + v] = one;
+            }
+        }
+    }
+    if constexpr (ALG == ALG_BEC) {
+        if (tx == 0 && era_any) atomicOr(&flags[2 * tile + 1], era_any);
+    }
+}
+
+__global__ void k_init_live(u64* __restrict__ live, int64_t B, int tiles) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    const int64_t rem = B - (int64_t)t * 64;
+    live[t] = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Check pass.  One wavefront = (tile, contiguous run of checks); UNR checks are in flight together so that
+// UNR*dc independent 256-byte (fp32) lines are outstanding per wave.
+template <typename T, int ALG, int DCMAX, int FIXED_DC, int UNR>
+__global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
+                                            T* __restrict__ msg, const T* __restrict__ prior_t,
+                                            const u64* __restrict__ live, int m, int n, int64_t E, int tiles, int chunks,
+                                            int cpw, int first) {
+    const int lane = threadIdx.x;
+    const int task = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + threadIdx.y));
+    const int tile = task / chunks, chunk = task - tile * chunks;
+    if (tile >= tiles) return;
+    const u64 lv = live[tile];
+    if (lv == 0) return;
+    const bool on = (lv >> lane) & 1ull;
+    T* mt = msg + (int64_t)tile * E * 64 + lane;
+    const T* pt = prior_t + (int64_t)tile * n * 64 + lane;
+    const int c_end = min(m, (chunk + 1) * cpw);
+    for (int c = chunk * cpw; c < c_end; c += UNR) {
+        T v[UNR][DCMAX];
+        int k0[UNR], deg[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int cc = c + u;
+            if (cc < c_end) {
+                if constexpr (FIXED_DC > 0) {
+                    k0[u] = cc * FIXED_DC;
+                    deg[u] = FIXED_DC;
+                } else {
+                    k0[u] = row_ptr[cc];
+                    deg[u] = row_ptr[cc + 1] - k0[u];
+                }
+            } else {
+                k0[u] = 0;
+                deg[u] = 0;
+            }
+        }
+        if (on) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+                for (int j = 0; j < DCMAX; ++j) {
+                    if (j < deg[u]) {
+                        v[u][j] = first ? pt[(int64_t)edge_var[k0[u] + j] * 64] : mt[(int64_t)(k0[u] + j) * 64];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                cn_rule<T, ALG, DCMAX>(v[u], deg[u]);
+#pragma unroll
+                for (int j = 0; j < DCMAX; ++j) {
+                    if (j < deg[u]) mt[(int64_t)(k0[u] + j) * 64] = v[u][j];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Variable pass: marginal = prior + ordered sum of c2v ; v2c = marginal - c2v (in place) ; decision bit.
+template <typename T, int ALG, int DVMAX, int UNR>
+__global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ col_edge,
+                                            T* __restrict__ msg, const T* __restrict__ prior_t,
+                                            const u64* __restrict__ live, u64* __restrict__ xbits, u64* __restrict__ xera,
+                                            u64* __restrict__ flags, T* __restrict__ soft_t, int n, int64_t E, int tiles,
+                                            int chunks, int vpw) {
+    const int lane = threadIdx.x;
+    const int task = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + threadIdx.y));
+    const int tile = task / chunks, chunk = task - tile * chunks;
+    if (tile >= tiles) return;
+    const u64 lv = live[tile];
+    if (lv == 0) return;
+    const bool on = (lv >> lane) & 1ull;
+    T* mt = msg + (int64_t)tile * E * 64 + lane;
+    const T* pt = prior_t + (int64_t)tile * n * 64 + lane;
+    T* sft = soft_t ? soft_t + (int64_t)tile * n * 64 + lane : nullptr;
+    u64* xb = xbits + (int64_t)tile * n;
+    u64* xe = (ALG == ALG_BEC) ? xera + (int64_t)tile * n : nullptr;
+    u64 chg = 0, era_any = 0;
+    const int v_end = min(n, (chunk + 1) * vpw);
+    for (int vbase = chunk * vpw; vbase < v_end; vbase += UNR) {
+        T c[UNR][DVMAX];
+        T pr[UNR];
+        int p0[UNR], deg[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int vv = vbase + u;
+            if (vv < v_end) {
+                p0[u] = col_ptr[vv];
+                deg[u] = col_ptr[vv + 1] - p0[u];
+            } else {
+                p0[u] = 0;
+                deg[u] = -1;
+            }
+        }
+        if (on) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (deg[u] >= 0) pr[u] = pt[(int64_t)(vbase + u) * 64];
+#pragma unroll
+                for (int j = 0; j < DVMAX; ++j) {
+                    if (j < deg[u]) c[u][j] = mt[(int64_t)col_edge[p0[u] + j] * 64];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (deg[u] < 0) continue;  // wave-uniform
+            bool b_one = false, b_era = false;
+            if (on) {
+                if constexpr (ALG == ALG_BEC) {
+                    int s = 0;
+#pragma unroll
+                    for (int j = 0; j < DVMAX; ++j)
+                        if (j < deg[u]) s += c[u][j];
+                    const int marg = (int)pr[u] + s;
+#pragma unroll
+                    for (int j = 0; j < DVMAX; ++j) {
+                        if (j < deg[u]) {
+                            const int d = marg - (int)c[u][j];
+                            mt[(int64_t)col_edge[p0[u] + j] * 64] = (T)((d > 0) - (d < 0));
+                        }
+                    }
+                    b_one = marg > 0;
+                    b_era = marg == 0;
+                } else {
+                    T s = T(0);
+#pragma unroll
+                    for (int j = 0; j < DVMAX; ++j)
+                        if (j < deg[u]) s += c[u][j];
+                    const T marg = pr[u] + s;
+#pragma unroll
+                    for (int j = 0; j < DVMAX; ++j)
+                        if (j < deg[u]) mt[(int64_t)col_edge[p0[u] + j] * 64] = marg - c[u][j];
+                    b_one = marg < T(0);  // NaN marginal -> 0 (src/bpa.py:38,62)
+                    if (sft) sft[(int64_t)(vbase + u) * 64] = marg;
+                }
+            }
+            const u64 one = __ballot(b_one);
+            const int vv = vbase + u;
+            if constexpr (ALG == ALG_BEC) {
+                const u64 era = __ballot(b_era);
+                const u64 old1 = xb[vv], olde = xe[vv];
+                const u64 new1 = (old1 & ~lv) | (one & lv), newe = (olde & ~lv) | (era & lv);
+                chg |= (old1 ^ new1) | (olde ^ newe);
+                era_any |= newe & lv;
+                if (lane == 0) {
+                    xb[vv] = new1;
+                    xe[vv] = newe;
+                }
+            } else {
+                u64 merged = one;
+                if (lv != ~0ull) merged = (xb[vv] & ~lv) | (one & lv);
+                if (lane == 0) xb[vv] = merged;
+            }
+        }
+    }
+    if constexpr (ALG == ALG_BEC) {
+        if (lane == 0) {
+            if (chg) atomicOr(&flags[2 * tile], chg);
+            if (era_any) atomicOr(&flags[2 * tile + 1], era_any);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Syndrome of the current hard decisions; frames whose syndrome is zero leave (iters = sweeps run so far).
+__global__ __launch_bounds__(256) void k_syndrome(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
+                                                  const u64* __restrict__ xbits, u64* __restrict__ live,
+                                                  int32_t* __restrict__ iters, int* __restrict__ live_tiles, int m, int n,
+                                                  int64_t B, int sweeps) {
+    __shared__ u64 s_un;
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const u64 lv = live[tile];
+    if (lv == 0) return;
+    if (t == 0) s_un = 0;
+    __syncthreads();
+    const u64* xb = xbits + (int64_t)tile * n;
+    u64 acc = 0;
+    for (int c = t; c < m; c += 256) {
+        u64 par = 0;
+        for (int k = row_ptr[c]; k < row_ptr[c + 1]; ++k) par ^= xb[edge_var[k]];
+        acc |= par;
+    }
+    acc = wave_or(acc);
+    if ((t & 63) == 0 && acc) atomicOr(&s_un, acc);
+    __syncthreads();
+    const u64 unsat = s_un;
+    const u64 stay = lv & unsat, leave = lv & ~unsat;
+    if (t == 0) {
+        live[tile] = stay;
+        if (stay && live_tiles) atomicAdd(live_tiles, 1);
+    }
+    if (t < 64 && ((leave >> t) & 1ull)) {
+        const int64_t fr = (int64_t)tile * 64 + t;
+        if (fr < B) iters[fr] = sweeps;
+    }
+}
+
+// Erasure decoder exit test (src/bec.py:97,120): keep iterating only while erasures remain AND the last sweep changed x_hat.
+__global__ void k_bec_check(u64* __restrict__ flags, u64* __restrict__ live, int32_t* __restrict__ iters,
+                            int* __restrict__ live_tiles, int64_t B, int tiles, int sweeps) {
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const u64 lv = live[tile];
+    if (lv == 0) return;
+    const u64 chg = sweeps == 0 ? ~0ull : flags[2 * tile];
+    const u64 era = flags[2 * tile + 1];
+    const u64 stay = lv & chg & era, leave = lv & ~stay;
+    __syncthreads();
+    if (t == 0) {
+        live[tile] = stay;
+        flags[2 * tile] = 0;
+        flags[2 * tile + 1] = 0;
+        if (stay && live_tiles) atomicAdd(live_tiles, 1);
+    }
+    if ((leave >> t) & 1ull) {
+        const int64_t fr = (int64_t)tile * 64 + t;
+        if (fr < B) iters[fr] = sweeps;
+    }
+}
+
+// Frames that hit max_iter: iters = sweeps ; then planes -> x_hat bytes [B,n] in {0,1} ({0,1,2} for BEC).
+__global__ void k_finish_iters(const u64* __restrict__ live, int32_t* __restrict__ iters, int64_t B, int sweeps) {
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const u64 lv = live[tile];
+    const int64_t fr = (int64_t)tile * 64 + t;
+    if (((lv >> t) & 1ull) && fr < B) iters[fr] = sweeps;
+}
+
+// marginal tile [n][64] -> [B,n] (diagnostic / soft-output path; not on the throughput path)
+template <typename T>
+__global__ void k_soft_out(const T* __restrict__ soft_t, T* __restrict__ out, int64_t B, int n) {
+    const int tile = blockIdx.y, lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t fr = (int64_t)tile * 64 + lane;
+    if (v < n && fr < B) out[fr * n + v] = soft_t[((int64_t)tile * n + v) * 64 + lane];
+}
+
+template <int ALG>
+__global__ __launch_bounds__(256) void k_unpack(const u64* __restrict__ xbits, const u64* __restrict__ xera,
+                                                uint8_t* __restrict__ xhat, int64_t B, int n) {
+    const int tile = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const u64 one = xbits[(int64_t)tile * n + v];
+    u64 era = 0;
+    if constexpr (ALG == ALG_BEC) era = xera[(int64_t)tile * n + v];
+    const int64_t f0 = (int64_t)tile * 64;
+    const int fmax = (int)min((int64_t)64, B - f0);
+    for (int f = 0; f < fmax; ++f) {
+        uint8_t s = (uint8_t)((one >> f) & 1ull);
+        if constexpr (ALG == ALG_BEC) s = ((era >> f) & 1ull) ? (uint8_t)2 : s;
+        xhat[(f0 + f) * n + v] = s;
+    }
+}
+
+int pick_pow2_ge(int x, int lo, int hi) {
+    int p = lo;
+    while (p < x && p < hi) p <<= 1;
+    return p;
+}
+
+// nodes kept in flight per wave: about 32 VGPRs (128 bytes per lane) of messages, at most 4 nodes
+constexpr int unroll_for(int row_bytes) { return row_bytes * 4 <= 128 ? 4 : (row_bytes * 2 <= 128 ? 2 : 1); }
+
+struct Geometry {
+    int tiles, cn_chunks, cpw, vn_chunks, vpw;
+};
+
+template <typename T, int ALG, int DCMAX, int FIXED_DC>
+void launch_cn(const Code* c, T* msg, const T* prior, const u64* live, const Geometry& g, int first, hipStream_t st) {
+    constexpr int UNR = unroll_for(DCMAX * (int)sizeof(T));
+    const int tasks = g.tiles * g.cn_chunks;
+    hipLaunchKernelGGL((k_cn<T, ALG, DCMAX, FIXED_DC, UNR>), dim3((tasks + 3) / 4), dim3(64, 4), 0, st, c->d_row_ptr,
+                       c->d_edge_var, msg, prior, live, c->m, c->n, c->E, g.tiles, g.cn_chunks, g.cpw, first);
+}
+
+template <typename T, int ALG, int DVMAX>
+void launch_vn(const Code* c, T* msg, const T* prior, const u64* live, u64* xbits, u64* xera, u64* flags, T* soft,
+               const Geometry& g, hipStream_t st) {
+    constexpr int UNR = unroll_for(DVMAX * (int)sizeof(T));
+    const int tasks = g.tiles * g.vn_chunks;
+    hipLaunchKernelGGL((k_vn<T, ALG, DVMAX, UNR>), dim3((tasks + 3) / 4), dim3(64, 4), 0, st, c->d_col_ptr, c->d_col_edge,
+                       msg, prior, live, xbits, xera, flags, soft, c->n, c->E, g.tiles, g.vn_chunks, g.vpw);
+}
+
+template <typename T, int ALG>
+int dispatch_cn(const Code* c, T* msg, const T* prior, const u64* live, const Geometry& g, int first, hipStream_t st) {
+    const bool regular = c->min_dc == c->max_dc;
+    if (regular && c->max_dc == 6) {
+        launch_cn<T, ALG, 6, 6>(c, msg, prior, live, g, first, st);
+        return 0;
+    }
+    switch (pick_pow2_ge(c->max_dc, 4, 64)) {
+        case 4: launch_cn<T, ALG, 4, 0>(c, msg, prior, live, g, first, st); break;
+        case 8: launch_cn<T, ALG, 8, 0>(c, msg, prior, live, g, first, st); break;
+        case 16: launch_cn<T, ALG, 16, 0>(c, msg, prior, live, g, first, st); break;
+        case 32: launch_cn<T, ALG, 32, 0>(c, msg, prior, live, g, first, st); break;
+        default: launch_cn<T, ALG, 64, 0>(c, msg, prior, live, g, first, st); break;
+    }
+    return 0;
+}
+
+template <typename T, int ALG>
+int dispatch_vn(const Code* c, T* msg, const T* prior, const u64* live, u64* xbits, u64* xera, u64* flags, T* soft,
+                const Geometry& g, hipStream_t st) {
+    switch (pick_pow2_ge(c->max_dv, 4, 64)) {
+        case 4: launch_vn<T, ALG, 4>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
+        case 8: launch_vn<T, ALG, 8>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
+        case 16: launch_vn<T, ALG, 16>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
+        case 32: launch_vn<T, ALG, 32>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
+        default: launch_vn<T, ALG, 64>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
+    }
+    return 0;
+}
+
+template <typename T, int ALG>
+int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags_in, uint8_t* xhat,
+        int32_t* iters, void* soft_out, hipStream_t st) {
+    const Code* c = d->code;
+    const int n = c->n, m = c->m;
+    const int64_t E = c->E;
+    const int tiles = (int)((B + 63) / 64);
+    if (c->max_dc > 64 || c->max_dv > 64) {
+        set_error("streaming backend supports node degrees up to 64 (max_dc=%d, max_dv=%d)", c->max_dc, c->max_dv);
+        return LDPC_E_UNSUPPORTED;
+    }
+    LDPC_TRY(d->msg.reserve((size_t)tiles * E * 64 * sizeof(T)));
+    LDPC_TRY(d->prior.reserve((size_t)tiles * n * 64 * sizeof(T)));
+    LDPC_TRY(d->xbits.reserve((size_t)tiles * n * 8));
+    LDPC_TRY(d->live.reserve((size_t)tiles * 8));
+    LDPC_TRY(d->flags.reserve((size_t)tiles * 16 + 64));
+    if (ALG == ALG_BEC) LDPC_TRY(d->xera.reserve((size_t)tiles * n * 8));
+    T* soft_t = nullptr;
+    if (soft_out && ALG != ALG_BEC) {
+        LDPC_TRY(d->scratch.reserve((size_t)tiles * n * 64 * sizeof(T)));
+        soft_t = (T*)d->scratch.p;
+        LDPC_HIP_TRY(hipMemsetAsync(soft_t, 0, (size_t)tiles * n * 64 * sizeof(T), st));
+    }
+    T* msg = (T*)d->msg.p;
+    T* prior = (T*)d->prior.p;
+    u64* xbits = (u64*)d->xbits.p;
+    u64* xera = (u64*)d->xera.p;
+    u64* live = (u64*)d->live.p;
+    u64* tflags = (u64*)d->flags.p;                         // [tiles][2]
+    int* live_tiles = (int*)((char*)d->flags.p + (size_t)tiles * 16);  // one polling counter
+    int* h_poll = (int*)d->pinned;
+
+    Geometry g;
+    g.tiles = tiles;
+    // aim for >= ~16k wave tasks per launch when the batch allows it, 4..64 nodes per wave otherwise
+    auto per_wave = [&](int nodes) {
+        long want = ((long)nodes * tiles + 16383) / 16384;
+        long v = want < 4 ? 4 : (want > 64 ? 64 : want);
+        v = (v + 3) / 4 * 4;
+        return (int)(v > nodes ? ((nodes + 3) / 4 * 4) : v);
+    };
+    g.cpw = per_wave(m);
+    g.cn_chunks = (m + g.cpw - 1) / g.cpw;
+    g.vpw = per_wave(n);
+    g.vn_chunks = (n + g.vpw - 1) / g.vpw;
+
+    LDPC_HIP_TRY(hipMemsetAsync(xbits, 0, (size_t)tiles * n * 8, st));
+    LDPC_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)tiles * 16 + 64, st));
+    LDPC_HIP_TRY(hipMemsetAsync(iters, 0, (size_t)B * sizeof(int32_t), st));
+    hipLaunchKernelGGL((k_load_tile<T, ALG>), dim3((n + 63) / 64, tiles), dim3(256), 0, st, (const T*)priors_v, y0, B, n,
+                       prior, xbits, xera, tflags);
+    hipLaunchKernelGGL(k_init_live, dim3((tiles + 255) / 256), dim3(256), 0, st, live, B, tiles);
+
+    const bool early = !(flags_in & FLAG_NO_EARLY_EXIT);
+    const int cap = max_iter > 0 ? max_iter : 100000;  // max_iter <= 0 == unlimited upstream (src/bpa.py:28); bounded here
+    // how often the host looks at the live-tile counter: about every 300 us of streaming work
+    const double iter_us = 15.0 + (double)tiles * 64.0 * sizeof(T) * (4.0 * E + n) / 4.0e6;
+    int poll_every = (int)(300.0 / iter_us);
+    poll_every = poll_every < 1 ? 1 : (poll_every > 16 ? 16 : poll_every);
+    int sweeps = 0;
+    for (int it = 0; it < cap; ++it) {
+        const bool check = early && (ALG == ALG_BEC || it > 0 || y0 != nullptr);
+        if (check) {
+            const bool poll = (it % poll_every) == 0 || max_iter <= 0;
+            if (poll) LDPC_HIP_TRY(hipMemsetAsync(live_tiles, 0, sizeof(int), st));
+            if (ALG == ALG_BEC) {
+                hipLaunchKernelGGL(k_bec_check, dim3(tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr,
+                                   B, tiles, sweeps);
+            } else {
+                hipLaunchKernelGGL(k_syndrome, dim3(tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, xbits, live, iters,
+                                   poll ? live_tiles : nullptr, m, n, B, sweeps);
+            }
+            if (poll) {
+                LDPC_HIP_TRY(hipMemcpyAsync(h_poll, live_tiles, sizeof(int), hipMemcpyDeviceToHost, st));
+                LDPC_HIP_TRY(hipStreamSynchronize(st));
+                if (*h_poll == 0) break;
+            }
+        }
+        dispatch_cn<T, ALG>(c, msg, prior, live, g, it == 0 ? 1 : 0, st);
+        dispatch_vn<T, ALG>(c, msg, prior, live, xbits, xera, tflags, soft_t, g, st);
+        ++sweeps;
+    }
+    hipLaunchKernelGGL(k_finish_iters, dim3(tiles), dim3(64), 0, st, live, iters, B, sweeps);
+    hipLaunchKernelGGL((k_unpack<ALG>), dim3((n + 255) / 256, tiles), dim3(256), 0, st, xbits, xera, xhat, B, n);
+    if (soft_t)
+        hipLaunchKernelGGL(k_soft_out<T>, dim3((n + 3) / 4, tiles), dim3(256), 0, st, soft_t, (T*)soft_out, B, n);
+    LDPC_HIP_TRY(hipGetLastError());
+    d->last_sweeps = sweeps;
+    d->last_backend = BK_STREAM;
+    return LDPC_OK;
+}
+
+}  // namespace
+
+int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
+                  uint8_t* xhat, int32_t* iters, void* soft_out, hipStream_t st) {
+    if (B <= 0) return LDPC_OK;
+    if (B > (int64_t)65535 * 64) {
+        set_error("batch of %lld frames exceeds one launch (max %d); split the call", (long long)B, 65535 * 64);
+        return LDPC_E_ARG;
+    }
+    if (d->alg == ALG_BEC) {
+        if (!y0) {
+            set_error("erasure decoder needs the received symbols (y0)");
+            return LDPC_E_ARG;
+        }
+        return run<int8_t, ALG_BEC>(d, nullptr, y0, B, max_iter, flags, xhat, iters, nullptr, st);
+    }
+    if (!priors) {
+        set_error("priors pointer is null");
+        return LDPC_E_ARG;
+    }
+    if (d->alg == ALG_MSA) {
+        return d->dtype == DT_F64 ? run<double, ALG_MSA>(d, priors, y0, B, max_iter, flags, xhat, iters, soft_out, st)
+                                  : run<float, ALG_MSA>(d, priors, y0, B, max_iter, flags, xhat, iters, soft_out, st);
+    }
+    return d->dtype == DT_F64 ? run<double, ALG_SPA>(d, priors, y0, B, max_iter, flags, xhat, iters, soft_out, st)
+                              : run<float, ALG_SPA>(d, priors, y0, B, max_iter, flags, xhat, iters, soft_out, st);
+}
+
+}  // namespace ldpc

@@ -1,0 +1,98 @@
+"""Experiment driver -- the build's counterpart of the reference's ``src/main.py``.
+
+    python -m ldpc_decoders_amd.main <channel> <code> <decoder> [--codeword C --min-wec W --params P.. --max-iter I ..]
+
+Same positional/flag grammar, same logger names, same JSON result files (see ``utils``), so the arg-lines emitted by
+the reference's ``simulations.py`` run unchanged and ``graph.py`` reads the outputs.  Differences, all additive:
+frames are decoded in batches on the GPU; ``--exact`` selects the reference-exact mode (host noise, sequential
+stopping rule); under ``torchrun`` each rank drives one GPU and the counters are all-reduced once per round.
+"""
+import logging
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+from . import codes, dist, utils
+from .models import models
+from .montecarlo import DeviceSimulator, run_point_exact
+
+
+def test(args, comm=None):
+    comm = comm or dist.Comm()
+    model = models[args.channel]
+    dec_fac = getattr(model, args.decoder)
+    id_keys = ["channel", "code", "decoder", "codeword", "min_wec"] + dec_fac.id_keys
+    id_val = [vars(args)[key] for key in id_keys]
+    log = logging.getLogger(".".join(utils.strl(id_val)))
+    code = codes.get_code(args.code)
+    code_n = code.get_n()
+    saver = utils.Saver(args.data_dir, list(zip(id_keys, id_val))) if comm.is_root else None
+    exact = bool(args.exact) or args.codeword == -1
+    if exact and comm.world > 1:
+        raise SystemExit("--exact / --codeword -1 follow the reference's sequential rule and run on a single rank")
+    if exact and args.np_seed is not None:
+        np.random.seed(args.np_seed)
+    kwargs = dict(vars(args))
+    kwargs["precision"] = args.precision or ("f64" if exact else "f32")
+    results = OrderedDict()
+
+    for pi, param in enumerate(args.params):
+        log.info("Starting parameter: %f" % param)
+        channel = model.Channel(param)
+        decoder = dec_fac(param, code, **kwargs)
+        state = dict(t=time.time())
+
+        def log_status(c, final=False):
+            tot, wec, bec = c["tot"], c["wec"], c["bec"]
+            wer, ber = (wec / tot, bec / (tot * code_n)) if tot else (0., 0.)
+            keys = ["tot", "wec", "wer", "bec", "ber"]
+            vals = [int(tot), int(wec), float(wer), int(bec), float(ber)]
+            if comm.is_root:
+                log.info(", ".join("%s:%s" % (k.upper(), v) for k, v in zip(keys, vals)))
+                saver.add(param, OrderedDict(zip(keys, vals)))
+            return OrderedDict(zip(keys, vals))
+
+        def progress(tot, wec, bec):
+            if time.time() - state["t"] > args.log_freq:
+                state["t"] = time.time()
+                log_status(dict(tot=tot, wec=wec, bec=bec))
+
+        if exact:
+            pick = None
+            if args.codeword == -1:
+                pick = lambda: code.cb[np.random.choice(code.cb.shape[0], 1)[0]]  # noqa: E731  (src/main.py:38)
+                x = code.cb[0]
+            else:
+                x = np.zeros(code_n, dtype=np.int64) + args.codeword
+            c = run_point_exact(channel, decoder, x, args.min_wec, chunk=1 if code_n < 64 else 32, on_progress=progress,
+                                pick_word=pick)
+        else:
+            handle = decoder.handle if hasattr(decoder, "handle") else decoder.dec.handle
+            sim = DeviceSimulator(handle, args.channel, args.max_iter, args.codeword, args.seed, comm)
+            c = sim.run_point(param, stream_id=pi, min_wec=args.min_wec, batch_per_rank=args.batch, on_progress=progress)
+        results[param] = log_status(c, final=True)
+    log.info("Done!")
+    return results
+
+
+def main(argv=None):
+    args = utils.setup_parser(codes.get_code_names(), models.keys(), utils.decoder_names).parse_args(argv)
+    comm = dist.init_from_env()
+    log_level = logging.DEBUG if args.debug else logging.INFO
+    if args.console:
+        utils.setup_console_logger(log_level)
+    else:
+        utils.make_dir_if_not_exists(args.data_dir)
+        utils.setup_file_logger(args.data_dir, "test", log_level)
+    if comm.is_root:
+        print(vars(args))
+    try:
+        return test(args, comm)
+    finally:
+        dist.finalize()
+
+
+if __name__ == "__main__":
+    # np.random is deliberately left unseeded, as upstream (src/main.py:68); use --np-seed / --seed for repeatability
+    main()
