@@ -58,6 +58,13 @@ int ldpc_decoder_destroy(ldpc_decoder_t dec);
 /* backend actually used by the last decode (LDPC_BACKEND_*) and the number of sweeps the batch ran */
 int ldpc_decoder_last_stats(ldpc_decoder_t dec, int* backend, int* sweeps);
 
+/* Per-kernel timing for roofline reports: when enabled, decode calls bracket their dominant kernels with HIP events
+ * recorded ON THE DECODE STREAM and accumulate elapsed milliseconds / launch counts per kernel class:
+ * [0] streaming check pass, [1] streaming variable pass, [2] fused decode kernel.  Enabling it makes every decode
+ * call end with a stream synchronise. */
+int ldpc_decoder_profile(ldpc_decoder_t dec, int enable);
+int ldpc_decoder_profile_read(ldpc_decoder_t dec, double* ms3, int64_t* launches3, int reset);
+
 /* Batched BPA.decode(y, priors) (src/bpa.py:17-63) / bec.SPA.decode(y) (src/bec.py:83-122).
  *   priors_dev  [B,n] float or double per `dtype` (ignored for LDPC_ALG_BEC)
  *   y0_dev      [B,n] uint8 or NULL: hard received word checked at iteration 0 (src/bpa.py:20,29: BSC), or

@@ -154,6 +154,16 @@ class DecoderHandle:
         _lib.check(_lib.load().ldpc_simulate(self.h, _lib.CHANNEL[channel], float(param), int(codeword), int(seed), int(stream_id),
                                              int(frame0), int(B), int(max_iter), flags, hist_bins, counters.data_ptr(), st))
 
+    def set_profiling(self, on):
+        _lib.check(_lib.load().ldpc_decoder_profile(self.h, 1 if on else 0))
+
+    def read_profile(self, reset=True):
+        """-> {kernel class: (milliseconds, launches)} accumulated since the last reset (HIP events on the decode stream)."""
+        ms = (ctypes.c_double * 3)()
+        ln = (ctypes.c_int64 * 3)()
+        _lib.check(_lib.load().ldpc_decoder_profile_read(self.h, ms, ln, 1 if reset else 0))
+        return {k: (ms[i], ln[i]) for i, k in enumerate(("stream_check_pass", "stream_variable_pass", "fused_decode"))}
+
     def last_stats(self):
         b, s = ctypes.c_int(0), ctypes.c_int(0)
         _lib.check(_lib.load().ldpc_decoder_last_stats(self.h, ctypes.byref(b), ctypes.byref(s)))

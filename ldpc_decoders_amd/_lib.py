@@ -31,6 +31,8 @@ SIGNATURES = {
     "ldpc_decoder_create": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_P)]),
     "ldpc_decoder_destroy": (_c.c_int, [_P]),
     "ldpc_decoder_last_stats": (_c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    "ldpc_decoder_profile": (_c.c_int, [_P, _c.c_int]),
+    "ldpc_decoder_profile_read": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.c_int]),
     "ldpc_decode": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P, _P]),
     "ldpc_decode_soft": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P, _P, _P]),
     "ldpc_decode_host": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P]),
@@ -55,6 +57,11 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise LdpcHipError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(or `make -C ldpc_decoders_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7 and owns the streams / device
+        # memory this library is handed.  Importing torch first makes the dynamic loader bind libldpc_hip.so to that
+        # already-loaded runtime (same soname) instead of a second copy from /opt/rocm.
+        import torch  # noqa: F401
+
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here == ABI mismatch with include/ldpc_hip.h

@@ -42,6 +42,26 @@ void DevBuf::release() {
     bytes = 0;
 }
 
+int prof_event(Decoder* d, size_t idx, hipEvent_t* out) {
+    while (d->ev_pool.size() <= idx) {
+        hipEvent_t e;
+        LDPC_HIP_TRY(hipEventCreate(&e));
+        d->ev_pool.push_back(e);
+    }
+    *out = d->ev_pool[idx];
+    return LDPC_OK;
+}
+
+int prof_collect(Decoder* d, const std::vector<ProfSpan>& spans) {
+    for (const ProfSpan& s : spans) {
+        float ms = 0.f;
+        LDPC_HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
+        d->prof_ms[s.kind] += ms;
+        d->prof_launches[s.kind] += 1;
+    }
+    return LDPC_OK;
+}
+
 namespace {
 template <typename T>
 int upload(const std::vector<T>& h, T** d) {
@@ -202,6 +222,7 @@ int ldpc_decoder_destroy(ldpc_decoder_t h) {
                       &d->h_iters})
         b->release();
     if (d->pinned) (void)hipHostFree(d->pinned);
+    for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
     delete d;
     return LDPC_OK;
 }
@@ -211,6 +232,27 @@ int ldpc_decoder_last_stats(ldpc_decoder_t h, int* backend, int* sweeps) {
     if (!d) return LDPC_E_ARG;
     if (backend) *backend = d->last_backend;
     if (sweeps) *sweeps = d->last_sweeps;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_profile(ldpc_decoder_t h, int enable) {
+    Decoder* d = (Decoder*)h;
+    if (!d) return LDPC_E_ARG;
+    d->profile = enable != 0;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_profile_read(ldpc_decoder_t h, double* ms, int64_t* launches, int reset) {
+    Decoder* d = (Decoder*)h;
+    if (!d) return LDPC_E_ARG;
+    for (int i = 0; i < 3; ++i) {
+        if (ms) ms[i] = d->prof_ms[i];
+        if (launches) launches[i] = d->prof_launches[i];
+        if (reset) {
+            d->prof_ms[i] = 0;
+            d->prof_launches[i] = 0;
+        }
+    }
     return LDPC_OK;
 }
 

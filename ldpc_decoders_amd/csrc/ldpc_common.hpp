@@ -86,10 +86,23 @@ struct Decoder {
     // staging used by the *_host entry points
     DevBuf h_in, h_y0, h_out, h_iters;
     void* pinned = nullptr;  // small page-locked host block (polling word, counters)
+    // optional per-kernel timing with HIP events recorded on the decode stream (bench.py roofline leg)
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[3] = {0, 0, 0};        // [0] check pass, [1] variable pass, [2] fused decode kernel
+    int64_t prof_launches[3] = {0, 0, 0};
     // statistics of the last decode call
     int last_sweeps = 0;
     int last_backend = BK_STREAM;
 };
+
+// event-pair bookkeeping used when Decoder::profile is set
+struct ProfSpan {
+    int kind;
+    hipEvent_t a, b;
+};
+int prof_event(Decoder* d, size_t idx, hipEvent_t* out);
+int prof_collect(Decoder* d, const std::vector<ProfSpan>& spans);
 
 // ---- backends (each returns an LDPC_* code) -------------------------------------------------------
 int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,

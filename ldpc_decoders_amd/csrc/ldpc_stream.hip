@@ -469,6 +469,8 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     int poll_every = (int)(300.0 / iter_us);
     poll_every = poll_every < 1 ? 1 : (poll_every > 16 ? 16 : poll_every);
     int sweeps = 0;
+    std::vector<ProfSpan> spans;
+    size_t ev_next = 0;
     for (int it = 0; it < cap; ++it) {
         const bool check = early && (ALG == ALG_BEC || it > 0 || y0 != nullptr);
         if (check) {
@@ -487,8 +489,21 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                 if (*h_poll == 0) break;
             }
         }
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        if (d->profile) {
+            LDPC_TRY(prof_event(d, ev_next++, &e0));
+            LDPC_TRY(prof_event(d, ev_next++, &e1));
+            LDPC_TRY(prof_event(d, ev_next++, &e2));
+            LDPC_HIP_TRY(hipEventRecord(e0, st));
+        }
         dispatch_cn<T, ALG>(c, msg, prior, live, g, it == 0 ? 1 : 0, st);
+        if (d->profile) LDPC_HIP_TRY(hipEventRecord(e1, st));
         dispatch_vn<T, ALG>(c, msg, prior, live, xbits, xera, tflags, soft_t, g, st);
+        if (d->profile) {
+            LDPC_HIP_TRY(hipEventRecord(e2, st));
+            spans.push_back({0, e0, e1});
+            spans.push_back({1, e1, e2});
+        }
         ++sweeps;
     }
     hipLaunchKernelGGL(k_finish_iters, dim3(tiles), dim3(64), 0, st, live, iters, B, sweeps);
@@ -496,6 +511,10 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     if (soft_t)
         hipLaunchKernelGGL(k_soft_out<T>, dim3((n + 3) / 4, tiles), dim3(256), 0, st, soft_t, (T*)soft_out, B, n);
     LDPC_HIP_TRY(hipGetLastError());
+    if (d->profile) {
+        LDPC_HIP_TRY(hipStreamSynchronize(st));
+        LDPC_TRY(prof_collect(d, spans));
+    }
     d->last_sweeps = sweeps;
     d->last_backend = BK_STREAM;
     return LDPC_OK;

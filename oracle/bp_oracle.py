@@ -169,6 +169,34 @@ def spa_check_update(g, v2c):
         return 2 * out
 
 
+def spa_phi_check_update(g, v2c):
+    """Sum-product check rule in the phi domain, leave-one-out, fp64 -- the statement the GPU's fp32 SPA mode follows:
+    |c2v_j| = phi(sum_{i != j} phi(|v2c_i|)) with phi(x) = -log(tanh(x/2)) = log1p(2/expm1(x)); sign as in min-sum.
+
+    Mathematically identical to ``spa_check_update`` (the reference formula).  It differs numerically only where the
+    reference leaves ordinary arithmetic: tanh saturating to exactly +-1 in fp64 (|LLR| >~ 38 -> +-inf, atanh(>1) = NaN
+    from exp(log(t))/t rounding, inf-inf = NaN -> marginal forced to 0) and v2c == 0 (0/0).  On frames whose messages
+    stay below saturation the two produce the same decisions (tests/test_oracle_golden.py::test_phi_rule_*)."""
+    with np.errstate(all="ignore"):
+        a = np.abs(v2c)
+        ph = np.log1p(2.0 / np.expm1(a))
+        tot_pre = np.zeros(a.shape[:-1] + (g.m,))
+        pre = np.empty_like(ph)
+        for idx in g.row_sets:  # prefix sums in edge order
+            c = g.chk[idx]
+            pre[..., idx] = tot_pre[..., c]
+            tot_pre[..., c] += ph[..., idx]
+        tot_suf = np.zeros(a.shape[:-1] + (g.m,))
+        mag = np.empty_like(ph)
+        for idx in reversed(g.row_sets):  # suffix sums, last edge first
+            c = g.chk[idx]
+            s = pre[..., idx] + tot_suf[..., c]
+            mag[..., idx] = np.log1p(2.0 / np.expm1(s))
+            tot_suf[..., c] += ph[..., idx]
+        flip = (_row_parity_sign(g, v2c)[..., g.chk] < 0) != ~(v2c >= 0)
+        return np.where(flip, -mag, mag)
+
+
 # --------------------------------------------------------------------------- flooding BP
 def syndrome_ok(g, word):
     """reference: ``((H @ x_hat) % 2 == 0).all()`` (src/bpa.py:29); ``word`` may be the
@@ -186,7 +214,7 @@ def bp_decode(g, alg, y, priors, max_iter, return_trace=False):
     ``return_trace`` additionally returns the list of marginals per sweep
     (NaN->0 applied, as the reference leaves them) for frames still running.
     """
-    cn = msa_check_update if alg == MSA else spa_check_update
+    cn = {MSA: msa_check_update, SPA: spa_check_update, "SPA_PHI": spa_phi_check_update}[alg]
     y = np.atleast_2d(np.asarray(y, dtype=np.float64))
     priors = np.atleast_2d(np.asarray(priors, dtype=np.float64))
     B = y.shape[0]
@@ -195,6 +223,7 @@ def bp_decode(g, alg, y, priors, max_iter, return_trace=False):
     live = np.ones(B, dtype=bool)
     v2c = priors[:, g.var].copy()
     trace = []
+    bp_decode.last_peak = np.zeros(B)  # largest |v2c| each frame ever fed to a check (saturation diagnostics)
     it = 0
     while live.any():
         if 0 < max_iter <= it:
@@ -204,6 +233,7 @@ def bp_decode(g, alg, y, priors, max_iter, return_trace=False):
             break
         L = np.flatnonzero(live)
         with np.errstate(all="ignore"):
+            bp_decode.last_peak[L] = np.fmax(bp_decode.last_peak[L], np.abs(v2c[L]).max(axis=1))
             c2v = cn(g, v2c[L])
             marginal = priors[L] + g.sum_cols(c2v)
             v2c[L] = marginal[:, g.var] - c2v
