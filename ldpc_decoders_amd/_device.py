@@ -154,6 +154,13 @@ class DecoderHandle:
         _lib.check(_lib.load().ldpc_simulate(self.h, _lib.CHANNEL[channel], float(param), int(codeword), int(seed), int(stream_id),
                                              int(frame0), int(B), int(max_iter), flags, hist_bins, counters.data_ptr(), st))
 
+    def fused_info(self):
+        out = (ctypes.c_double * 8)()
+        _lib.check(_lib.load().ldpc_decoder_fused_info(self.h, out))
+        keys = ("available", "lds_gather_cycles_min", "conflict_cycles_identity", "conflict_cycles_planned", "waves_per_cu",
+                "lds_bytes_per_wave", "check_rounds", "variable_rounds")
+        return dict(zip(keys, list(out)))
+
     def set_profiling(self, on):
         _lib.check(_lib.load().ldpc_decoder_profile(self.h, 1 if on else 0))
 

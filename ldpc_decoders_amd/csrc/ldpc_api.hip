@@ -235,6 +235,12 @@ int ldpc_decoder_last_stats(ldpc_decoder_t h, int* backend, int* sweeps) {
     return LDPC_OK;
 }
 
+int ldpc_decoder_fused_info(ldpc_decoder_t h, double* out8) {
+    Decoder* d = (Decoder*)h;
+    if (!d || !out8) return LDPC_E_ARG;
+    return fused_info(d, out8);
+}
+
 int ldpc_decoder_profile(ldpc_decoder_t h, int enable) {
     Decoder* d = (Decoder*)h;
     if (!d) return LDPC_E_ARG;

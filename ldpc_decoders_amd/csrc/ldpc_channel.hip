@@ -100,32 +100,47 @@ __global__ __launch_bounds__(256) void k_discrete(uint64_t thr, double llr, int 
     }
 }
 
-// one wavefront per frame
+// one wavefront per frame, grid-stride; counters are combined per block (LDS) before touching global atomics
 __global__ __launch_bounds__(256) void k_count(const uint8_t* __restrict__ xhat, const uint8_t* __restrict__ sent, int codeword,
                                                const int32_t* __restrict__ iters, int64_t B, int n, int hist_bins,
                                                unsigned long long* __restrict__ counters) {
+    extern __shared__ unsigned int s_hist[];  // [hist_bins]
+    __shared__ unsigned long long s_cnt[4];
+    for (int i = threadIdx.x; i < hist_bins; i += 256) s_hist[i] = 0;
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (f >= B) return;
-    int err = 0;
-    for (int v = lane; v < n; v += 64) {
-        const uint8_t want = sent ? sent[v] : (uint8_t)codeword;
-        err += xhat[f * n + v] != want;
-    }
+    unsigned long long tot = 0, wec = 0, bec = 0, itsum = 0;  // meaningful on lane 0 of each wave
+    for (int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); f < B; f += (int64_t)gridDim.x * 4) {
+        int err = 0;
+        const uint8_t* row = xhat + f * n;
+        for (int v = lane; v < n; v += 64) {
+            const uint8_t want = sent ? sent[v] : (uint8_t)codeword;
+            err += row[v] != want;
+        }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) err += __shfl_xor(err, off, 64);
-    if (lane == 0) {
-        atomicAdd(&counters[0], 1ull);
-        if (err) {
-            atomicAdd(&counters[1], 1ull);
-            atomicAdd(&counters[2], (unsigned long long)err);
-        }
-        if (iters) {
-            const int it = iters[f];
-            atomicAdd(&counters[3], (unsigned long long)it);
-            if (hist_bins > 0) atomicAdd(&counters[4 + (it < hist_bins ? it : hist_bins - 1)], 1ull);
+        for (int off = 32; off >= 1; off >>= 1) err += __shfl_xor(err, off, 64);
+        if (lane == 0) {
+            tot += 1;
+            wec += err > 0;
+            bec += (unsigned long long)err;
+            if (iters) {
+                const int it = iters[f];
+                itsum += (unsigned long long)it;
+                if (hist_bins > 0) atomicAdd(&s_hist[it < hist_bins ? it : hist_bins - 1], 1u);
+            }
         }
     }
+    if (lane == 0) {
+        atomicAdd(&s_cnt[0], tot);
+        atomicAdd(&s_cnt[1], wec);
+        atomicAdd(&s_cnt[2], bec);
+        atomicAdd(&s_cnt[3], itsum);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], s_cnt[threadIdx.x]);
+    for (int i = threadIdx.x; i < hist_bins; i += 256)
+        if (s_hist[i]) atomicAdd(&counters[4 + i], (unsigned long long)s_hist[i]);
 }
 
 }  // namespace
@@ -184,8 +199,14 @@ int channel_generate(int channel, int dtype, double param, int codeword, uint64_
 int count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const int32_t* iters, int64_t B, int32_t n,
                  int32_t hist_bins, int64_t* counters, hipStream_t st) {
     if (B <= 0) return LDPC_OK;
-    hipLaunchKernelGGL(k_count, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, xhat, sent, codeword, iters, B, n, hist_bins,
-                       (unsigned long long*)counters);
+    if (hist_bins > 8192) {
+        set_error("at most 8192 histogram bins");
+        return LDPC_E_ARG;
+    }
+    const int64_t want = (B + 3) / 4;
+    const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(k_count, dim3(grid), dim3(256), (size_t)hist_bins * sizeof(unsigned int), st, xhat, sent, codeword, iters, B, n,
+                       hist_bins, (unsigned long long*)counters);
     LDPC_HIP_TRY(hipGetLastError());
     return LDPC_OK;
 }

@@ -111,6 +111,7 @@ int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, 
 int fused_plan_create(Decoder* d);
 void fused_plan_destroy(Decoder* d);
 bool fused_supported(const Decoder* d);
+int fused_info(const Decoder* d, double* out8);
 int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
                  uint8_t* xhat, int32_t* iters, hipStream_t st);
 

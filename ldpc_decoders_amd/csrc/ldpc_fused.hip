@@ -23,7 +23,11 @@
 #include <algorithm>
 #include <numeric>
 
+#include <cstdlib>
+#include <type_traits>
+
 #include "ldpc_common.hpp"
+#include "ldpc_layout.hpp"
 
 namespace ldpc {
 
@@ -37,17 +41,38 @@ struct FusedPlan {
     unsigned long long* d_next = nullptr;       // frame dispenser
     size_t lds_bytes = 0;
     int waves_per_cu = 0, num_cu = 0;
+    double extra_identity = 0, extra_planned = 0, base_cycles = 0;
 };
 
 namespace {
 
 using u64 = unsigned long long;
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- needed where the index feeds an asm immediate
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 template <int K>
 __device__ __forceinline__ uint32_t half_of(const uint32_t (&tab)[(K + 1) / 2], int k) {
     const uint32_t w = tab[k >> 1];
     return (k & 1) ? (w >> 16) : (w & 0xffffu);
 }
+
+// Lane-contiguous LDS store without an address register: LDS[M0 + OFF + 4*lane] = v (ds_write_addtid_b32 moves one
+// source dword instead of two -> half the store-path cycles of ds_write_b32; MI355X_MICROARCH.md, LDS table).
+// Inline asm: the compiler does not count it in lgkmcnt; its own waits then only become more conservative
+// (LDS operations of a wave retire in order), never too early.
+template <int OFF>
+__device__ __forceinline__ void lds_st_tid(float v) {
+    static_assert(OFF >= 0 && OFF < 65536, "16-bit DS offset");
+    asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_set_m0(uint32_t base) { asm volatile("s_mov_b32 m0, %0" ::"s"(base) : "memory"); }
 
 __device__ __forceinline__ float lds_ld(const unsigned char* base, uint32_t byte_off) {
     return *reinterpret_cast<const float*>(base + byte_off);
@@ -115,7 +140,7 @@ __global__ __launch_bounds__(64, 2) void k_fused_msa(const float* __restrict__ p
                 u64 par = 0;
 #pragma unroll
                 for (int j = 0; j < DC; ++j) par ^= __ballot(lds_ld(smem, half_of<CR * DC>(cn_idx, r * DC + j)) < 0.0f);
-                unsat |= par & cn_active[r];
+                if constexpr (DC % 2 == 0) unsat |= par; else unsat |= par & cn_active[r];
             }
             left_at_0 = early && unsat == 0;
             __builtin_amdgcn_wave_barrier();
@@ -124,23 +149,42 @@ __global__ __launch_bounds__(64, 2) void k_fused_msa(const float* __restrict__ p
 #pragma unroll
             for (int q = 0; q < VR; ++q) lds_marg[q * 64 + lane] = prior[q];
             __builtin_amdgcn_wave_barrier();
+            // The sweep is one software-pipelined stream of LDS traffic: the gathers of check round r+1 (variable
+            // group g+1) are issued before round r (group g) is computed, so a wave always has a full round of
+            // ds_reads in flight while it does arithmetic.  (The wave is latency-bound otherwise: 2 waves per SIMD.)
+            constexpr int VG = 4;                      // variable rounds per pipeline stage
+            constexpr int NVG = (VR + VG - 1) / VG;
+            const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
             for (;;) {
                 if (max_iter > 0 && it >= max_iter) break;
+                lds_set_m0(lds_base);
                 // ---------------- check phase (+ syndrome of the decisions of the previous sweep)
-                u64 unsat = 0;
+                uint32_t synd = 0;  // bit 31: some owned check is unsatisfied by the previous decisions
+                float mg[2][DC];
 #pragma unroll
-                for (int r = 0; r < CR; ++r) {
+                for (int j = 0; j < DC; ++j) mg[0][j] = lds_ld(smem, half_of<CR * DC>(cn_idx, j));
+                static_for<0, CR>([&](auto R_) {
+                    constexpr int r = decltype(R_)::value;
+                    if constexpr (r + 1 < CR) {
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_ld(smem, half_of<CR * DC>(cn_idx, (r + 1) * DC + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this round's arithmetic
+                    // Sign handling on the raw IEEE bits (bit 31), all in the vector ALU: row parity = XOR of the sign
+                    // bits, extrinsic sign = parity ^ own sign.  Equivalent to the reference's comparisons
+                    // ((v < 0) for the parity, (v >= 0) for the own sign, src/math_utils.py:10,38-43) because v is never
+                    // -0.0 here: marginals are built as prior + ((0.0 + c_a) + c_b + c_c) (see the variable phase).
                     float v[DC], a[DC];
-                    u64 par = 0, negpar = 0;
+                    uint32_t vx = 0, mx = 0;
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
-                        const float mg = lds_ld(smem, half_of<CR * DC>(cn_idx, r * DC + j));
-                        par ^= __ballot(mg < 0.0f);
-                        v[j] = mg - c2v_old[r][j];
+                        const float m0 = mg[r & 1][j];
+                        mx ^= __float_as_uint(m0);
+                        v[j] = m0 - c2v_old[r][j];
                         a[j] = __builtin_fabsf(v[j]);
-                        negpar ^= __ballot(v[j] < 0.0f);
+                        vx ^= __float_as_uint(v[j]);
                     }
-                    unsat |= par & cn_active[r];
+                    if constexpr (DC % 2 == 0) synd |= mx; else synd |= ((cn_active[r] >> lane) & 1ull) ? mx : 0u;
                     // leave-one-out minimum of |v|
                     float pre[DC], suf[DC];
                     pre[0] = __builtin_huge_valf();
@@ -149,29 +193,49 @@ __global__ __launch_bounds__(64, 2) void k_fused_msa(const float* __restrict__ p
                     suf[DC - 1] = __builtin_huge_valf();
 #pragma unroll
                     for (int j = DC - 2; j >= 0; --j) suf[j] = fminf(suf[j + 1], a[j + 1]);
-                    const bool row_neg = (negpar >> lane) & 1ull;
-#pragma unroll
-                    for (int j = 0; j < DC; ++j) {
+                    static_for<0, DC>([&](auto J_) {
+                        constexpr int j = decltype(J_)::value;
                         const float mag = fminf(pre[j], suf[j]);
-                        const bool own_neg = !(v[j] >= 0.0f);
-                        const float c = (row_neg != own_neg) ? -mag : mag;
+                        const float c = __uint_as_float(__float_as_uint(mag) | ((vx ^ __float_as_uint(v[j])) & 0x80000000u));
                         c2v_old[r][j] = c;
-                        lds_c2v[(r * DC + j) * 64 + lane] = c;
-                    }
-                }
+                        lds_st_tid<(NPAD + (r * DC + j) * 64) * 4>(c);
+                    });
+                });
+                const u64 unsat = __ballot((synd & 0x80000000u) != 0u);
                 if (early && it > 0 && unsat == 0) break;
                 __builtin_amdgcn_wave_barrier();
                 // ---------------- variable phase
                 xb = 0;
+                float cv[2][VG][DV];
 #pragma unroll
-                for (int q = 0; q < VR; ++q) {
-                    float s = lds_ld(smem, half_of<VR * DV>(vn_idx, q * DV));
+                for (int u = 0; u < VG; ++u)
 #pragma unroll
-                    for (int j = 1; j < DV; ++j) s += lds_ld(smem, half_of<VR * DV>(vn_idx, q * DV + j));
-                    const float mg = prior[q] + s;
-                    lds_marg[q * 64 + lane] = mg;
-                    xb |= (mg < 0.0f) ? (1u << q) : 0u;
-                }
+                    for (int j = 0; j < DV; ++j)
+                        if (u < VR) cv[0][u][j] = lds_ld(smem, half_of<VR * DV>(vn_idx, u * DV + j));
+                static_for<0, NVG>([&](auto G_) {
+                    constexpr int g = decltype(G_)::value;
+                    if constexpr (g + 1 < NVG) {
+#pragma unroll
+                        for (int u = 0; u < VG; ++u)
+#pragma unroll
+                            for (int j = 0; j < DV; ++j)
+                                if ((g + 1) * VG + u < VR)
+                                    cv[(g + 1) & 1][u][j] = lds_ld(smem, half_of<VR * DV>(vn_idx, ((g + 1) * VG + u) * DV + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, VG>([&](auto U_) {
+                        constexpr int u = decltype(U_)::value;
+                        constexpr int q = g * VG + u;
+                        if constexpr (q < VR) {
+                            float s = 0.0f + cv[g & 1][u][0];  // as scipy: accumulate from +0.0 (keeps -0.0 out of the marginals)
+#pragma unroll
+                            for (int j = 1; j < DV; ++j) s += cv[g & 1][u][j];
+                            const float m1 = prior[q] + s;
+                            lds_st_tid<q * 256>(m1);
+                            xb |= (m1 < 0.0f) ? (1u << q) : 0u;
+                        }
+                    });
+                });
                 __builtin_amdgcn_wave_barrier();
                 ++it;
             }
@@ -210,6 +274,21 @@ const ShapeEntry kShapes[] = {shape_entry<6, 3, 4, 8>(), shape_entry<6, 3, 10, 1
 
 bool fused_supported(const Decoder* d) { return d->fused && d->fused->ok; }
 
+int fused_info(const Decoder* d, double* out8) {
+    const FusedPlan* p = d->fused;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!p || !p->ok) return LDPC_OK;
+    out8[0] = 1;
+    out8[1] = p->base_cycles;     // conflict-free LDS cycles of the gathers per sweep
+    out8[2] = p->extra_identity;  // extra bank-conflict cycles per sweep, trivial placement
+    out8[3] = p->extra_planned;   // ... with the planned placement
+    out8[4] = p->waves_per_cu;
+    out8[5] = (double)p->lds_bytes;
+    out8[6] = p->CR;
+    out8[7] = p->VR;
+    return LDPC_OK;
+}
+
 int fused_plan_create(Decoder* d) {
     const Code* c = d->code;
     d->fused = new FusedPlan();
@@ -227,13 +306,21 @@ int fused_plan_create(Decoder* d) {
     p->DC = DC; p->DV = DV; p->CR = CR; p->VR = VR;
     const int NPAD = VR * 64;
 
-    // ---- layout: check c -> slot (r, lane), variable v -> slot s, edge position inside its check.
-    std::vector<int> chk_slot(c->m), var_slot(c->n);
-    std::iota(chk_slot.begin(), chk_slot.end(), 0);
-    std::iota(var_slot.begin(), var_slot.end(), 0);
-    std::vector<int> edge_pos(c->E);
-    for (int cc = 0; cc < c->m; ++cc)
-        for (int k = c->row_ptr[cc]; k < c->row_ptr[cc + 1]; ++k) edge_pos[k] = k - c->row_ptr[cc];
+    // ---- layout: check c -> slot (r, lane), variable v -> slot, edge positions (ldpc_layout.hpp)
+    FusedLayout L;
+    const char* mode = std::getenv("LDPC_FUSED_LAYOUT");
+    const char* ms = std::getenv("LDPC_FUSED_PLAN_MS");
+    if (mode && std::string(mode) == "identity") {
+        identity_layout(*c, DC, DV, &L);
+        L.base_cycles = 2.0 * (CR * DC + VR * DV);
+        L.extra_cycles_identity = L.extra_cycles_planned = layout_extra_cycles(*c, DC, DV, CR, VR, L);
+    } else {
+        plan_fused_layout(*c, DC, DV, CR, VR, 0x1200u, ms ? atof(ms) * 1e-3 : 0.6, &L);
+    }
+    p->extra_identity = L.extra_cycles_identity;
+    p->extra_planned = L.extra_cycles_planned;
+    p->base_cycles = L.base_cycles;
+    const std::vector<int>&chk_slot = L.chk_slot, &var_slot = L.var_slot, &edge_pos = L.edge_pos, &var_pos = L.var_pos;
 
     std::vector<uint32_t> cn_tab((size_t)((CR * DC + 1) / 2) * 64, 0), vn_tab((size_t)((VR * DV + 1) / 2) * 64, 0);
     std::vector<int32_t> var_of_slot((size_t)NPAD, -1);
@@ -242,30 +329,70 @@ int fused_plan_create(Decoder* d) {
         uint32_t& w = tab[(size_t)(k >> 1) * 64 + lane];
         w = (k & 1) ? ((w & 0x0000ffffu) | (val << 16)) : ((w & 0xffff0000u) | val);
     };
+    const uint32_t c2v_base = (uint32_t)NPAD * 4;
+    std::vector<int64_t> cn_addr((size_t)CR * DC * 64, -1), vn_addr((size_t)VR * DV * 64, -1);  // byte offsets, -1 = padded lane
     for (int v = 0; v < c->n; ++v) var_of_slot[var_slot[v]] = v;
-    // padded check slots read marg slot of variable 0 (any valid address) and are masked out of the syndrome
-    for (int r = 0; r < CR; ++r)
-        for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < DC; ++j) put16(cn_tab, r * DC + j, lane, 0);
     for (int cc = 0; cc < c->m; ++cc) {
         const int r = chk_slot[cc] / 64, lane = chk_slot[cc] % 64;
         cn_active[r] |= 1ull << lane;
         for (int k = c->row_ptr[cc]; k < c->row_ptr[cc + 1]; ++k)
-            put16(cn_tab, r * DC + edge_pos[k], lane, (uint32_t)(var_slot[c->edge_var[k]] * 4));
+            cn_addr[(size_t)(r * DC + edge_pos[k]) * 64 + lane] = (int64_t)var_slot[c->edge_var[k]] * 4;
     }
-    const uint32_t c2v_base = (uint32_t)NPAD * 4;
-    for (int q = 0; q < VR; ++q)
-        for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < DV; ++j) put16(vn_tab, q * DV + j, lane, c2v_base + (uint32_t)(CR * DC * 64 + lane) * 4);  // zero row
     for (int v = 0; v < c->n; ++v) {
         const int q = var_slot[v] / 64, lane = var_slot[v] % 64;
-        int j = 0;
-        for (int pidx = c->col_ptr[v]; pidx < c->col_ptr[v + 1]; ++pidx, ++j) {
-            const int k = c->col_edge[pidx];  // ascending edge order == the reference's summation order
-            const int cs = chk_slot[c->edge_chk[k]];
-            put16(vn_tab, q * DV + j, lane, c2v_base + (uint32_t)(((cs / 64) * DC + edge_pos[k]) * 64 + cs % 64) * 4);
+        // a real variable with fewer than DV edges sums the always-zero row for the missing ones
+        for (int j = 0; j < DV; ++j) vn_addr[(size_t)(q * DV + j) * 64 + lane] = c2v_base + (int64_t)(CR * DC * 64 + lane) * 4;
+        for (int pidx = c->col_ptr[v]; pidx < c->col_ptr[v + 1]; ++pidx) {
+            const int k = c->col_edge[pidx], cs = chk_slot[c->edge_chk[k]];
+            vn_addr[(size_t)(q * DV + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(((cs / 64) * DC + edge_pos[k]) * 64 + cs % 64) * 4;
         }
     }
+    // padded lanes may read anything: let them repeat an address of their own half-wave (LDS broadcast, no extra cycle)
+    auto fill_padding = [](std::vector<int64_t>& addr, int64_t fallback) {
+        for (size_t g0 = 0; g0 < addr.size(); g0 += 32) {
+            int64_t rep = fallback;
+            for (int l = 0; l < 32; ++l)
+                if (addr[g0 + l] >= 0) { rep = addr[g0 + l]; break; }
+            for (int l = 0; l < 32; ++l)
+                if (addr[g0 + l] < 0) addr[g0 + l] = rep;
+        }
+    };
+    if (DC % 2 == 0) {
+        // even dc: a padded check lane reads ONE marginal dc times, so its sign parity is even and it never shows up in
+        // the syndrome (no lane mask needed).  Pick, per half-wave, the slot that collides least with the real reads.
+        for (int r = 0; r < CR; ++r)
+            for (int h = 0; h < 2; ++h) {
+                bool any_pad = false;
+                for (int l = 0; l < 32; ++l) any_pad |= cn_addr[(size_t)(r * DC) * 64 + h * 32 + l] < 0;
+                if (!any_pad) continue;
+                int best_slot = 0, best_cost = 1 << 30;
+                for (int slot = 0; slot < NPAD && best_cost > 0; ++slot) {
+                    int cost = 0;
+                    for (int j = 0; j < DC; ++j) {
+                        bool clash = false, same = false;
+                        for (int l = 0; l < 32; ++l) {
+                            const int64_t a = cn_addr[(size_t)(r * DC + j) * 64 + h * 32 + l];
+                            if (a < 0) continue;
+                            if (a == (int64_t)slot * 4) same = true;
+                            else if (((a / 4) & 31) == (slot & 31)) clash = true;
+                        }
+                        cost += (clash && !same) ? 1 : 0;
+                    }
+                    if (cost < best_cost) { best_cost = cost; best_slot = slot; }
+                }
+                for (int j = 0; j < DC; ++j)
+                    for (int l = 0; l < 32; ++l) {
+                        int64_t& a = cn_addr[(size_t)(r * DC + j) * 64 + h * 32 + l];
+                        if (a < 0) a = (int64_t)best_slot * 4;
+                    }
+            }
+    }
+    fill_padding(cn_addr, 0);
+    fill_padding(vn_addr, c2v_base);
+    for (int k = 0; k < CR * DC; ++k)
+        for (int lane = 0; lane < 64; ++lane) put16(cn_tab, k, lane, (uint32_t)cn_addr[(size_t)k * 64 + lane]);
+    for (int k = 0; k < VR * DV; ++k)
+        for (int lane = 0; lane < 64; ++lane) put16(vn_tab, k, lane, (uint32_t)vn_addr[(size_t)k * 64 + lane]);
     p->lds_bytes = (size_t)(NPAD + (CR * DC + 1) * 64) * 4;
     if (p->lds_bytes > 65535) return LDPC_OK;  // 16-bit offsets
     LDPC_HIP_TRY(hipSetDevice(c->device));

@@ -1,0 +1,287 @@
+// LDS layout planner of the fused backend -- host code only (see ldpc_layout.hpp for the problem statement).
+#include "ldpc_layout.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <numeric>
+#include <cstdlib>
+#include <cstdio>
+
+namespace ldpc {
+
+namespace {
+
+struct Rng {  // xorshift64*
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull) {}
+    uint64_t next() {
+        s ^= s >> 12;
+        s ^= s << 25;
+        s ^= s >> 27;
+        return s * 0x2545F4914F6CDD1Dull;
+    }
+    int below(int n) { return (int)((next() >> 33) % (uint64_t)n); }
+    double unit() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+inline int slot_of(int group, int bank) { return (group >> 1) * 64 + (group & 1) * 32 + bank; }
+inline int group_of_slot(int s) { return (s >> 6) * 2 + ((s >> 5) & 1); }
+inline int bank_of_slot(int s) { return s & 31; }
+
+}  // namespace
+
+void identity_layout(const Code& c, int DC, int DV, FusedLayout* L) {
+    L->chk_slot.resize(c.m);
+    L->var_slot.resize(c.n);
+    std::iota(L->chk_slot.begin(), L->chk_slot.end(), 0);
+    std::iota(L->var_slot.begin(), L->var_slot.end(), 0);
+    L->edge_pos.assign(c.E, 0);
+    L->var_pos.assign(c.E, 0);
+    for (int cc = 0; cc < c.m; ++cc)
+        for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) L->edge_pos[k] = k - c.row_ptr[cc];
+    for (int v = 0; v < c.n; ++v)
+        for (int p = c.col_ptr[v]; p < c.col_ptr[v + 1]; ++p) L->var_pos[c.col_edge[p]] = p - c.col_ptr[v];
+}
+
+double layout_extra_cycles(const Code& c, int DC, int DV, int CR, int VR, const FusedLayout& L) {
+    // address seen by lane `lane` of gather instruction (round, position); -1 == padded lane (free to broadcast)
+    double extra = 0;
+    auto group_cost = [](const int* addr32) {
+        int mx = 1;
+        for (int b = 0; b < 32; ++b) {
+            int distinct = 0, seen[32];
+            for (int l = 0; l < 32; ++l) {
+                if (addr32[l] < 0 || (addr32[l] & 31) != b) continue;
+                bool dup = false;
+                for (int i = 0; i < distinct; ++i) dup |= seen[i] == addr32[l];
+                if (!dup) seen[distinct++] = addr32[l];
+            }
+            mx = std::max(mx, distinct);
+        }
+        return mx - 1;
+    };
+    std::vector<int> cn((size_t)CR * DC * 64, -1), vn((size_t)VR * DV * 64, -1);
+    for (int cc = 0; cc < c.m; ++cc)
+        for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) {
+            const int s = L.chk_slot[cc];
+            cn[(size_t)((s / 64) * DC + L.edge_pos[k]) * 64 + s % 64] = L.var_slot[c.edge_var[k]];
+        }
+    for (int k = 0; k < c.E; ++k) {
+        const int vs = L.var_slot[c.edge_var[k]], cs = L.chk_slot[c.edge_chk[k]];
+        vn[(size_t)((vs / 64) * DV + L.var_pos[k]) * 64 + vs % 64] = ((cs / 64) * DC + L.edge_pos[k]) * 64 + cs % 64;
+    }
+    for (size_t i = 0; i < cn.size(); i += 32) extra += group_cost(&cn[i]);
+    for (size_t i = 0; i < vn.size(); i += 32) extra += group_cost(&vn[i]);
+    return extra;
+}
+
+void plan_fused_layout(const Code& c, int DC, int DV, int CR, int VR, uint64_t seed, double budget_s, FusedLayout* L) {
+    identity_layout(c, DC, DV, L);
+    L->base_cycles = 2.0 * (CR * DC + VR * DV);
+    L->extra_cycles_identity = layout_extra_cycles(c, DC, DV, CR, VR, *L);
+    const int NGC = 2 * CR, NGV = 2 * VR, m = c.m, n = c.n;
+    const int64_t E = c.E;
+    Rng rng(seed);
+
+    // ---- state
+    std::vector<int> cgrp(m), cbank(m), vgrp(n), vbank(n), vflip(n, 0);
+    std::vector<int> chk_at((size_t)NGC * 32, -1), var_at((size_t)NGV * 32, -1);
+    for (int cc = 0; cc < m; ++cc) {
+        cgrp[cc] = group_of_slot(cc);
+        cbank[cc] = bank_of_slot(cc);
+        chk_at[(size_t)cgrp[cc] * 32 + cbank[cc]] = cc;
+    }
+    for (int v = 0; v < n; ++v) {
+        vgrp[v] = group_of_slot(v);
+        vbank[v] = bank_of_slot(v);
+        var_at[(size_t)vgrp[v] * 32 + vbank[v]] = v;
+    }
+    std::vector<int> edge_vj(E);  // canonical index of edge k in its variable's list
+    for (int v = 0; v < n; ++v)
+        for (int p = c.col_ptr[v]; p < c.col_ptr[v + 1]; ++p) edge_vj[c.col_edge[p]] = p - c.col_ptr[v];
+    auto vpos = [&](int v, int j) { return (j < 2 && vflip[v] && (c.col_ptr[v + 1] - c.col_ptr[v]) >= 2) ? 1 - j : j; };
+
+    std::vector<int> cnA((size_t)NGC * 32, 0), cnB((size_t)NGV * DV * 32, 0);
+    long cost = 0;
+    auto addA = [&](int gc, int bv, int d) {
+        int& x = cnA[(size_t)gc * 32 + bv];
+        cost -= std::max(0, x - DC);
+        x += d;
+        cost += std::max(0, x - DC);
+    };
+    auto addB = [&](int gv, int pos, int bc, int d) {
+        int& x = cnB[((size_t)gv * DV + pos) * 32 + bc];
+        cost -= std::max(0, x - 1);
+        x += d;
+        cost += std::max(0, x - 1);
+    };
+    auto touch_var = [&](int v, int d) {
+        for (int p = c.col_ptr[v]; p < c.col_ptr[v + 1]; ++p) {
+            const int k = c.col_edge[p], cc = c.edge_chk[k];
+            addA(cgrp[cc], vbank[v], d);
+            addB(vgrp[v], vpos(v, p - c.col_ptr[v]), cbank[cc], d);
+        }
+    };
+    auto touch_chk = [&](int cc, int d) {
+        for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) {
+            const int v = c.edge_var[k];
+            addA(cgrp[cc], vbank[v], d);
+            addB(vgrp[v], vpos(v, edge_vj[k]), cbank[cc], d);
+        }
+    };
+    for (int v = 0; v < n; ++v) touch_var(v, +1);
+
+    auto swap_vars = [&](int s1, int s2) {
+        const int a = var_at[s1], b = var_at[s2];
+        if (a >= 0) touch_var(a, -1);
+        if (b >= 0) touch_var(b, -1);
+        if (a >= 0) { vgrp[a] = s2 / 32; vbank[a] = s2 % 32; }
+        if (b >= 0) { vgrp[b] = s1 / 32; vbank[b] = s1 % 32; }
+        std::swap(var_at[s1], var_at[s2]);
+        if (a >= 0) touch_var(a, +1);
+        if (b >= 0) touch_var(b, +1);
+    };
+    auto swap_chks = [&](int s1, int s2) {
+        const int a = chk_at[s1], b = chk_at[s2];
+        if (a >= 0) touch_chk(a, -1);
+        if (b >= 0) touch_chk(b, -1);
+        if (a >= 0) { cgrp[a] = s2 / 32; cbank[a] = s2 % 32; }
+        if (b >= 0) { cgrp[b] = s1 / 32; cbank[b] = s1 % 32; }
+        std::swap(chk_at[s1], chk_at[s2]);
+        if (a >= 0) touch_chk(a, +1);
+        if (b >= 0) touch_chk(b, +1);
+    };
+    auto flip_var = [&](int v) {
+        touch_var(v, -1);
+        vflip[v] ^= 1;
+        touch_var(v, +1);
+    };
+
+    // ---- annealing
+    const auto t_start = std::chrono::steady_clock::now();
+    auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+    const int nvs = NGV * 32, ncs = NGC * 32;
+    double T = 1.5;
+    const double T_end = 0.08;
+    long best = cost;
+    std::vector<int> b_cgrp = cgrp, b_cbank = cbank, b_vgrp = vgrp, b_vbank = vbank, b_vflip = vflip;
+    const long max_moves = 60000000;
+    for (long it = 0; it < max_moves && best > 0; ++it) {
+        if ((it & 4095) == 0) {
+            const double el = elapsed();
+            if (el > budget_s) break;
+            T = 1.5 * std::pow(T_end / 1.5, el / budget_s);
+        }
+        const long before = cost;
+        const int kind = rng.below(100);
+        int a = 0, b = 0;
+        if (kind < 45) {
+            a = rng.below(nvs); b = rng.below(nvs);
+            if (a == b || (var_at[a] < 0 && var_at[b] < 0)) continue;
+            swap_vars(a, b);
+        } else if (kind < 85) {
+            a = rng.below(ncs); b = rng.below(ncs);
+            if (a == b || (chk_at[a] < 0 && chk_at[b] < 0)) continue;
+            swap_chks(a, b);
+        } else {
+            a = rng.below(n);
+            flip_var(a);
+        }
+        const long delta = cost - before;
+        if (delta > 0 && rng.unit() >= std::exp(-(double)delta / T)) {  // reject: every move is an involution
+            if (kind < 45) swap_vars(a, b);
+            else if (kind < 85) swap_chks(a, b);
+            else flip_var(a);
+        } else if (cost < best) {
+            best = cost;
+            b_cgrp = cgrp; b_cbank = cbank; b_vgrp = vgrp; b_vbank = vbank; b_vflip = vflip;
+        }
+    }
+    cgrp = b_cgrp; cbank = b_cbank; vgrp = b_vgrp; vbank = b_vbank; vflip = b_vflip;
+    if (std::getenv("LDPC_PLAN_DEBUG")) fprintf(stderr, "[plan] annealing: surrogate cost %ld after %.2fs\n", best, elapsed());
+
+    for (int cc = 0; cc < m; ++cc) L->chk_slot[cc] = slot_of(cgrp[cc], cbank[cc]);
+    for (int v = 0; v < n; ++v) L->var_slot[v] = slot_of(vgrp[v], vbank[v]);
+    for (int k = 0; k < E; ++k) L->var_pos[k] = vpos(c.edge_var[k], edge_vj[k]);
+
+    // ---- positions inside each check: edge-colour every check group against the variable banks
+    std::vector<std::vector<int>> group_checks(NGC);
+    for (int cc = 0; cc < m; ++cc) group_checks[cgrp[cc]].push_back(cc);
+    for (int g = 0; g < NGC; ++g) {
+        std::vector<int> edges;  // edge ids of this group
+        for (int cc : group_checks[g])
+            for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) edges.push_back(k);
+        // "proper" edges: at most DC per bank; the overflow is placed afterwards
+        std::vector<int> bank_deg(32, 0);
+        std::vector<int> proper, overflow;
+        for (int k : edges) {
+            const int b = vbank[c.edge_var[k]];
+            if (bank_deg[b] < DC) { ++bank_deg[b]; proper.push_back(k); } else overflow.push_back(k);
+        }
+        std::vector<int> colour_of(edges.size(), -1);
+        auto eidx = [&](int k) { return (int)(std::lower_bound(edges.begin(), edges.end(), k) - edges.begin()); };
+        std::sort(edges.begin(), edges.end());
+        std::vector<std::vector<int>> cAt(m > 0 ? group_checks[g].size() : 0, std::vector<int>(DC, -1));
+        std::vector<std::vector<int>> bAt(32, std::vector<int>(DC, -1));
+        auto cloc = [&](int cc) { return (int)(std::find(group_checks[g].begin(), group_checks[g].end(), cc) - group_checks[g].begin()); };
+        auto set_col = [&](int k, int colr) {
+            colour_of[eidx(k)] = colr;
+            cAt[cloc(c.edge_chk[k])][colr] = k;
+            bAt[vbank[c.edge_var[k]]][colr] = k;
+        };
+        for (int k : proper) {
+            const int cl = cloc(c.edge_chk[k]), b = vbank[c.edge_var[k]];
+            int a = -1, bf = -1;
+            for (int x = 0; x < DC && a < 0; ++x) if (cAt[cl][x] < 0) a = x;
+            for (int x = 0; x < DC && bf < 0; ++x) if (bAt[b][x] < 0) bf = x;
+            if (a < 0 || bf < 0) { if (a >= 0) { colour_of[eidx(k)] = a; cAt[cl][a] = k; } continue; }
+            if (bAt[b][a] < 0) { set_col(k, a); continue; }
+            if (cAt[cl][bf] < 0) { set_col(k, bf); continue; }
+            // alternating a/bf path from bank b; afterwards colour a is free at b (and still free at the check)
+            std::vector<int> path;
+            int cur = b;
+            for (int guard = 0; guard < 4096; ++guard) {
+                const int e1 = bAt[cur][a];
+                if (e1 < 0) break;
+                path.push_back(e1);
+                const int e2 = cAt[cloc(c.edge_chk[e1])][bf];
+                if (e2 < 0) break;
+                path.push_back(e2);
+                cur = vbank[c.edge_var[e2]];
+            }
+            for (int e : path) {
+                const int old = colour_of[eidx(e)];
+                cAt[cloc(c.edge_chk[e])][old] = -1;
+                bAt[vbank[c.edge_var[e]]][old] = -1;
+            }
+            for (int e : path) set_col(e, colour_of[eidx(e)] == a ? bf : a);
+            set_col(k, a);
+        }
+        for (int k : overflow) {  // leftover colours of the check; pick the one whose bank cell is least loaded
+            const int cl = cloc(c.edge_chk[k]);
+            int a = -1;
+            for (int x = 0; x < DC && a < 0; ++x) if (cAt[cl][x] < 0) a = x;
+            if (a >= 0) { colour_of[eidx(k)] = a; cAt[cl][a] = k; }
+        }
+        // any edge still uncoloured (should not happen): give it the first free colour of its check
+        for (int cc : group_checks[g]) {
+            std::vector<char> used(DC, 0);
+            for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k)
+                if (colour_of[eidx(k)] >= 0) used[colour_of[eidx(k)]] = 1;
+            for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k)
+                if (colour_of[eidx(k)] < 0)
+                    for (int x = 0; x < DC; ++x)
+                        if (!used[x]) { colour_of[eidx(k)] = x; used[x] = 1; break; }
+        }
+        for (int k : edges) L->edge_pos[k] = colour_of[eidx(k)];
+    }
+    L->extra_cycles_planned = layout_extra_cycles(c, DC, DV, CR, VR, *L);
+    if (L->extra_cycles_planned >= L->extra_cycles_identity) {  // never ship a layout worse than the trivial one
+        const double id_cost = L->extra_cycles_identity;
+        identity_layout(c, DC, DV, L);
+        L->extra_cycles_planned = id_cost;
+    }
+}
+
+}  // namespace ldpc

@@ -1,0 +1,43 @@
+// LDS layout planner for the fused backend (host side).
+//
+// The fused kernel gathers marginals (check phase) and check messages (variable phase) from the LDS with
+// ds_read_b32, which services a wave64 access as two 32-lane groups over 32 dword banks: k distinct addresses
+// on one bank inside a group cost k cycles.  With an arbitrary placement the 32 random addresses of a group
+// collide ~3.5-way on average, and the gathers dominate the kernel.  H is fixed, so the placement can be chosen:
+//
+//   * every variable gets an LDS slot (group gv, bank bv), every check a slot (group gc, bank bc)
+//     (slot = 64*(group/2) + 32*(group%2) + bank; group == the 32-lane half-wave that owns it);
+//   * every check orders its dc edges freely (min-sum is order independent); a variable keeps the reference's
+//     summation order ((c_a + c_b) + c_c), only its first two (commutative) positions may be swapped;
+//   * check phase  : the 32 edges read by one half-wave instruction must hit 32 different variable banks.  For a
+//     check group this is possible for all dc positions iff no variable bank receives more than dc of the
+//     group's edges (Koenig: a bipartite multigraph of maximum degree dc splits into dc matchings);
+//   * variable phase: for a variable group and position j the 32 checks read must sit on 32 different check banks.
+//
+// plan_fused_layout() minimises the excess over those capacities by simulated annealing (swap two variable
+// slots / two check slots / flip a variable's first two positions), then edge-colours every check group.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "ldpc_common.hpp"
+
+namespace ldpc {
+
+struct FusedLayout {
+    std::vector<int> chk_slot;  // [m]  slot index r*64 + lane
+    std::vector<int> var_slot;  // [n]  slot index q*64 + lane
+    std::vector<int> edge_pos;  // [E]  position of edge k inside its check's gather order (0..dc-1)
+    std::vector<int> var_pos;   // [E]  position of edge k inside its variable's gather order (0..dv-1)
+    double extra_cycles_identity = 0;  // LDS conflict cycles per sweep beyond the conflict-free minimum
+    double extra_cycles_planned = 0;
+    double base_cycles = 0;  // conflict-free LDS cycles of the gathers per sweep (one per half-wave instruction)
+};
+
+// exact conflict model: sum over gather instructions and half-waves of (max distinct-address multiplicity - 1)
+double layout_extra_cycles(const Code& c, int DC, int DV, int CR, int VR, const FusedLayout& L);
+
+void identity_layout(const Code& c, int DC, int DV, FusedLayout* L);
+void plan_fused_layout(const Code& c, int DC, int DV, int CR, int VR, uint64_t seed, double budget_s, FusedLayout* L);
+
+}  // namespace ldpc

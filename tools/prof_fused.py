@@ -1,0 +1,27 @@
+"""Small driver for profiler runs: N decodes of one resident batch (priors already in HBM), no CPU baseline."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import argparse
+import torch
+from bench import load_code
+from ldpc_decoders_amd._device import DecoderHandle
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--backend", default="auto"); ap.add_argument("--snr", type=float, default=1.0)
+ap.add_argument("--batch", type=int, default=65536); ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--code", default="1200_3_6_rand_ldpc_1"); ap.add_argument("--precision", default="f32")
+ap.add_argument("--alg", default="MSA")
+a = ap.parse_args()
+g, code = load_code(a.code)
+h = DecoderHandle(code, a.alg, a.precision, a.backend)
+pri, _ = h.channel_device("biawgn", a.snr, 0, 1, 0, 0, a.batch)
+xh, it = h.decode_device(pri, None, 50)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.reps):
+    h.decode_device(pri, None, 50, xhat=xh, iters=it)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.reps
+print("backend", h.last_stats()[0], "ms/decode %.3f" % (dt * 1e3), "frames/s %.3e" % (a.batch / dt), "mean iters %.2f" % it.float().mean().item(), h.fused_info())
