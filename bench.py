@@ -156,15 +156,29 @@ def main():
         frac_bytes = {"stream_check_pass": 2 * g.E * s, "stream_variable_pass": (2 * g.E + g.n) * s,
                       "fused_decode": bytes_per_frame_iter}[kind]
         roof = None
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, calibrated and
+        # corrected as MI355X_MICROARCH.md prescribes): collected by tools/collect_profiles.sh, committed under profiles/
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fp:
+                tj = json.load(fp)
+            key = {"stream_check_pass": "stream:k_cn", "stream_variable_pass": "stream:k_vn", "fused_decode": "fused:k_fused_msa"}[kind]
+            for k, v in tj.items():
+                if k.startswith(key) and args.batch == 65536 and args.code == "1200_3_6_rand_ldpc_1" and abs(args.snr - 1.0) < 1e-9:
+                    traffic = int(v)
+        except Exception:
+            pass
         if launches > 0 and ms > 0:
             bytes_total = iter_sum_rank0_share * frac_bytes
             ach = bytes_total / (ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": kind, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(bytes_total / launches), "avg_launch_ms": round(ms / launches, 4),
                     "launches": int(launches),
-                    "note": "algorithmic bytes = sum over frames of sweeps executed x %d B (%s share of s(4E+n)); "
-                            "HIP events on the decode stream, rank 0" % (frac_bytes, kind),
+                    "note": "algorithmic bytes = sum over frames of sweeps executed x %d B (%s share of s(4E+n)); HIP events on the "
+                            "decode stream, rank 0; traffic = PMC HBM bytes/launch from profiles/hbm_traffic.json (same workload). "
+                            "frac > 1 means the messages stayed on-chip (fused backend): the kernel is then LDS/VALU-bound, "
+                            "see DESIGN.md" % (frac_bytes, kind),
                     "all_kernels_ms": {k: round(v[0], 3) for k, v in prof.items()}}
         out = {
             "metric": "decoded frames/s, n=1200 (3,6) min-sum max_iter=50 (+ achieved HBM GB/s in roofline)",

@@ -101,6 +101,10 @@ int ldpc_channel(int channel, int dtype, double param, int codeword, uint64_t se
 int ldpc_count_errors(const uint8_t* xhat_dev, const uint8_t* sent_dev, int codeword, const int32_t* iters_dev, int64_t B,
                       int32_t n, int32_t hist_bins, int64_t* counters_dev, void* stream);
 
+/* Profiling aid: coalesced 4-byte-per-lane device copy of a known size, used to calibrate the profiler's HBM byte
+ * counters for the access width of the streaming kernels. */
+int ldpc_debug_copy4(const void* src_dev, void* dst_dev, int64_t nbytes, void* stream);
+
 /* One pass of the whole hot path for frames [frame0, frame0+B): channel -> LLR -> decode -> count, everything on
  * the device; counters accumulate as in ldpc_count_errors.  This is the body of `while wec < min_wec`
  * (src/main.py:37-45) for B frames at once. */

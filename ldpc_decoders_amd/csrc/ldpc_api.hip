@@ -345,6 +345,11 @@ int ldpc_channel(int channel, int dtype, double param, int codeword, uint64_t se
     return channel_generate(channel, dtype, param, codeword, seed, stream_id, frame0, B, n, priors, y, (hipStream_t)stream);
 }
 
+int ldpc_debug_copy4(const void* src_dev, void* dst_dev, int64_t nbytes, void* stream) {
+    if (!src_dev || !dst_dev || nbytes < 0) return LDPC_E_ARG;
+    return debug_copy4(src_dev, dst_dev, nbytes, (hipStream_t)stream);
+}
+
 int ldpc_count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const int32_t* iters, int64_t B, int32_t n,
                       int32_t hist_bins, int64_t* counters, void* stream) {
     if (!xhat || !counters || B < 0 || n <= 0 || hist_bins < 0) {

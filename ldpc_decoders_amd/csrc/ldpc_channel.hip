@@ -143,7 +143,19 @@ __global__ __launch_bounds__(256) void k_count(const uint8_t* __restrict__ xhat,
         if (s_hist[i]) atomicAdd(&counters[4 + i], (unsigned long long)s_hist[i]);
 }
 
+// 4-byte-per-lane coalesced copy with a known byte count: calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE for the access
+// width the streaming kernels use (MI355X_MICROARCH.md: the counters are only calibrated for 16-byte-per-lane streams)
+__global__ __launch_bounds__(256) void k_copy4(const float* __restrict__ src, float* __restrict__ dst, int64_t nwords) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace
+
+int debug_copy4(const void* src, void* dst, int64_t nbytes, hipStream_t st) {
+    hipLaunchKernelGGL(k_copy4, dim3(8192), dim3(256), 0, st, (const float*)src, (float*)dst, nbytes / 4);
+    LDPC_HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
 
 int channel_generate(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0,
                      int64_t B, int32_t n, void* priors, uint8_t* y, hipStream_t st) {

@@ -121,6 +121,8 @@ int channel_generate(int channel, int dtype, double param, int codeword, uint64_
 int count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const int32_t* iters, int64_t B, int32_t n,
                  int32_t max_iter_hist, int64_t* counters, hipStream_t st);
 
+int debug_copy4(const void* src, void* dst, int64_t nbytes, hipStream_t st);
+
 constexpr uint32_t FLAG_NO_EARLY_EXIT = 1u;  // run exactly max_iter sweeps (NOT reference behaviour; benchmarking aid)
 
 }  // namespace ldpc

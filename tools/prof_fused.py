@@ -24,4 +24,10 @@ for _ in range(a.reps):
     h.decode_device(pri, None, 50, xhat=xh, iters=it)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.reps
+# known-size 4 B/lane copy (calibration of FETCH_SIZE / WRITE_SIZE): 1 GiB in, 1 GiB out
+from ldpc_decoders_amd import _lib
+src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
+dst = torch.empty_like(src)
+_lib.check(_lib.load().ldpc_debug_copy4(src.data_ptr(), dst.data_ptr(), src.numel() * 4, torch.cuda.current_stream().cuda_stream))
+torch.cuda.synchronize()
 print("backend", h.last_stats()[0], "ms/decode %.3f" % (dt * 1e3), "frames/s %.3e" % (a.batch / dt), "mean iters %.2f" % it.float().mean().item(), h.fused_info())
