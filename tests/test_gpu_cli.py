@@ -1,0 +1,46 @@
+"""GPU tests of the experiment driver (ldpc_decoders_amd.main): --exact reproduces the reference's counters for a fixed
+np.random seed; device-noise mode writes the same JSON schema and statistically consistent error rates."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, main_counter_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("run", [r for r in main_counter_cases() if " SPA " not in r["argline"] or r["argline"].startswith("bec")],
+                         ids=lambda r: r["argline"].replace(" ", "_")[:60])
+def test_exact_mode_reproduces_reference_counters(run, tmp_path, monkeypatch):
+    # reference: `np.random.seed(s); python src/main.py <argline>` (tests/golden/main_counters.json)
+    from ldpc_decoders_amd import codes, main
+
+    monkeypatch.setenv(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
+    argv = run["argline"].split() + ["--data_dir", str(tmp_path), "--console", "--exact", "--np-seed", str(run["seed"])]
+    main.main(argv)
+    with open(os.path.join(str(tmp_path), run["file_name"])) as fp:
+        got = json.load(fp)
+    want = run["result"]
+    assert list(got) == list(want)
+    for key in ("tot", "wec", "bec"):
+        assert got[key] == want[key]
+    for key in ("wer", "ber"):
+        for prm in want[key]:
+            assert got[key][prm] == pytest.approx(want[key][prm], rel=1e-12)
+
+
+def test_device_mode_schema_and_rates(tmp_path, monkeypatch):
+    from ldpc_decoders_amd import codes, main
+
+    monkeypatch.setenv(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
+    argv = "biawgn 1200_3_6_rand_ldpc_1 MSA --codeword 0 --min-wec 200 --max-iter 10 --params 2.0 2.5 --batch 8192".split()
+    res = main.main(argv + ["--data_dir", str(tmp_path), "--console"])
+    data = json.load(open(os.path.join(str(tmp_path), "biawgn-1200_3_6_rand_ldpc_1-MSA-0-200-10.json")))
+    assert list(data)[:6] == ["channel", "code", "decoder", "codeword", "min_wec", "max_iter"]
+    # published curve of this very code/decoder/max_iter (reference data/output/biawgn-1200_3_6_rand_ldpc_1-MSA-10-1.json):
+    # BER 2.18e-2 @ 2.0 dB (140 frames), 2.37e-3 @ 2.5 dB (626 frames) -- same order of magnitude expected
+    assert 0.012 < data["ber"]["2.0"] < 0.035 and 0.0012 < data["ber"]["2.5"] < 0.0045
+    assert data["wec"]["2.0"] >= 200 and data["tot"]["2.0"] % 8192 == 0
+    assert res[2.0]["wer"] == data["wer"]["2.0"]

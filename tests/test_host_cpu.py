@@ -1,0 +1,126 @@
+"""CPU-side tests: the C ABI library loads and exports every symbol of include/ldpc_hip.h, the code store mirrors the
+reference loader, and the CLI / JSON surface keeps the reference's schema.  No GPU compute calls here."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, golden_edges
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    with open(os.path.join(ROOT, "include", "ldpc_hip.h")) as fp:
+        text = fp.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ldpc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import ctypes
+
+    from ldpc_decoders_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _header_symbols()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), "symbol %s declared in include/ldpc_hip.h but not exported" % name
+    # the ctypes binding covers the same set
+    assert set(_lib.SIGNATURES) == set(names)
+    assert _lib.load().ldpc_abi_version() == 1
+
+
+def test_argument_errors_are_reported_not_thrown():
+    import ctypes
+
+    from ldpc_decoders_amd import _lib
+
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    chk = np.array([0, 0, 1], dtype=np.int32)
+    var = np.array([1, 0, 1], dtype=np.int32)  # not row-major sorted
+    rc = lib.ldpc_code_create(0, 2, 2, 3, chk.ctypes.data, var.ctypes.data, ctypes.byref(h))
+    assert rc == -3 and b"row-major" in lib.ldpc_last_error()
+    rc = lib.ldpc_code_create(0, 0, 2, 3, chk.ctypes.data, var.ctypes.data, ctypes.byref(h))
+    assert rc == -1
+    with pytest.raises(_lib.LdpcHipError):
+        _lib.check(rc)
+
+
+@pytest.mark.parametrize("name", ["4_2_test", "6_2_3_ldpc", "7_4_hamming", "12_3_4_ldpc"])
+def test_builtin_codes_match_reference(name):
+    from ldpc_decoders_amd import codes
+
+    c, g = codes.get_code(name), golden_edges(name)
+    assert (c.m, c.n, c.E) == (g.m, g.n, g.E) and (c.edge_chk == g.chk).all() and (c.edge_var == g.var).all()
+    cb = c.cb  # G H^T = 0 and the all-zero word first (src/codes.py:17-19)
+    assert cb.shape == (2 ** c.gen_mtx.shape[0], c.n) and cb[0].sum() == 0 and c.syndrome(cb).sum() == 0
+    assert (c.parity_mtx == g.to_dense()).all() and c.get_k() == c.n - c.m
+
+
+@pytest.mark.parametrize("name", ["1200_3_6_rand_ldpc_1", "1200_rho_x5_rand_ldpc_5", "512_3_6_rand_ldpc_2", "margulis", "1200_3_6_ldpc"])
+def test_file_loader_matches_reference(name, monkeypatch):
+    from ldpc_decoders_amd import codes
+
+    monkeypatch.setenv(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
+    assert name in codes.get_code_names()
+    c, g = codes.get_code(name), golden_edges(name)
+    assert (c.m, c.n, c.E) == (g.m, g.n, g.E) and (c.edge_chk == g.chk).all() and (c.edge_var == g.var).all()
+
+
+def test_loader_edge_cases(tmp_path):
+    from ldpc_decoders_amd import codes
+
+    assert codes.parse_parity_text("1 2\n\n 2 3 3\n").E == 4  # blank lines skipped, duplicates collapse
+    zero_based = codes.parse_parity_text("0 1\n1 2\n")  # var-1 quirk: variable 0 lands in the last column
+    assert zero_based.n == 3 and sorted(zero_based.edge_var[zero_based.edge_chk == 0]) == [0, 2]
+    with pytest.raises(Exception):
+        codes.parse_parity_text("2 3\n3 4\n")
+    np.random.seed(3)
+    c = codes.rand_reg_ldpc(96, 3, 6)
+    assert (c.row_degrees() == 6).all() and (c.col_degrees() == 3).all()
+    path = codes.save_parity_mtx(c, "t_96_3_6", str(tmp_path))
+    back = codes.load_parity_mtx(path)
+    assert (back.edge_chk == c.edge_chk).all() and (back.edge_var == c.edge_var).all()
+
+
+def test_cli_grammar_and_result_schema(tmp_path):
+    from ldpc_decoders_amd import codes, utils
+    from ldpc_decoders_amd.models import models
+
+    p = utils.setup_parser(codes.get_code_names(), models.keys(), utils.decoder_names)
+    # an arg-line as emitted by the reference's simulations.py (src/simulations.py:27-39)
+    a = p.parse_args(("biawgn 7_4_hamming SPA --codeword=1 --min-wec=50 --max-iter=10 --params 2 4 --data_dir=%s --console" % tmp_path).split())
+    assert a.params == [2.0, 4.0] and a.max_iter == 10 and a.min_wec == 50 and a.codeword == 1 and a.log_freq == 5.0
+    with pytest.raises(SystemExit):
+        p.parse_args("awgn 7_4_hamming SPA".split())
+    ids = [("channel", "biawgn"), ("code", "7_4_hamming"), ("decoder", "SPA"), ("codeword", 1), ("min_wec", 50), ("max_iter", 10)]
+    s = utils.Saver(str(tmp_path), ids)
+    assert os.path.basename(s.file_path) == "biawgn-7_4_hamming-SPA-1-50-10.json"
+    s.add(2.0, {"tot": 412, "wec": 50, "wer": 50 / 412, "bec": 118, "ber": 118 / (412 * 7)})
+    s.add(4.0, {"tot": 2025, "wec": 50, "wer": 50 / 2025, "bec": 133, "ber": 133 / (2025 * 7)})
+    data = json.load(open(s.file_path))
+    assert list(data)[:6] == [k for k, _ in ids] and data["tot"] == {"2.0": 412, "4.0": 2025}
+    assert set(data) == {"channel", "code", "decoder", "codeword", "min_wec", "max_iter", "tot", "wec", "wer", "bec", "ber"}
+
+
+def test_registry_surface():
+    from ldpc_decoders_amd.models import decoder_names, models
+
+    assert set(models) == {"bsc", "bec", "biawgn"} and decoder_names == ["ML", "SPA", "MSA", "LP", "ADMM", "ADMMA"]
+    for ch, mod in models.items():
+        assert hasattr(mod, "Channel")
+        for name in ("SPA", "MSA"):
+            assert getattr(mod, name).id_keys == ["max_iter"]
+        with pytest.raises(NotImplementedError):
+            mod.LP(0.1, None, max_iter=1)
+    np.random.seed(0)
+    x = np.zeros(8, dtype=np.int64)
+    assert set(np.unique(models["bec"].Channel(0.5).send(x))) <= {0, 2}
+    assert set(np.unique(models["bsc"].Channel(0.5).send(x))) <= {0, 1}
+    assert models["biawgn"].Channel(2.0).send(x).dtype == np.float64
