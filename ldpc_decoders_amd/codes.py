@@ -182,19 +182,71 @@ def save_parity_mtx(code, code_name, directory=None):
 
 
 def rand_reg_ldpc(n, l, r, rng=None):
-    """Random (l, r)-regular code, same ensemble as ``codes.rand_reg_ldpc`` (src/codes.py:108-120): every check
-    takes the r currently least-loaded variables, ties broken uniformly at random.  Sparse: O(m n log n) -> O(m n)
-    via a random-keyed partial sort, no dense H."""
+    """Random (l, r)-regular code, same ensemble as ``codes.rand_reg_ldpc`` (src/codes.py:108-120): every check takes
+    the r currently least-loaded variables, ties broken uniformly at random.  Sparse (no dense H).
+
+    When r divides n the greedy fill is exactly "l independent uniform permutations of the variables, dealt r at a
+    time" (all variables of the current minimum degree are equally likely, and a level is used up exactly at a check
+    boundary), which is what is done here in O(E); otherwise the level boundaries are handled check by check.
+    """
     rng = rng or np.random
     m = int(n * l / r)
-    deg = np.zeros(n, dtype=np.int64)
-    chk, var = [], []
-    for i in range(m):
-        key = deg + rng.random_sample(n)  # integer part orders by load, fractional part breaks ties at random
-        pick = np.argpartition(key, r - 1)[:r]
-        deg[pick] += 1
-        chk += [i] * r
-        var += sorted(int(v) for v in pick)
+    if n % r == 0 and m * r == n * l:
+        var = np.concatenate([rng.permutation(n) for _ in range(l)])
+        chk = np.repeat(np.arange(m), r)
+    else:
+        deg = np.zeros(n, dtype=np.int64)
+        chk, var = [], []
+        for i in range(m):
+            key = deg + rng.random_sample(n)  # integer part orders by load, fractional part breaks ties at random
+            pick = np.argpartition(key, r - 1)[:r]
+            deg[pick] += 1
+            chk += [i] * r
+            var += [int(v) for v in pick]
     code = Code.from_edges(m, n, chk, var)
     assert (code.col_degrees() == l).all() and (code.row_degrees() == r).all()
     return code
+
+
+def rand_irregular_ldpc(n, lambda_edge, dc, rng=None):
+    """Random irregular code from an edge-perspective variable degree distribution and check degree ``dc``.
+
+    Same ensemble as ``ldpc.gen_rand_irg_ldpc`` (src/ldpc.py:149-192): node fractions L_i ~ lambda_i / i, floor(L_i n)
+    variables of degree i, variable sockets matched to check sockets by a uniform permutation, edges of even
+    multiplicity cancelled (src/ldpc.py:189).  The reference hard-codes the few "extra" variables that make the counts
+    integral (src/ldpc.py:154,167) and therefore asserts out for n != 1200; here they are solved for: the leftover
+    variables take the degrees that make the socket count a multiple of dc.  ``lambda_edge``: {degree: edge fraction}.
+    Sparse, O(E).  Degree-0/odd-multiplicity effects mean a few checks end up with degree < dc, as upstream.
+    """
+    rng = rng or np.random
+    degs = sorted(lambda_edge)
+    node = np.array([lambda_edge[d] / d for d in degs], dtype=np.float64)
+    node /= node.sum()
+    counts = {d: int(f * n) for d, f in zip(degs, node)}
+    left = n - sum(counts.values())
+    sockets = sum(d * c for d, c in counts.items())
+    # choose degrees for the `left` remaining variables so that sockets % dc == 0 (search small combinations)
+    best = None
+    import itertools
+
+    for combo in itertools.combinations_with_replacement(degs, left):
+        if (sockets + sum(combo)) % dc == 0:
+            best = combo
+            break
+    if best is None:
+        raise ValueError("cannot complete the degree sequence for n=%d, dc=%d" % (n, dc))
+    for d in best:
+        counts[d] += 1
+    var_sockets = np.concatenate([np.repeat(np.arange(start, start + counts[d]), d)
+                                  for d, start in zip(degs, np.cumsum([0] + [counts[d] for d in degs[:-1]]))])
+    m = len(var_sockets) // dc
+    chk_sockets = np.tile(np.arange(m), dc)  # check sockets in the order 1..m repeated dc times, as upstream
+    var_sockets = var_sockets[rng.permutation(len(var_sockets))]
+    key = chk_sockets.astype(np.int64) * n + var_sockets
+    uniq, mult = np.unique(key, return_counts=True)
+    keep = uniq[mult % 2 == 1]
+    return Code.from_edges(m, n, keep // n, keep % n)
+
+
+# lambda(x) of the reference's LP design for rho(x) = x^5, rate 1/2 (SURVEY.md 8(d), from ldpc.solve_dist src/ldpc.py:83-94)
+LAMBDA_RHO_X5_HALF_RATE = {2: 0.4126, 3: 0.1763, 4: 0.1189, 7: 0.1136, 8: 0.1786}

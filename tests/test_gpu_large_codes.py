@@ -1,0 +1,83 @@
+"""Parity at the sizes of BASELINE.json configs 4 and 5 (streaming backend; the reference itself cannot run these: its H is
+dense, SURVEY.md 8(c) 'limits of the oracle').  Checker = the C oracle, pinned to the reference at n <= 2640."""
+import numpy as np
+import pytest
+
+import bp_oracle as O
+import c_oracle as C
+
+pytestmark = pytest.mark.gpu
+
+
+class _G:  # minimal graph view for the C oracle
+    def __init__(self, code):
+        self.m, self.n, self.chk, self.var = code.m, code.n, code.edge_chk, code.edge_var
+
+
+def _noise(rng, B, n, snr):
+    y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(snr)), (B, n))
+    return O.biawgn_priors(y, snr)
+
+
+def test_config4_irregular_n10000_msa():
+    # rate-1/2 irregular ensemble of src/ldpc.py (lambda from its LP design, rho = x^5), n = 10 000, min-sum
+    from ldpc_decoders_amd import bpa, codes
+
+    code = codes.rand_irregular_ldpc(10000, codes.LAMBDA_RHO_X5_HALF_RATE, 6, np.random.RandomState(4))
+    assert code.n == 10000 and code.col_degrees().max() == 8 and set(np.unique(code.row_degrees())) <= {2, 4, 6}
+    pri = _noise(np.random.RandomState(1), 192, code.n, 1.2)
+    for prec, dt in (("f32", np.float32), ("f64", np.float64)):
+        dec = bpa.MSA(code, max_iter=50, precision=prec)
+        xhat, iters = dec.decode_batch(None, pri.astype(dt))
+        xo, io = C.bp_decode(_G(code), "MSA", None, pri.astype(dt), 50, dtype=dt)
+        assert dec.handle.last_stats()[0] == "stream"
+        assert (xhat == xo).all() and (iters == io).all()
+        assert 1 < iters.mean() < 50  # early termination active, both converging and failing frames present
+
+
+def test_config5_regular_n64800_msa_early_termination():
+    from ldpc_decoders_amd import bpa, codes
+
+    code = codes.rand_reg_ldpc(64800, 3, 6, np.random.RandomState(8))
+    assert (code.m, code.E) == (32400, 194400)
+    pri = _noise(np.random.RandomState(2), 96, code.n, 1.9).astype(np.float32)
+    dec = bpa.MSA(code, max_iter=50, precision="f32")
+    xhat, iters = dec.decode_batch(None, pri)
+    xo, io = C.bp_decode(_G(code), "MSA", None, pri, 50, dtype=np.float32)
+    assert (xhat == xo).all() and (iters == io).all()
+    done = iters < 50
+    assert done.any() and code.syndrome(xhat[done]).sum() == 0
+
+
+def test_config3_spa_bsc_bec_batch():
+    # config 3: n=1200 SPA over BSC and the erasure decoder over BEC, batch 65 536 on one GPU (device channel kernels);
+    # size-independent properties + a sample re-decoded by the oracle
+    import torch
+    from helpers import golden_edges
+    from ldpc_decoders_amd._device import DecoderHandle
+    from ldpc_decoders_amd.codes import Code
+
+    g = golden_edges("1200_3_6_rand_ldpc_1")
+    code = Code.from_edges(g.m, g.n, g.chk, g.var)
+    B = 65536
+    h = DecoderHandle(code, "SPA", "f32")
+    pri, y = h.channel_device("bsc", 0.06, 0, 11, 0, 0, B)
+    xhat, iters = h.decode_device(pri, y, 50)
+    xh, it = xhat.cpu().numpy(), iters.cpu().numpy()
+    done = it < 50
+    assert done.mean() > 0.9 and code.syndrome(xh[done][:2048]).sum() == 0
+    ber = (xh != 0).mean()
+    assert 1e-4 < ber < 8e-3  # reference ensemble curve (max_iter=10): 2.1e-3 at p=.06 (data/output/bsc-1200_3_6_rand_ldpc-SPA.json)
+    idx = np.arange(0, B, 1024)
+    xo, io = O.bp_decode(g, "SPA_PHI", y[idx].cpu().numpy().astype(float), pri[idx].double().cpu().numpy(), 50)
+    assert ((xh[idx] == xo).all(axis=1)).mean() >= 0.95
+    hb = DecoderHandle(code, "BEC", "f32")
+    _, ye = hb.channel_device("bec", 0.40, 0, 12, 0, 0, B)
+    xe, ie = hb.decode_device(None, ye, 50)
+    xe_h, ye_h = xe.cpu().numpy(), ye.cpu().numpy()
+    assert ((xe_h == ye_h) | (ye_h == 2)).all()  # known symbols are never changed
+    assert ((xe_h == 2).sum(axis=1) <= (ye_h == 2).sum(axis=1)).all() and (xe_h[xe_h != 2] == 0).all()
+    ber_e = (xe_h != 0).mean()
+    assert 0.003 < ber_e < 0.2  # reference ensemble (max_iter=10): 9.6e-2 at eps=.40 (data/output/bec-1200_3_6_rand_ldpc-SPA.json)
+    xo, io = C.bec_decode(g, ye_h[idx], 50)
+    assert (xe_h[idx] == xo).all() and (ie.cpu().numpy()[idx] == io).all()
