@@ -76,7 +76,8 @@ def init_from_env(prefer_gpu=True):
     if world > 1:
         import torch.distributed as td
 
-        backend = "nccl" if use_gpu else "gloo"
+        # "nccl" is RCCL on ROCm; LDPC_DIST_BACKEND=gloo lets several ranks share one GPU (tests of the N>1 path on a 1-GPU box)
+        backend = os.environ.get("LDPC_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if not td.is_initialized():
