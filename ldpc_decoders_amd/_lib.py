@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libldpc_hip.so")
+LIB_PATH = os.environ.get("LDPC_LIB_PATH") or os.path.join(_HERE, "csrc", "libldpc_hip.so")  # override: A/B builds of the same ABI
 
 ALG = {"MSA": 0, "SPA": 1, "BEC": 2}
 DTYPE = {"f32": 0, "f64": 1}

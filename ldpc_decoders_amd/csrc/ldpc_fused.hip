@@ -405,7 +405,9 @@ int fused_plan_create(Decoder* d) {
     LDPC_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     p->num_cu = prop.multiProcessorCount;
     const int by_lds = (int)((size_t)160 * 1024 / p->lds_bytes);
-    p->waves_per_cu = by_lds < 8 ? by_lds : 8;
+    int cap = 8;
+    if (const char* w = std::getenv("LDPC_FUSED_WAVES")) cap = atoi(w) > 0 ? atoi(w) : 8;  // experiment knob: resident waves per CU
+    p->waves_per_cu = by_lds < cap ? by_lds : cap;
     LDPC_HIP_TRY(hipFuncSetAttribute(shape->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
     p->ok = p->waves_per_cu >= 1;
     return LDPC_OK;

@@ -23,6 +23,26 @@ namespace {
 
 using u64 = unsigned long long;
 
+// streaming (non-temporal) access to the message array, selectable per pass and per direction (measured)
+#ifndef LDPC_CN_NTL
+#define LDPC_CN_NTL 0
+#endif
+#ifndef LDPC_CN_NTS
+#define LDPC_CN_NTS 1
+#endif
+#ifndef LDPC_VN_NTL
+#define LDPC_VN_NTL 0
+#endif
+#ifndef LDPC_VN_NTS
+#define LDPC_VN_NTS 0
+#endif
+template <bool NT, typename T> __device__ __forceinline__ T msg_ld(const T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
+}
+template <bool NT, typename T> __device__ __forceinline__ void msg_st(T* p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 __device__ __forceinline__ u64 wave_or(u64 x) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -135,7 +155,7 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
 #pragma unroll
                 for (int j = 0; j < DCMAX; ++j) {
                     if (j < deg[u]) {
-                        v[u][j] = first ? pt[(int64_t)edge_var[k0[u] + j] * 64] : mt[(int64_t)(k0[u] + j) * 64];
+                        v[u][j] = first ? pt[(int64_t)edge_var[k0[u] + j] * 64] : msg_ld<LDPC_CN_NTL != 0>(mt + (int64_t)(k0[u] + j) * 64);
                     }
                 }
             }
@@ -144,7 +164,7 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
                 cn_rule<T, ALG, DCMAX>(v[u], deg[u]);
 #pragma unroll
                 for (int j = 0; j < DCMAX; ++j) {
-                    if (j < deg[u]) mt[(int64_t)(k0[u] + j) * 64] = v[u][j];
+                    if (j < deg[u]) msg_st<LDPC_CN_NTS != 0>(mt + (int64_t)(k0[u] + j) * 64, v[u][j]);
                 }
             }
         }
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
                 if (deg[u] >= 0) pr[u] = pt[(int64_t)(vbase + u) * 64];
 #pragma unroll
                 for (int j = 0; j < DVMAX; ++j) {
-                    if (j < deg[u]) c[u][j] = mt[(int64_t)col_edge[p0[u] + j] * 64];
+                    if (j < deg[u]) c[u][j] = msg_ld<LDPC_VN_NTL != 0>(mt + (int64_t)col_edge[p0[u] + j] * 64);
                 }
             }
         }
@@ -226,7 +246,7 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
                     const T marg = pr[u] + s;
 #pragma unroll
                     for (int j = 0; j < DVMAX; ++j)
-                        if (j < deg[u]) mt[(int64_t)col_edge[p0[u] + j] * 64] = marg - c[u][j];
+                        if (j < deg[u]) msg_st<LDPC_VN_NTS != 0>(mt + (int64_t)col_edge[p0[u] + j] * 64, (T)(marg - c[u][j]));
                     b_one = marg < T(0);  // NaN marginal -> 0 (src/bpa.py:38,62)
                     if (sft) sft[(int64_t)(vbase + u) * 64] = marg;
                 }
@@ -356,7 +376,17 @@ int pick_pow2_ge(int x, int lo, int hi) {
 }
 
 // nodes kept in flight per wave: about 32 VGPRs (128 bytes per lane) of messages, at most 4 nodes
-constexpr int unroll_for(int row_bytes) { return row_bytes * 4 <= 128 ? 4 : (row_bytes * 2 <= 128 ? 2 : 1); }
+#ifndef LDPC_STREAM_UNR_BYTES
+#define LDPC_STREAM_UNR_BYTES 128
+#endif
+#ifndef LDPC_STREAM_UNR_MAX
+#define LDPC_STREAM_UNR_MAX 4
+#endif
+constexpr int unroll_for(int row_bytes) {
+    int u = LDPC_STREAM_UNR_BYTES / row_bytes;
+    u = u > LDPC_STREAM_UNR_MAX ? LDPC_STREAM_UNR_MAX : u;
+    return u >= 8 ? 8 : (u >= 4 ? 4 : (u >= 2 ? 2 : 1));
+}
 
 struct Geometry {
     int tiles, cn_chunks, cpw, vn_chunks, vpw;
