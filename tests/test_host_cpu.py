@@ -124,3 +124,16 @@ def test_registry_surface():
     assert set(np.unique(models["bec"].Channel(0.5).send(x))) <= {0, 2}
     assert set(np.unique(models["bsc"].Channel(0.5).send(x))) <= {0, 1}
     assert models["biawgn"].Channel(2.0).send(x).dtype == np.float64
+
+
+@pytest.mark.parametrize("case", ["HMG", "MAR", "REG_BAD", "REG_ENS", "IREG_ENS"])
+def test_simulation_case_tables_match_reference(case):
+    # arg-lines printed by the reference's simulations.py (captured in tests/golden/simulations_lines.json)
+    from ldpc_decoders_amd import simulations
+
+    with open(os.path.join(GOLDEN, "simulations_lines.json")) as fp:
+        want = json.load(fp)[case]
+    extra = ["--data_dir=/tmp/x", "--console"]
+    assert simulations.lines(case, extra, all_decoders=True) == want
+    bp_only = simulations.lines(case, extra)
+    assert bp_only == [ln for ln in want if ln.split()[2] in ("SPA", "MSA")] and len(bp_only) > 0
