@@ -84,35 +84,47 @@ __device__ __forceinline__ void cn_spa(double (&v)[DCMAX], int deg) {
     }
 }
 
-// ---- sum-product, fp32: phi-domain, leave-one-out -------------------------------------------------
-// phi(x) = -log(tanh(x/2)) = log1p(2/expm1(x)) is its own inverse, so
-//   |c2v_j| = phi( sum_{i != j} phi(|v2c_i|) ),   sign as in min-sum.
-// Same quantity as the reference's tanh product, but it does not saturate at |LLR| ~ 17 the way
-// fp32 tanh does and it avoids the reference's divide (0/0 at v2c == 0, src/bpa.py:74 TODO).
+// ---- sum-product, fp32: leave-one-out in the "distance from certainty" domain -----------------------
+// With t_i = tanh(|v2c_i|/2) the reference computes |c2v_j| = 2 atanh(prod_{i != j} t_i) (src/bpa.py:71-75).  fp32 tanh
+// saturates to exactly 1 at |LLR| ~ 17, so the product is carried as D = 1 - prod instead, built from
+// d_i = 1 - t_i = 2u/(1+u), u = e^-|v2c_i|, with the cancellation-free join  1-(1-x)(1-y) = x + y - xy :
+//     |c2v_j| = ln((2 - D_j) / D_j),   D_j = join over i != j of d_i   (prefix/suffix joins, dc-1 each).
+// Exactly the same quantity as the reference's tanh product (and as the phi-domain statement of the oracle,
+// bp_oracle.spa_phi_check_update); small D (all other edges reliable) keeps full relative precision up to |LLR| ~ 88,
+// D -> 1 (an unreliable edge) gives |c2v| -> 0 with absolute error ~1e-7.  Unlike the reference it has no 0/0 at
+// v2c == 0 (src/bpa.py:74 TODO) and no +-inf / NaN artefacts below |LLR| ~ 88.
 // Agreement with the fp64 reference is a TOLERANCE (tests/test_gpu_parity.py), not bit-exactness.
-__device__ __forceinline__ float phi_f32(float x) { return log1pf(2.0f / expm1f(x)); }
+// 4 transcendental-unit operations per edge (exp2, rcp, rcp, log2).
+__device__ __forceinline__ float spa_d_of_llr(float a) {  // a = |v2c| >= 0  ->  1 - tanh(a/2)
+    const float u = __builtin_amdgcn_exp2f(a * -1.44269504088896340736f);  // e^-a on the exp2 unit (v_exp_f32, ~1 ulp)
+    return (2.0f * u) * __builtin_amdgcn_rcpf(1.0f + u);                   // v_rcp_f32, ~1 ulp
+}
+__device__ __forceinline__ float spa_join(float x, float y) { return fmaf(-x, y, x) + y; }  // 1 - (1-x)(1-y)
+__device__ __forceinline__ float spa_llr_of_d(float D) {  // 2 atanh(1 - D) = ln((2 - D) / D); D == 0 -> +inf
+    return 0.69314718055994530942f * __builtin_amdgcn_logf((2.0f - D) * __builtin_amdgcn_rcpf(D));  // v_log_f32 is log2
+}
 
 template <int DCMAX>
 __device__ __forceinline__ void cn_spa(float (&v)[DCMAX], int deg) {
-    float ph[DCMAX];
+    float d[DCMAX];
     float pre[DCMAX];
     bool parity = false;
     float run = 0.0f;
 #pragma unroll
     for (int j = 0; j < DCMAX; ++j) {
         if (j < deg) {
-            ph[j] = phi_f32(fabsf(v[j]));
+            d[j] = spa_d_of_llr(fabsf(v[j]));
             parity ^= (v[j] < 0.0f);
-            pre[j] = run;  // sum of phi over edges before j
-            run += ph[j];
+            pre[j] = run;  // join over the edges before j
+            run = spa_join(run, d[j]);
         }
     }
-    float suf = 0.0f;  // sum of phi over edges after j
+    float suf = 0.0f;  // join over the edges after j
 #pragma unroll
     for (int j = DCMAX - 1; j >= 0; --j) {
         if (j < deg) {
-            const float mag = phi_f32(pre[j] + suf);
-            suf += ph[j];
+            const float mag = spa_llr_of_d(spa_join(pre[j], suf));
+            suf = spa_join(suf, d[j]);
             const bool own_neg = !(v[j] >= 0.0f);
             v[j] = (parity != own_neg) ? -mag : mag;
         }

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "ldpc_cn.hpp"
 #include "ldpc_common.hpp"
 #include "ldpc_layout.hpp"
 
@@ -78,8 +79,8 @@ __device__ __forceinline__ float lds_ld(const unsigned char* base, uint32_t byte
     return *reinterpret_cast<const float*>(base + byte_off);
 }
 
-template <int DC, int DV, int CR, int VR>
-__global__ __launch_bounds__(64, 2) void k_fused_msa(const float* __restrict__ priors, const uint8_t* __restrict__ y0,
+template <int ALG, int DC, int DV, int CR, int VR>
+__global__ __launch_bounds__(64, 2) void k_fused_bp(const float* __restrict__ priors, const uint8_t* __restrict__ y0,
                                                      long long B, int n, int max_iter, unsigned flags,
                                                      const uint32_t* __restrict__ cn_tab, const uint32_t* __restrict__ vn_tab,
                                                      const int32_t* __restrict__ var_of_slot,
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(64, 2) void k_fused_msa(const float* __restrict__ p
             // The sweep is one software-pipelined stream of LDS traffic: the gathers of check round r+1 (variable
             // group g+1) are issued before round r (group g) is computed, so a wave always has a full round of
             // ds_reads in flight while it does arithmetic.  (The wave is latency-bound otherwise: 2 waves per SIMD.)
-            constexpr int VG = 4;                      // variable rounds per pipeline stage
+            constexpr int VG = ALG == ALG_MSA ? 4 : 2;  // variable rounds per pipeline stage (sum-product needs the registers)
             constexpr int NVG = (VR + VG - 1) / VG;
             const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
             for (;;) {
@@ -185,17 +186,28 @@ __global__ __launch_bounds__(64, 2) void k_fused_msa(const float* __restrict__ p
                         vx ^= __float_as_uint(v[j]);
                     }
                     if constexpr (DC % 2 == 0) synd |= mx; else synd |= ((cn_active[r] >> lane) & 1ull) ? mx : 0u;
-                    // leave-one-out minimum of |v|
+                    // leave-one-out reduction of |v|: minimum (min-sum) or join of 1 - tanh(|v|/2) (sum-product, ldpc_cn.hpp)
                     float pre[DC], suf[DC];
-                    pre[0] = __builtin_huge_valf();
+                    if constexpr (ALG == ALG_MSA) {
+                        pre[0] = __builtin_huge_valf();
 #pragma unroll
-                    for (int j = 1; j < DC; ++j) pre[j] = fminf(pre[j - 1], a[j - 1]);
-                    suf[DC - 1] = __builtin_huge_valf();
+                        for (int j = 1; j < DC; ++j) pre[j] = fminf(pre[j - 1], a[j - 1]);
+                        suf[DC - 1] = __builtin_huge_valf();
 #pragma unroll
-                    for (int j = DC - 2; j >= 0; --j) suf[j] = fminf(suf[j + 1], a[j + 1]);
+                        for (int j = DC - 2; j >= 0; --j) suf[j] = fminf(suf[j + 1], a[j + 1]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) a[j] = spa_d_of_llr(a[j]);
+                        pre[0] = 0.0f;
+#pragma unroll
+                        for (int j = 1; j < DC; ++j) pre[j] = spa_join(pre[j - 1], a[j - 1]);
+                        suf[DC - 1] = 0.0f;
+#pragma unroll
+                        for (int j = DC - 2; j >= 0; --j) suf[j] = spa_join(suf[j + 1], a[j + 1]);
+                    }
                     static_for<0, DC>([&](auto J_) {
                         constexpr int j = decltype(J_)::value;
-                        const float mag = fminf(pre[j], suf[j]);
+                        const float mag = ALG == ALG_MSA ? fminf(pre[j], suf[j]) : spa_llr_of_d(spa_join(pre[j], suf[j]));
                         const float c = __uint_as_float(__float_as_uint(mag) | ((vx ^ __float_as_uint(v[j])) & 0x80000000u));
                         c2v_old[r][j] = c;
                         lds_st_tid<(NPAD + (r * DC + j) * 64) * 4>(c);
@@ -258,17 +270,18 @@ int upload_vec(const std::vector<T>& h, T** d) {
 }
 
 struct ShapeEntry {
-    int DC, DV, CR, VR;
+    int alg, DC, DV, CR, VR;
     const void* kernel;
 };
 
-template <int DC, int DV, int CR, int VR>
+template <int ALG, int DC, int DV, int CR, int VR>
 constexpr ShapeEntry shape_entry() {
-    return ShapeEntry{DC, DV, CR, VR, (const void*)k_fused_msa<DC, DV, CR, VR>};
+    return ShapeEntry{ALG, DC, DV, CR, VR, (const void*)k_fused_bp<ALG, DC, DV, CR, VR>};
 }
 
-// instantiated shapes: (3,6)-regular codes up to n = 1216 and up to n = 512
-const ShapeEntry kShapes[] = {shape_entry<6, 3, 4, 8>(), shape_entry<6, 3, 10, 19>()};
+// instantiated shapes: (3,6)-regular codes up to n = 512 and up to n = 1216, min-sum and sum-product (fp32)
+const ShapeEntry kShapes[] = {shape_entry<ALG_MSA, 6, 3, 4, 8>(), shape_entry<ALG_MSA, 6, 3, 10, 19>(),
+                              shape_entry<ALG_SPA, 6, 3, 4, 8>(), shape_entry<ALG_SPA, 6, 3, 10, 19>()};
 
 }  // namespace
 
@@ -293,11 +306,11 @@ int fused_plan_create(Decoder* d) {
     const Code* c = d->code;
     d->fused = new FusedPlan();
     FusedPlan* p = d->fused;
-    if (d->alg != ALG_MSA || d->dtype != DT_F32) return LDPC_OK;  // other combinations stay on the streaming backend
+    if ((d->alg != ALG_MSA && d->alg != ALG_SPA) || d->dtype != DT_F32) return LDPC_OK;  // the rest stays on the streaming backend
     if (c->min_dc != c->max_dc) return LDPC_OK;
     const ShapeEntry* shape = nullptr;
     for (const ShapeEntry& s : kShapes)
-        if (c->max_dc == s.DC && c->max_dv <= s.DV && c->m <= s.CR * 64 && c->n <= s.VR * 64) {
+        if (s.alg == d->alg && c->max_dc == s.DC && c->max_dv <= s.DV && c->m <= s.CR * 64 && c->n <= s.VR * 64) {
             shape = &s;
             break;
         }
@@ -436,7 +449,7 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
     }
     const ShapeEntry* shape = nullptr;
     for (const ShapeEntry& s : kShapes)
-        if (s.DC == p->DC && s.DV == p->DV && s.CR == p->CR && s.VR == p->VR) shape = &s;
+        if (s.alg == d->alg && s.DC == p->DC && s.DV == p->DV && s.CR == p->CR && s.VR == p->VR) shape = &s;
     const Code* c = d->code;
     LDPC_HIP_TRY(hipMemsetAsync(p->d_next, 0, 8, st));
     long long waves = (long long)p->num_cu * p->waves_per_cu;
