@@ -58,9 +58,9 @@ int ldpc_decoder_destroy(ldpc_decoder_t dec);
 /* backend actually used by the last decode (LDPC_BACKEND_*) and the number of sweeps the batch ran */
 int ldpc_decoder_last_stats(ldpc_decoder_t dec, int* backend, int* sweeps);
 
-/* Fused-backend plan of this decoder: out8 = {available, conflict-free LDS gather cycles per sweep, extra bank-conflict
+/* Fused-backend plan of this decoder: out8 = {wavefronts per frame (0 = fused backend unavailable), conflict-free LDS gather cycles per sweep, extra bank-conflict
  * cycles with the trivial placement, extra cycles with the planned placement, resident waves per CU, LDS bytes per
- * wave, check rounds, variable rounds}. */
+ * frame, check rounds, variable rounds}. */
 int ldpc_decoder_fused_info(ldpc_decoder_t dec, double* out8);
 
 /* Per-kernel timing for roofline reports: when enabled, decode calls bracket their dominant kernels with HIP events

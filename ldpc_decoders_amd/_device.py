@@ -157,8 +157,8 @@ class DecoderHandle:
     def fused_info(self):
         out = (ctypes.c_double * 8)()
         _lib.check(_lib.load().ldpc_decoder_fused_info(self.h, out))
-        keys = ("available", "lds_gather_cycles_min", "conflict_cycles_identity", "conflict_cycles_planned", "waves_per_cu",
-                "lds_bytes_per_wave", "check_rounds", "variable_rounds")
+        keys = ("waves_per_frame", "lds_gather_cycles_min", "conflict_cycles_identity", "conflict_cycles_planned", "waves_per_cu",
+                "lds_bytes_per_frame", "check_rounds", "variable_rounds")
         return dict(zip(keys, list(out)))
 
     def set_profiling(self, on):

@@ -1,29 +1,29 @@
-// Fused on-chip backend: one wavefront owns one frame for ALL of its sweeps; messages never leave the CU.
+// Fused on-chip backend: one workgroup of NW wavefronts owns one frame for ALL of its sweeps; messages never leave the CU.
 //
 // Regime: (dv,dc)-regular codes whose per-frame state fits the LDS (n = 1200 (3,6): 20 KB -> 8 frames per CU).
 // The HBM traffic of a frame shrinks from sizeof(T)(4E+n) PER SWEEP (streaming backend) to its priors in and its
 // decisions out, once; the kernel is bound by LDS gathers and VALU instead.
 //
 // Mapping (all tables are built once on the host, FusedPlan):
-//   * lane L of the wave owns check slots (r, L), r = 0..CR-1, and variable slots (q, L), q = 0..VR-1.
-//   * registers: the check->variable messages of the owned checks (c2v_old[CR][DC]), the priors of the owned
+//   * wave w, lane L owns check slots (w*CRW + r, L), r < CRW, and variable slots (w*VRW + q, L), q < VRW.
+//   * registers: the check->variable messages of the owned checks (c2v_old[CRW][DC]), the priors of the owned
 //     variables, and every gather address (packed 16-bit LDS byte offsets) -- loaded once per launch.
-//   * LDS (per wave): marg[VR*64]  marginal of variable slot s at dword s
-//                     c2v [(CR*DC+1)*64]  message of (check slot (r,L), edge position j) at dword (r*DC+j)*64+L;
-//                                         the last row stays 0 (target of padded gathers)
-//   * check phase : v2c_j = marg[var] - c2v_old_j  (6 LDS gathers), leave-one-out min + sign parity, write c2v
+//   * LDS (per frame): marg[VR*64]  marginal of variable slot s at dword s            (VR = NW*VRW)
+//                      c2v [CR*DC*64 (+64)]  message of (check slot (R,L), edge position j) at dword (R*DC+j)*64+L;
+//                                            an optional last row stays 0 (target of the gathers of missing edges)
+//   * check phase : v2c_j = marg[var] - c2v_old_j  (dc LDS gathers), leave-one-out min / join + sign parity, write c2v
 //                   (lane-contiguous, conflict-free); the syndrome of the previous decisions falls out of the same
 //                   gathers (sign of marg) -- that is the reference's early-exit test (src/bpa.py:29).
-//   * variable phase: marginal = prior + ((c_a + c_b) + c_c) in ascending edge order (3 LDS gathers), write marg.
-//   Single-wave workgroups: LDS is private to the wave and DS operations of one wave execute in order, so the two
-//   phases need no s_barrier.
+//   * variable phase: marginal = prior + ((0 + c_a) + c_b) + c_c in ascending edge order (dv LDS gathers), write marg.
+//   NW = 1: LDS is private to the wave and DS operations of one wave execute in order, so the phases need no barrier.
+//   NW = 2: twice the resident waves per CU (the kernel is latency-bound at 2 waves per SIMD); one s_barrier after each
+//           phase, the syndrome verdicts of the two waves are exchanged through padded c2v slots each wave owns.
 //
 // Arithmetic identical to the streaming backend / reference (src/bpa.py:17-63, 86-102): the leave-one-out minimum
 // equals "second minimum at the first arg-min, first minimum elsewhere"; min/compare/negate/add/sub only.
 #include <algorithm>
-#include <numeric>
-
 #include <cstdlib>
+#include <numeric>
 #include <type_traits>
 
 #include "ldpc_cn.hpp"
@@ -34,14 +34,17 @@ namespace ldpc {
 
 struct FusedPlan {
     bool ok = false;
-    int DC = 0, DV = 0, CR = 0, VR = 0;
-    uint32_t* d_cn_tab = nullptr;     // [(CR*DC+1)/2][64] two 16-bit marg byte offsets per word
-    uint32_t* d_vn_tab = nullptr;     // [(VR*DV+1)/2][64] two 16-bit c2v byte offsets per word
+    int shape = -1;                    // index into kShapes
+    int DC = 0, DV = 0, CR = 0, VR = 0, NW = 1;
+    uint32_t* d_cn_tab = nullptr;      // [NW][(CRW*DC+1)/2][64] two 16-bit marg byte offsets per word
+    uint32_t* d_vn_tab = nullptr;      // [NW][(VRW*DV+1)/2][64] two 16-bit c2v byte offsets per word
     int32_t* d_var_of_slot = nullptr;  // [VR*64] variable index of a slot, -1 for padding
-    unsigned long long* d_cn_active = nullptr;  // [CR] lanes holding a real check in round r
+    unsigned long long* d_cn_active = nullptr;  // [CR] lanes holding a real check in round R
     unsigned long long* d_next = nullptr;       // frame dispenser
+    int sync_off[2] = {0, 0};          // NW = 2: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
+    int zero_row = 0;                  // 1: the c2v area ends with an always-zero row
     size_t lds_bytes = 0;
-    int waves_per_cu = 0, num_cu = 0;
+    int groups_per_cu = 0, num_cu = 0;
     double extra_identity = 0, extra_planned = 0, base_cycles = 0;
 };
 
@@ -79,96 +82,137 @@ __device__ __forceinline__ float lds_ld(const unsigned char* base, uint32_t byte
     return *reinterpret_cast<const float*>(base + byte_off);
 }
 
-template <int ALG, int DC, int DV, int CR, int VR>
-__global__ __launch_bounds__(64, 2) void k_fused_bp(const float* __restrict__ priors, const uint8_t* __restrict__ y0,
-                                                     long long B, int n, int max_iter, unsigned flags,
-                                                     const uint32_t* __restrict__ cn_tab, const uint32_t* __restrict__ vn_tab,
-                                                     const int32_t* __restrict__ var_of_slot,
-                                                     const u64* __restrict__ cn_active, uint8_t* __restrict__ xhat,
-                                                     int32_t* __restrict__ iters, u64* __restrict__ next_frame) {
+struct FusedArgs {
+    const float* priors;
+    const uint8_t* y0;
+    long long B;
+    int n, max_iter;
+    unsigned flags;
+    const uint32_t* cn_tab;
+    const uint32_t* vn_tab;
+    const int32_t* var_of_slot;
+    const u64* cn_active;
+    uint8_t* xhat;
+    int32_t* iters;
+    u64* next_frame;
+    int sync_off0, sync_off1, zero_row;
+};
+
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const FusedArgs A) {
+    constexpr int CR = CRW * NW, VR = VRW * NW;
     constexpr int NPAD = VR * 64;
-    constexpr int CNW = (CR * DC + 1) / 2, VNW = (VR * DV + 1) / 2;
+    constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VRW * DV + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
-    float* lds_marg = reinterpret_cast<float*>(smem);
-    float* lds_c2v = reinterpret_cast<float*>(smem) + NPAD;
+    const int lane = threadIdx.x & 63;
+    const int w = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    float* lds_marg = reinterpret_cast<float*>(smem) + w * VRW * 64;  // this wave's marginal rows
+    const int32_t* vslot = A.var_of_slot + w * VRW * 64;
+    const u64* cn_active = A.cn_active + w * CRW;
+    const int n = A.n, max_iter = A.max_iter;
 
     // gather addresses, resident in registers for the whole launch
     uint32_t cn_idx[CNW], vn_idx[VNW];
 #pragma unroll
-    for (int i = 0; i < CNW; ++i) cn_idx[i] = cn_tab[i * 64 + lane];
+    for (int i = 0; i < CNW; ++i) cn_idx[i] = A.cn_tab[(w * CNW + i) * 64 + lane];
 #pragma unroll
-    for (int i = 0; i < VNW; ++i) vn_idx[i] = vn_tab[i * 64 + lane];
-    lds_c2v[CR * DC * 64 + lane] = 0.0f;  // the always-zero row
+    for (int i = 0; i < VNW; ++i) vn_idx[i] = A.vn_tab[(w * VNW + i) * 64 + lane];
+    if (A.zero_row && w == 0) reinterpret_cast<float*>(smem)[NPAD + CR * DC * 64 + lane] = 0.0f;  // the always-zero row
 
-    const bool early = !(flags & FLAG_NO_EARLY_EXIT);
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+    const uint32_t m0_c2v = lds_base + (uint32_t)(NPAD + w * CRW * DC * 64) * 4;  // this wave's c2v rows
+    const uint32_t m0_marg = lds_base + (uint32_t)(w * VRW * 64) * 4;            // this wave's marginal rows
+    const uint32_t my_sync = (uint32_t)(w == 0 ? A.sync_off0 : A.sync_off1);
+    const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
+
+    // verdict exchange between the NW waves of a frame: each wave publishes "my checks see an unsatisfied syndrome" in a
+    // padded c2v slot it owns (nobody else ever writes it; its own garbage write precedes in program order) -> barrier ->
+    // everybody reads all verdicts.  The next write to those slots happens after the following barrier.
+    auto any_unsat = [&](bool mine) -> bool {
+        if constexpr (NW == 1) {
+            return mine;
+        } else {
+            if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_sync) = mine ? 1u : 0u;
+            __syncthreads();
+            const uint32_t v0 = *reinterpret_cast<volatile uint32_t*>(smem + A.sync_off0);
+            const uint32_t v1 = *reinterpret_cast<volatile uint32_t*>(smem + A.sync_off1);
+            return (v0 | v1) != 0u;
+        }
+    };
+
     for (;;) {
         u64 fr = 0;
-        if (lane == 0) fr = atomicAdd(next_frame, 1ull);
-        fr = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(fr >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)fr);
-        if ((long long)fr >= B) break;
-        const float* pf = priors + fr * n;
+        if constexpr (NW == 1) {
+            if (lane == 0) fr = atomicAdd(A.next_frame, 1ull);
+            fr = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(fr >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)fr);
+        } else {
+            __syncthreads();  // the verdict slots of the previous frame have been read by everybody
+            if (w == 0 && lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + A.sync_off0) = (uint32_t)atomicAdd(A.next_frame, 1ull);
+            __syncthreads();
+            fr = (u64) __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(smem + A.sync_off0));
+        }
+        if ((long long)fr >= A.B) break;
+        const float* pf = A.priors + fr * n;
 
-        float prior[VR];
-        float c2v_old[CR][DC];
-        unsigned xb = 0;  // bit q = hard decision of variable slot (q, lane)
+        float prior[VRW];
+        float c2v_old[CRW][DC];
+        unsigned xb = 0;  // bit q = hard decision of variable slot (w*VRW + q, lane)
 #pragma unroll
-        for (int q = 0; q < VR; ++q) {
-            const int v = var_of_slot[q * 64 + lane];
+        for (int q = 0; q < VRW; ++q) {
+            const int v = vslot[q * 64 + lane];
             prior[q] = v >= 0 ? pf[v] : 0.0f;
         }
 #pragma unroll
-        for (int r = 0; r < CR; ++r)
+        for (int r = 0; r < CRW; ++r)
 #pragma unroll
             for (int j = 0; j < DC; ++j) c2v_old[r][j] = 0.0f;
 
         int it = 0;
         bool left_at_0 = false;
-        if (y0 != nullptr) {
+        if (A.y0 != nullptr) {
             // iteration-0 test of the received hard word (src/bpa.py:20,29): park it in the marg area as -+1
-            const uint8_t* yf = y0 + fr * n;
+            const uint8_t* yf = A.y0 + fr * n;
 #pragma unroll
-            for (int q = 0; q < VR; ++q) {
-                const int v = var_of_slot[q * 64 + lane];
+            for (int q = 0; q < VRW; ++q) {
+                const int v = vslot[q * 64 + lane];
                 const bool one = v >= 0 && yf[v] != 0;
                 lds_marg[q * 64 + lane] = one ? -1.0f : 1.0f;
                 xb |= one ? (1u << q) : 0u;
             }
-            __builtin_amdgcn_wave_barrier();
+            if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
             u64 unsat = 0;
 #pragma unroll
-            for (int r = 0; r < CR; ++r) {
+            for (int r = 0; r < CRW; ++r) {
                 u64 par = 0;
 #pragma unroll
-                for (int j = 0; j < DC; ++j) par ^= __ballot(lds_ld(smem, half_of<CR * DC>(cn_idx, r * DC + j)) < 0.0f);
+                for (int j = 0; j < DC; ++j) par ^= __ballot(lds_ld(smem, half_of<CRW * DC>(cn_idx, r * DC + j)) < 0.0f);
                 if constexpr (DC % 2 == 0) unsat |= par; else unsat |= par & cn_active[r];
             }
-            left_at_0 = early && unsat == 0;
-            __builtin_amdgcn_wave_barrier();
+            left_at_0 = early && !any_unsat(unsat != 0);
+            if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         }
         if (!left_at_0) {
 #pragma unroll
-            for (int q = 0; q < VR; ++q) lds_marg[q * 64 + lane] = prior[q];
-            __builtin_amdgcn_wave_barrier();
+            for (int q = 0; q < VRW; ++q) lds_marg[q * 64 + lane] = prior[q];
+            if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
             // The sweep is one software-pipelined stream of LDS traffic: the gathers of check round r+1 (variable
             // group g+1) are issued before round r (group g) is computed, so a wave always has a full round of
-            // ds_reads in flight while it does arithmetic.  (The wave is latency-bound otherwise: 2 waves per SIMD.)
-            constexpr int VG = ALG == ALG_MSA ? 4 : 2;  // variable rounds per pipeline stage (sum-product needs the registers)
-            constexpr int NVG = (VR + VG - 1) / VG;
-            const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+            // ds_reads in flight while it does arithmetic.
+            constexpr int VG = (ALG == ALG_MSA && NW == 1) ? 4 : 2;  // variable rounds per pipeline stage (register budget)
+            constexpr int NVG = (VRW + VG - 1) / VG;
             for (;;) {
                 if (max_iter > 0 && it >= max_iter) break;
-                lds_set_m0(lds_base);
+                lds_set_m0(m0_c2v);
                 // ---------------- check phase (+ syndrome of the decisions of the previous sweep)
                 uint32_t synd = 0;  // bit 31: some owned check is unsatisfied by the previous decisions
                 float mg[2][DC];
 #pragma unroll
-                for (int j = 0; j < DC; ++j) mg[0][j] = lds_ld(smem, half_of<CR * DC>(cn_idx, j));
-                static_for<0, CR>([&](auto R_) {
+                for (int j = 0; j < DC; ++j) mg[0][j] = lds_ld(smem, half_of<CRW * DC>(cn_idx, j));
+                static_for<0, CRW>([&](auto R_) {
                     constexpr int r = decltype(R_)::value;
-                    if constexpr (r + 1 < CR) {
+                    if constexpr (r + 1 < CRW) {
 #pragma unroll
-                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_ld(smem, half_of<CR * DC>(cn_idx, (r + 1) * DC + j));
+                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_ld(smem, half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this round's arithmetic
                     // Sign handling on the raw IEEE bits (bit 31), all in the vector ALU: row parity = XOR of the sign
@@ -210,20 +254,21 @@ __global__ __launch_bounds__(64, 2) void k_fused_bp(const float* __restrict__ pr
                         const float mag = ALG == ALG_MSA ? fminf(pre[j], suf[j]) : spa_llr_of_d(spa_join(pre[j], suf[j]));
                         const float c = __uint_as_float(__float_as_uint(mag) | ((vx ^ __float_as_uint(v[j])) & 0x80000000u));
                         c2v_old[r][j] = c;
-                        lds_st_tid<(NPAD + (r * DC + j) * 64) * 4>(c);
+                        lds_st_tid<(r * DC + j) * 256>(c);
                     });
                 });
-                const u64 unsat = __ballot((synd & 0x80000000u) != 0u);
-                if (early && it > 0 && unsat == 0) break;
-                __builtin_amdgcn_wave_barrier();
+                const bool unsat = any_unsat(__ballot((synd & 0x80000000u) != 0u) != 0);  // NW > 1: contains the barrier
+                if (early && it > 0 && !unsat) break;
+                if constexpr (NW == 1) __builtin_amdgcn_wave_barrier();
                 // ---------------- variable phase
+                lds_set_m0(m0_marg);
                 xb = 0;
                 float cv[2][VG][DV];
 #pragma unroll
                 for (int u = 0; u < VG; ++u)
 #pragma unroll
                     for (int j = 0; j < DV; ++j)
-                        if (u < VR) cv[0][u][j] = lds_ld(smem, half_of<VR * DV>(vn_idx, u * DV + j));
+                        if (u < VRW) cv[0][u][j] = lds_ld(smem, half_of<VRW * DV>(vn_idx, u * DV + j));
                 static_for<0, NVG>([&](auto G_) {
                     constexpr int g = decltype(G_)::value;
                     if constexpr (g + 1 < NVG) {
@@ -231,14 +276,14 @@ __global__ __launch_bounds__(64, 2) void k_fused_bp(const float* __restrict__ pr
                         for (int u = 0; u < VG; ++u)
 #pragma unroll
                             for (int j = 0; j < DV; ++j)
-                                if ((g + 1) * VG + u < VR)
-                                    cv[(g + 1) & 1][u][j] = lds_ld(smem, half_of<VR * DV>(vn_idx, ((g + 1) * VG + u) * DV + j));
+                                if ((g + 1) * VG + u < VRW)
+                                    cv[(g + 1) & 1][u][j] = lds_ld(smem, half_of<VRW * DV>(vn_idx, ((g + 1) * VG + u) * DV + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     static_for<0, VG>([&](auto U_) {
                         constexpr int u = decltype(U_)::value;
                         constexpr int q = g * VG + u;
-                        if constexpr (q < VR) {
+                        if constexpr (q < VRW) {
                             float s = 0.0f + cv[g & 1][u][0];  // as scipy: accumulate from +0.0 (keeps -0.0 out of the marginals)
 #pragma unroll
                             for (int j = 1; j < DV; ++j) s += cv[g & 1][u][j];
@@ -248,15 +293,15 @@ __global__ __launch_bounds__(64, 2) void k_fused_bp(const float* __restrict__ pr
                         }
                     });
                 });
-                __builtin_amdgcn_wave_barrier();
+                if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
                 ++it;
             }
         }
-        if (lane == 0) iters[fr] = it;
-        uint8_t* xf = xhat + fr * n;
+        if (w == 0 && lane == 0) A.iters[fr] = it;
+        uint8_t* xf = A.xhat + fr * n;
 #pragma unroll
-        for (int q = 0; q < VR; ++q) {
-            const int v = var_of_slot[q * 64 + lane];
+        for (int q = 0; q < VRW; ++q) {
+            const int v = vslot[q * 64 + lane];
             if (v >= 0) xf[v] = (uint8_t)((xb >> q) & 1u);
         }
     }
@@ -270,18 +315,23 @@ int upload_vec(const std::vector<T>& h, T** d) {
 }
 
 struct ShapeEntry {
-    int alg, DC, DV, CR, VR;
+    int alg, DC, DV, CRW, VRW, NW;
     const void* kernel;
 };
 
-template <int ALG, int DC, int DV, int CR, int VR>
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW>
 constexpr ShapeEntry shape_entry() {
-    return ShapeEntry{ALG, DC, DV, CR, VR, (const void*)k_fused_bp<ALG, DC, DV, CR, VR>};
+    return ShapeEntry{ALG, DC, DV, CRW, VRW, NW, (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW>};
 }
 
-// instantiated shapes: (3,6)-regular codes up to n = 512 and up to n = 1216, min-sum and sum-product (fp32)
-const ShapeEntry kShapes[] = {shape_entry<ALG_MSA, 6, 3, 4, 8>(), shape_entry<ALG_MSA, 6, 3, 10, 19>(),
-                              shape_entry<ALG_SPA, 6, 3, 4, 8>(), shape_entry<ALG_SPA, 6, 3, 10, 19>()};
+// instantiated shapes, (3,6)-regular codes, min-sum and sum-product (fp32).  Preference order = table order:
+// two waves per frame for n <= 1280 (fully regular codes only: no room for the zero row), else one wave per frame.
+const ShapeEntry kShapes[] = {
+    shape_entry<ALG_MSA, 6, 3, 4, 8, 1>(),   shape_entry<ALG_SPA, 6, 3, 4, 8, 1>(),    // m <= 256, n <= 512
+    shape_entry<ALG_MSA, 6, 3, 5, 10, 2>(),  shape_entry<ALG_SPA, 6, 3, 5, 10, 2>(),   // m <= 640, n <= 1280, 2 waves/frame
+    shape_entry<ALG_MSA, 6, 3, 10, 19, 1>(), shape_entry<ALG_SPA, 6, 3, 10, 19, 1>(),  // m <= 640, n <= 1216, 1 wave/frame
+};
+constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
 }  // namespace
 
@@ -291,12 +341,12 @@ int fused_info(const Decoder* d, double* out8) {
     const FusedPlan* p = d->fused;
     for (int i = 0; i < 8; ++i) out8[i] = 0;
     if (!p || !p->ok) return LDPC_OK;
-    out8[0] = 1;
+    out8[0] = p->NW;              // wavefronts per frame (0 = fused backend not available)
     out8[1] = p->base_cycles;     // conflict-free LDS cycles of the gathers per sweep
     out8[2] = p->extra_identity;  // extra bank-conflict cycles per sweep, trivial placement
     out8[3] = p->extra_planned;   // ... with the planned placement
-    out8[4] = p->waves_per_cu;
-    out8[5] = (double)p->lds_bytes;
+    out8[4] = p->groups_per_cu * p->NW;  // resident waves per CU
+    out8[5] = (double)p->lds_bytes;      // LDS bytes per frame
     out8[6] = p->CR;
     out8[7] = p->VR;
     return LDPC_OK;
@@ -308,23 +358,35 @@ int fused_plan_create(Decoder* d) {
     FusedPlan* p = d->fused;
     if ((d->alg != ALG_MSA && d->alg != ALG_SPA) || d->dtype != DT_F32) return LDPC_OK;  // the rest stays on the streaming backend
     if (c->min_dc != c->max_dc) return LDPC_OK;
-    const ShapeEntry* shape = nullptr;
-    for (const ShapeEntry& s : kShapes)
-        if (s.alg == d->alg && c->max_dc == s.DC && c->max_dv <= s.DV && c->m <= s.CR * 64 && c->n <= s.VR * 64) {
-            shape = &s;
-            break;
-        }
-    if (!shape) return LDPC_OK;
-    const int DC = shape->DC, DV = shape->DV, CR = shape->CR, VR = shape->VR;
-    p->DC = DC; p->DV = DV; p->CR = CR; p->VR = VR;
-    const int NPAD = VR * 64;
+    const bool full_dv = c->min_dv == c->max_dv;  // every variable has all its DV edges: no zero row needed
+    int force_nw = 0;
+    if (const char* e = std::getenv("LDPC_FUSED_NW")) force_nw = atoi(e);
+    int si = -1;
+    for (int i = 0; i < kNumShapes && si < 0; ++i) {
+        const ShapeEntry& s = kShapes[i];
+        const int CR = s.CRW * s.NW, VR = s.VRW * s.NW;
+        if (s.alg != d->alg || c->max_dc != s.DC || c->max_dv > s.DV || c->m > CR * 64 || c->n > VR * 64) continue;
+        if (force_nw && s.NW != force_nw) continue;
+        if (s.NW > 1 && (!full_dv || c->max_dv != s.DV || CR * 64 - c->m < s.NW)) continue;  // needs padded check slots for the hand-off
+        si = i;
+    }
+    if (si < 0) return LDPC_OK;
+    const ShapeEntry& shape = kShapes[si];
+    const int DC = shape.DC, DV = shape.DV, NW = shape.NW, CRW = shape.CRW, VRW = shape.VRW;
+    const int CR = CRW * NW, VR = VRW * NW, NPAD = VR * 64;
+    p->shape = si; p->DC = DC; p->DV = DV; p->CR = CR; p->VR = VR; p->NW = NW;
+    p->zero_row = (NW == 1) ? 1 : 0;
 
-    // ---- layout: check c -> slot (r, lane), variable v -> slot, edge positions (ldpc_layout.hpp)
+    // ---- layout: check c -> slot (R, lane), variable v -> slot, edge positions (ldpc_layout.hpp)
     FusedLayout L;
     const char* mode = std::getenv("LDPC_FUSED_LAYOUT");
     const char* ms = std::getenv("LDPC_FUSED_PLAN_MS");
     if (mode && std::string(mode) == "identity") {
         identity_layout(*c, DC, DV, &L);
+        if (NW > 1) {  // spread the checks / variables evenly over the waves so that every wave keeps padded slots
+            for (int cc = 0; cc < c->m; ++cc) L.chk_slot[cc] = (int)((int64_t)cc * CR * 64 / c->m);
+            for (int v = 0; v < c->n; ++v) L.var_slot[v] = (int)((int64_t)v * NPAD / c->n);
+        }
         L.base_cycles = 2.0 * (CR * DC + VR * DV);
         L.extra_cycles_identity = L.extra_cycles_planned = layout_extra_cycles(*c, DC, DV, CR, VR, L);
     } else {
@@ -335,29 +397,33 @@ int fused_plan_create(Decoder* d) {
     p->base_cycles = L.base_cycles;
     const std::vector<int>&chk_slot = L.chk_slot, &var_slot = L.var_slot, &edge_pos = L.edge_pos, &var_pos = L.var_pos;
 
-    std::vector<uint32_t> cn_tab((size_t)((CR * DC + 1) / 2) * 64, 0), vn_tab((size_t)((VR * DV + 1) / 2) * 64, 0);
+    const int CNW = (CRW * DC + 1) / 2, VNW = (VRW * DV + 1) / 2;
+    std::vector<uint32_t> cn_tab((size_t)NW * CNW * 64, 0), vn_tab((size_t)NW * VNW * 64, 0);
     std::vector<int32_t> var_of_slot((size_t)NPAD, -1);
     std::vector<u64> cn_active((size_t)CR, 0);
-    auto put16 = [](std::vector<uint32_t>& tab, int k, int lane, uint32_t val) {
-        uint32_t& w = tab[(size_t)(k >> 1) * 64 + lane];
+    // global gather index K = R*DC + j (check side) or Q*DV + j (variable side) -> (wave, packed half-word) of the table
+    auto put16 = [](std::vector<uint32_t>& tab, int words_per_wave, int per_wave, int K, int lane, uint32_t val) {
+        const int wv = K / per_wave, k = K % per_wave;
+        uint32_t& w = tab[((size_t)wv * words_per_wave + (k >> 1)) * 64 + lane];
         w = (k & 1) ? ((w & 0x0000ffffu) | (val << 16)) : ((w & 0xffff0000u) | val);
     };
     const uint32_t c2v_base = (uint32_t)NPAD * 4;
     std::vector<int64_t> cn_addr((size_t)CR * DC * 64, -1), vn_addr((size_t)VR * DV * 64, -1);  // byte offsets, -1 = padded lane
     for (int v = 0; v < c->n; ++v) var_of_slot[var_slot[v]] = v;
     for (int cc = 0; cc < c->m; ++cc) {
-        const int r = chk_slot[cc] / 64, lane = chk_slot[cc] % 64;
-        cn_active[r] |= 1ull << lane;
+        const int R = chk_slot[cc] / 64, lane = chk_slot[cc] % 64;
+        cn_active[R] |= 1ull << lane;
         for (int k = c->row_ptr[cc]; k < c->row_ptr[cc + 1]; ++k)
-            cn_addr[(size_t)(r * DC + edge_pos[k]) * 64 + lane] = (int64_t)var_slot[c->edge_var[k]] * 4;
+            cn_addr[(size_t)(R * DC + edge_pos[k]) * 64 + lane] = (int64_t)var_slot[c->edge_var[k]] * 4;
     }
     for (int v = 0; v < c->n; ++v) {
-        const int q = var_slot[v] / 64, lane = var_slot[v] % 64;
-        // a real variable with fewer than DV edges sums the always-zero row for the missing ones
-        for (int j = 0; j < DV; ++j) vn_addr[(size_t)(q * DV + j) * 64 + lane] = c2v_base + (int64_t)(CR * DC * 64 + lane) * 4;
+        const int Q = var_slot[v] / 64, lane = var_slot[v] % 64;
+        // a real variable with fewer than DV edges sums the always-zero row for the missing ones (NW == 1 shapes only)
+        if (p->zero_row)
+            for (int j = 0; j < DV; ++j) vn_addr[(size_t)(Q * DV + j) * 64 + lane] = c2v_base + (int64_t)(CR * DC * 64 + lane) * 4;
         for (int pidx = c->col_ptr[v]; pidx < c->col_ptr[v + 1]; ++pidx) {
             const int k = c->col_edge[pidx], cs = chk_slot[c->edge_chk[k]];
-            vn_addr[(size_t)(q * DV + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(((cs / 64) * DC + edge_pos[k]) * 64 + cs % 64) * 4;
+            vn_addr[(size_t)(Q * DV + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(((cs / 64) * DC + edge_pos[k]) * 64 + cs % 64) * 4;
         }
     }
     // padded lanes may read anything: let them repeat an address of their own half-wave (LDS broadcast, no extra cycle)
@@ -373,10 +439,10 @@ int fused_plan_create(Decoder* d) {
     if (DC % 2 == 0) {
         // even dc: a padded check lane reads ONE marginal dc times, so its sign parity is even and it never shows up in
         // the syndrome (no lane mask needed).  Pick, per half-wave, the slot that collides least with the real reads.
-        for (int r = 0; r < CR; ++r)
+        for (int R = 0; R < CR; ++R)
             for (int h = 0; h < 2; ++h) {
                 bool any_pad = false;
-                for (int l = 0; l < 32; ++l) any_pad |= cn_addr[(size_t)(r * DC) * 64 + h * 32 + l] < 0;
+                for (int l = 0; l < 32; ++l) any_pad |= cn_addr[(size_t)(R * DC) * 64 + h * 32 + l] < 0;
                 if (!any_pad) continue;
                 int best_slot = 0, best_cost = 1 << 30;
                 for (int slot = 0; slot < NPAD && best_cost > 0; ++slot) {
@@ -384,7 +450,7 @@ int fused_plan_create(Decoder* d) {
                     for (int j = 0; j < DC; ++j) {
                         bool clash = false, same = false;
                         for (int l = 0; l < 32; ++l) {
-                            const int64_t a = cn_addr[(size_t)(r * DC + j) * 64 + h * 32 + l];
+                            const int64_t a = cn_addr[(size_t)(R * DC + j) * 64 + h * 32 + l];
                             if (a < 0) continue;
                             if (a == (int64_t)slot * 4) same = true;
                             else if (((a / 4) & 31) == (slot & 31)) clash = true;
@@ -395,18 +461,30 @@ int fused_plan_create(Decoder* d) {
                 }
                 for (int j = 0; j < DC; ++j)
                     for (int l = 0; l < 32; ++l) {
-                        int64_t& a = cn_addr[(size_t)(r * DC + j) * 64 + h * 32 + l];
+                        int64_t& a = cn_addr[(size_t)(R * DC + j) * 64 + h * 32 + l];
                         if (a < 0) a = (int64_t)best_slot * 4;
                     }
             }
     }
     fill_padding(cn_addr, 0);
     fill_padding(vn_addr, c2v_base);
-    for (int k = 0; k < CR * DC; ++k)
-        for (int lane = 0; lane < 64; ++lane) put16(cn_tab, k, lane, (uint32_t)cn_addr[(size_t)k * 64 + lane]);
-    for (int k = 0; k < VR * DV; ++k)
-        for (int lane = 0; lane < 64; ++lane) put16(vn_tab, k, lane, (uint32_t)vn_addr[(size_t)k * 64 + lane]);
-    p->lds_bytes = (size_t)(NPAD + (CR * DC + 1) * 64) * 4;
+    for (int K = 0; K < CR * DC; ++K)
+        for (int lane = 0; lane < 64; ++lane) put16(cn_tab, CNW, CRW * DC, K, lane, (uint32_t)cn_addr[(size_t)K * 64 + lane]);
+    for (int K = 0; K < VR * DV; ++K)
+        for (int lane = 0; lane < 64; ++lane) put16(vn_tab, VNW, VRW * DV, K, lane, (uint32_t)vn_addr[(size_t)K * 64 + lane]);
+    if (NW > 1) {
+        // hand-off words: for each wave the c2v slot (position dc-1) of one of its padded check lanes, in its LAST round
+        // that has one (so the wave's own garbage write to it precedes the verdict write in program order)
+        for (int wv = 0; wv < NW; ++wv) {
+            int found = -1;
+            for (int R = (wv + 1) * CRW - 1; R >= wv * CRW && found < 0; --R)
+                for (int lane = 0; lane < 64 && found < 0; ++lane)
+                    if (!((cn_active[R] >> lane) & 1ull)) found = (int)c2v_base + ((R * DC + DC - 1) * 64 + lane) * 4;
+            if (found < 0) return LDPC_OK;  // (plan stays !ok -> streaming backend; practically unreachable)
+            p->sync_off[wv] = found;
+        }
+    }
+    p->lds_bytes = (size_t)(NPAD + (CR * DC + p->zero_row) * 64) * 4;
     if (p->lds_bytes > 65535) return LDPC_OK;  // 16-bit offsets
     LDPC_HIP_TRY(hipSetDevice(c->device));
     LDPC_TRY(upload_vec(cn_tab, &p->d_cn_tab));
@@ -418,11 +496,11 @@ int fused_plan_create(Decoder* d) {
     LDPC_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     p->num_cu = prop.multiProcessorCount;
     const int by_lds = (int)((size_t)160 * 1024 / p->lds_bytes);
-    int cap = 8;
-    if (const char* w = std::getenv("LDPC_FUSED_WAVES")) cap = atoi(w) > 0 ? atoi(w) : 8;  // experiment knob: resident waves per CU
-    p->waves_per_cu = by_lds < cap ? by_lds : cap;
-    LDPC_HIP_TRY(hipFuncSetAttribute(shape->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
-    p->ok = p->waves_per_cu >= 1;
+    int cap = 8;  // resident frames per CU (waves: NW x that)
+    if (const char* wenv = std::getenv("LDPC_FUSED_WAVES")) cap = atoi(wenv) > 0 ? atoi(wenv) : cap;  // experiment knob
+    p->groups_per_cu = by_lds < cap ? by_lds : cap;
+    LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    p->ok = p->groups_per_cu >= 1;
     return LDPC_OK;
 }
 
@@ -447,25 +525,40 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
         set_error("priors pointer is null");
         return LDPC_E_ARG;
     }
-    const ShapeEntry* shape = nullptr;
-    for (const ShapeEntry& s : kShapes)
-        if (s.alg == d->alg && s.DC == p->DC && s.DV == p->DV && s.CR == p->CR && s.VR == p->VR) shape = &s;
+    if (B >= ((int64_t)1 << 31)) {
+        set_error("fused backend: at most 2^31-1 frames per call");
+        return LDPC_E_ARG;
+    }
+    const ShapeEntry& shape = kShapes[p->shape];
     const Code* c = d->code;
     LDPC_HIP_TRY(hipMemsetAsync(p->d_next, 0, 8, st));
-    long long waves = (long long)p->num_cu * p->waves_per_cu;
-    if (waves > B) waves = B;
-    const float* pr = (const float*)priors;
-    long long Bll = B;
-    int n = c->n, mi = max_iter > 0 ? max_iter : 100000;
-    unsigned fl = flags;
-    void* args[] = {&pr, &y0, &Bll, &n, &mi, &fl, &p->d_cn_tab, &p->d_vn_tab, &p->d_var_of_slot, &p->d_cn_active, &xhat, &iters, &p->d_next};
+    long long groups = (long long)p->num_cu * p->groups_per_cu;
+    if (groups > B) groups = B;
+    FusedArgs a;
+    a.priors = (const float*)priors;
+    a.y0 = y0;
+    a.B = B;
+    a.n = c->n;
+    a.max_iter = max_iter > 0 ? max_iter : 100000;
+    a.flags = flags;
+    a.cn_tab = p->d_cn_tab;
+    a.vn_tab = p->d_vn_tab;
+    a.var_of_slot = p->d_var_of_slot;
+    a.cn_active = p->d_cn_active;
+    a.xhat = xhat;
+    a.iters = iters;
+    a.next_frame = p->d_next;
+    a.sync_off0 = p->sync_off[0];
+    a.sync_off1 = p->sync_off[1];
+    a.zero_row = p->zero_row;
+    void* args[] = {&a};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (d->profile) {
         LDPC_TRY(prof_event(d, 0, &e0));
         LDPC_TRY(prof_event(d, 1, &e1));
         LDPC_HIP_TRY(hipEventRecord(e0, st));
     }
-    LDPC_HIP_TRY(hipLaunchKernel(shape->kernel, dim3((unsigned)waves), dim3(64), args, p->lds_bytes, st));
+    LDPC_HIP_TRY(hipLaunchKernel(shape.kernel, dim3((unsigned)groups), dim3(64 * shape.NW), args, p->lds_bytes, st));
     if (d->profile) {
         LDPC_HIP_TRY(hipEventRecord(e1, st));
         LDPC_HIP_TRY(hipStreamSynchronize(st));

@@ -235,3 +235,34 @@ def test_ragged_and_edge_batches():
     assert (xhat == xo).all() and (iters == 1).all()
     with pytest.raises(ValueError):
         dec.decode_batch(None, pri[:, :-1])
+
+
+@pytest.mark.parametrize("nw", ["1", "2"])
+def test_fused_variants_ragged_and_iteration0(nw, monkeypatch):
+    # both fused kernels (1 and 2 wavefronts per frame) on tiny / ragged batches, with and without the iteration-0 word
+    from ldpc_decoders_amd import bpa, bsc
+
+    monkeypatch.setenv("LDPC_FUSED_NW", nw)
+    g, code = _code("1200_3_6_rand_ldpc_1")
+    rng = np.random.RandomState(21)
+    for B in (1, 5, 130):
+        y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(2.2)), (B, g.n))
+        pri = O.biawgn_priors(y, 2.2).astype(np.float32)
+        dec = bpa.MSA(code, max_iter=40, precision="f32", backend="fused")
+        assert dec.handle.fused_info()["waves_per_frame"] == float(nw)
+        xhat, iters = dec.decode_batch(None, pri)
+        xo, io = C.bp_decode(g, "MSA", None, pri, 40, dtype=np.float32)
+        assert (xhat == xo).all() and (iters == io).all()
+    yb = (rng.random_sample((150, g.n)) < 0.03).astype(np.int64)
+    yb[:5] = 0
+    yb[5] = 1
+    dec = bsc.MSA(0.03, code, max_iter=30, precision="f32", backend="fused")
+    xhat, iters = dec.decode_batch(yb)
+    pri = O.bsc_priors(yb, 0.03).astype(np.float32)
+    xo, io = C.bp_decode(g, "MSA", yb.astype(np.float32), pri, 30, dtype=np.float32)
+    assert (xhat == xo).all() and (iters == io).all() and (iters[:6] == 0).all()
+    # max_iter = 1 and the no-early-exit flag
+    import torch
+    h = bpa.MSA(code, max_iter=3, precision="f32", backend="fused").handle
+    x3, i3 = h.decode_device(torch.from_numpy(pri).cuda(), None, 3, flags=1)
+    assert (i3.cpu().numpy() == 3).all()
