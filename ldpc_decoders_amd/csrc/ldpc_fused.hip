@@ -78,6 +78,8 @@ __device__ __forceinline__ void lds_st_tid(float v) {
 }
 __device__ __forceinline__ void lds_set_m0(uint32_t base) { asm volatile("s_mov_b32 m0, %0" ::"s"(base) : "memory"); }
 
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
 __device__ __forceinline__ float lds_ld(const unsigned char* base, uint32_t byte_off) {
     return *reinterpret_cast<const float*>(base + byte_off);
 }
@@ -223,16 +225,34 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                     uint32_t vx = 0, mx = 0;
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
-                        const float m0 = mg[r & 1][j];
-                        mx ^= __float_as_uint(m0);
-                        v[j] = m0 - c2v_old[r][j];
+                        v[j] = mg[r & 1][j] - c2v_old[r][j];
                         a[j] = __builtin_fabsf(v[j]);
+                    }
+                    // XOR of the raw words, three inputs per instruction (v_bitop3_b32, truth table 0x96)
+#pragma unroll
+                    for (int j = 0; j + 2 < DC; j += 3) {
+                        mx ^= xor3(__float_as_uint(mg[r & 1][j]), __float_as_uint(mg[r & 1][j + 1]), __float_as_uint(mg[r & 1][j + 2]));
+                        vx ^= xor3(__float_as_uint(v[j]), __float_as_uint(v[j + 1]), __float_as_uint(v[j + 2]));
+                    }
+#pragma unroll
+                    for (int j = DC - DC % 3; j < DC; ++j) {
+                        mx ^= __float_as_uint(mg[r & 1][j]);
                         vx ^= __float_as_uint(v[j]);
                     }
                     if constexpr (DC % 2 == 0) synd |= mx; else synd |= ((cn_active[r] >> lane) & 1ull) ? mx : 0u;
                     // leave-one-out reduction of |v|: minimum (min-sum) or join of 1 - tanh(|v|/2) (sum-product, ldpc_cn.hpp)
                     float pre[DC], suf[DC];
-                    if constexpr (ALG == ALG_MSA) {
+                    if constexpr (ALG == ALG_MSA && DC == 6) {
+                        // 11 minimum instructions for the six leave-one-out minima (v_min3_f32 where three inputs meet)
+                        const float s3 = fminf(a[4], a[5]), s2 = fminf(fminf(a[3], a[4]), a[5]), s1 = fminf(a[2], s2);
+                        const float p2 = fminf(a[0], a[1]), p3 = fminf(fminf(a[0], a[1]), a[2]);
+                        pre[0] = fminf(fminf(a[1], a[2]), s2); suf[0] = pre[0];
+                        pre[1] = fminf(a[0], s1);              suf[1] = pre[1];
+                        pre[2] = fminf(p2, s2);                suf[2] = pre[2];
+                        pre[3] = fminf(p3, s3);                suf[3] = pre[3];
+                        pre[4] = fminf(fminf(p3, a[3]), a[5]); suf[4] = pre[4];
+                        pre[5] = fminf(fminf(p3, a[3]), a[4]); suf[5] = pre[5];
+                    } else if constexpr (ALG == ALG_MSA) {
                         pre[0] = __builtin_huge_valf();
 #pragma unroll
                         for (int j = 1; j < DC; ++j) pre[j] = fminf(pre[j - 1], a[j - 1]);
@@ -289,7 +309,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                             for (int j = 1; j < DV; ++j) s += cv[g & 1][u][j];
                             const float m1 = prior[q] + s;
                             lds_st_tid<q * 256>(m1);
-                            xb |= (m1 < 0.0f) ? (1u << q) : 0u;
+                            // decision bit: (m1 < 0); for min-sum the sign bit itself (m1 is never -0.0 and never NaN for finite priors)
+                            if constexpr (ALG == ALG_MSA) xb |= (__float_as_uint(m1) >> 31) << q; else xb |= (m1 < 0.0f) ? (1u << q) : 0u;
                         }
                     });
                 });
