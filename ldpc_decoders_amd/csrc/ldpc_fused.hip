@@ -119,6 +119,16 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
     for (int i = 0; i < CNW; ++i) cn_idx[i] = A.cn_tab[(w * CNW + i) * 64 + lane];
 #pragma unroll
     for (int i = 0; i < VNW; ++i) vn_idx[i] = A.vn_tab[(w * VNW + i) * 64 + lane];
+    // variable index of each owned slot (-1: padding): resident in registers where the budget allows, else re-read per frame
+    constexpr bool VMAP_RESIDENT = (NW == 1) || (ALG == ALG_MSA);
+    int vmap_reg[VMAP_RESIDENT ? VRW : 1];
+    if constexpr (VMAP_RESIDENT) {
+#pragma unroll
+        for (int q = 0; q < VRW; ++q) vmap_reg[q] = vslot[q * 64 + lane];
+    }
+    auto vmap_of = [&](int q) -> int {
+        if constexpr (VMAP_RESIDENT) return vmap_reg[q]; else return vslot[q * 64 + lane];
+    };
     if (A.zero_row && w == 0) reinterpret_cast<float*>(smem)[NPAD + CR * DC * 64 + lane] = 0.0f;  // the always-zero row
 
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
@@ -142,18 +152,43 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
         }
     };
 
+    // Frame hand-out.  One device-wide counter sustains only ~88 dequeues/us (MI355X_MICROARCH.md, row "dequeue"): 65 536
+    // single-frame dequeues alone would take 0.75 ms.  The frame range is therefore cut into NSHARD contiguous shards with
+    // one counter each (64 B apart); a workgroup drains its home shard (blockIdx % NSHARD -- the XCD it runs on, as
+    // observed) one frame at a time and then helps with the next shards.  Frame granularity keeps the load balanced when
+    // frames need different numbers of sweeps.
+    constexpr int NSHARD = 8;
+    const long long shard_len = (A.B + NSHARD - 1) / NSHARD;
+    int shard = (int)(blockIdx.x % NSHARD), shards_left = NSHARD;
+    auto next_frame = [&]() -> long long {  // wave-uniform; -1 when every shard is drained
+        long long got = -1;
+        while (shards_left > 0) {
+            const long long base = shard * shard_len;
+            const long long len = (base + shard_len <= A.B ? shard_len : A.B - base);
+            u64 t = 0;
+            if (lane == 0) t = atomicAdd(A.next_frame + shard * 8, 1ull);
+            const long long k = (long long)(((u64)__builtin_amdgcn_readfirstlane((unsigned)(t >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)t));
+            if (k < len) { got = base + k; break; }
+            shard = (shard + 1) % NSHARD;
+            --shards_left;
+        }
+        return got;
+    };
     for (;;) {
-        u64 fr = 0;
+        long long fr_s = 0;
         if constexpr (NW == 1) {
-            if (lane == 0) fr = atomicAdd(A.next_frame, 1ull);
-            fr = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(fr >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)fr);
+            fr_s = next_frame();
         } else {
             __syncthreads();  // the verdict slots of the previous frame have been read by everybody
-            if (w == 0 && lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + A.sync_off0) = (uint32_t)atomicAdd(A.next_frame, 1ull);
+            if (w == 0) {
+                const long long f0 = next_frame();
+                if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + A.sync_off0) = (int32_t)f0;
+            }
             __syncthreads();
-            fr = (u64) __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(smem + A.sync_off0));
+            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(smem + A.sync_off0));
         }
-        if ((long long)fr >= A.B) break;
+        if (fr_s < 0) break;
+        const u64 fr = (u64)fr_s;
         const float* pf = A.priors + fr * n;
 
         float prior[VRW];
@@ -161,7 +196,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
         unsigned xb = 0;  // bit q = hard decision of variable slot (w*VRW + q, lane)
 #pragma unroll
         for (int q = 0; q < VRW; ++q) {
-            const int v = vslot[q * 64 + lane];
+            const int v = vmap_of(q);
             prior[q] = v >= 0 ? pf[v] : 0.0f;
         }
 #pragma unroll
@@ -176,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
             const uint8_t* yf = A.y0 + fr * n;
 #pragma unroll
             for (int q = 0; q < VRW; ++q) {
-                const int v = vslot[q * 64 + lane];
+                const int v = vmap_of(q);
                 const bool one = v >= 0 && yf[v] != 0;
                 lds_marg[q * 64 + lane] = one ? -1.0f : 1.0f;
                 xb |= one ? (1u << q) : 0u;
@@ -322,7 +357,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
         uint8_t* xf = A.xhat + fr * n;
 #pragma unroll
         for (int q = 0; q < VRW; ++q) {
-            const int v = vslot[q * 64 + lane];
+            const int v = vmap_of(q);
             if (v >= 0) xf[v] = (uint8_t)((xb >> q) & 1u);
         }
     }
@@ -512,7 +547,7 @@ int fused_plan_create(Decoder* d) {
     LDPC_TRY(upload_vec(vn_tab, &p->d_vn_tab));
     LDPC_TRY(upload_vec(var_of_slot, &p->d_var_of_slot));
     LDPC_TRY(upload_vec(cn_active, &p->d_cn_active));
-    LDPC_HIP_TRY(hipMalloc((void**)&p->d_next, 64));
+    LDPC_HIP_TRY(hipMalloc((void**)&p->d_next, 8 * 64));  // 8 frame counters, one cache line apart
     hipDeviceProp_t prop;
     LDPC_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     p->num_cu = prop.multiProcessorCount;
@@ -552,7 +587,7 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
     }
     const ShapeEntry& shape = kShapes[p->shape];
     const Code* c = d->code;
-    LDPC_HIP_TRY(hipMemsetAsync(p->d_next, 0, 8, st));
+    LDPC_HIP_TRY(hipMemsetAsync(p->d_next, 0, 8 * 64, st));
     long long groups = (long long)p->num_cu * p->groups_per_cu;
     if (groups > B) groups = B;
     FusedArgs a;
