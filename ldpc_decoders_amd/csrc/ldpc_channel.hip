@@ -13,32 +13,6 @@
 namespace ldpc {
 namespace {
 
-template <typename T>
-__device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, T& z0, T& z1);
-
-template <>
-__device__ __forceinline__ void box_muller<float>(uint32_t wa, uint32_t wb, float& z0, float& z1) {
-    // u = (w + 0.5) / 2^32 in (0,1); radius from the full 32 bits (tail to 6.7 sigma), angle from 32 bits
-    const float u1 = fmaf((float)wa, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-    const float u2 = fmaf((float)wb, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-    const float r = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincospif(2.0f * u2, &s, &c);
-    z0 = r * c;
-    z1 = r * s;
-}
-
-template <>
-__device__ __forceinline__ void box_muller<double>(uint32_t wa, uint32_t wb, double& z0, double& z1) {
-    const double u1 = ((double)wa + 0.5) * 2.3283064365386963e-10;
-    const double u2 = ((double)wb + 0.5) * 2.3283064365386963e-10;
-    const double r = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincospi(2.0 * u2, &s, &c);
-    z0 = r * c;
-    z1 = r * s;
-}
-
 // one thread = 4 consecutive variables of one frame (one Philox block)
 template <typename T>
 __global__ __launch_bounds__(256) void k_biawgn(double sigma, double inv_var2, int codeword, uint64_t seed, uint32_t stream,

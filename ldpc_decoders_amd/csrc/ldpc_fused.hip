@@ -29,6 +29,7 @@
 #include "ldpc_cn.hpp"
 #include "ldpc_common.hpp"
 #include "ldpc_layout.hpp"
+#include "ldpc_rng.hpp"
 
 namespace ldpc {
 
@@ -39,6 +40,7 @@ struct FusedPlan {
     uint32_t* d_cn_tab = nullptr;      // [NW][(CRW*DC+1)/2][64] two 16-bit marg byte offsets per word
     uint32_t* d_vn_tab = nullptr;      // [NW][(VRW*DV+1)/2][64] two 16-bit c2v byte offsets per word
     int32_t* d_var_of_slot = nullptr;  // [VR*64] variable index of a slot, -1 for padding
+    int32_t* d_slot_of_var = nullptr;  // [n rounded up to 4] slot (LDS dword index) of a variable
     unsigned long long* d_cn_active = nullptr;  // [CR] lanes holding a real check in round R
     unsigned long long* d_next = nullptr;       // frame dispenser
     int sync_off[2] = {0, 0};          // NW = 2: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
@@ -98,9 +100,16 @@ struct FusedArgs {
     int32_t* iters;
     u64* next_frame;
     int sync_off0, sync_off1, zero_row;
+    // fused simulate (SIM kernels): BI-AWGN noise generated in the kernel, errors counted in the kernel
+    const int32_t* slot_of_var;     // [n rounded up to 4] LDS dword index (marg area) of each variable
+    float sim_mean, sim_sigma, sim_k;  // y = mean + sigma z ; prior = -(k y), k = 2/sigma^2   (src/biawgn.py:17-28)
+    unsigned long long seed, frame0;
+    unsigned stream;
+    int codeword, hist_bins;
+    unsigned long long* counters;   // [4 + hist_bins] tot, wec, bec, iter_sum, histogram of sweeps
 };
 
-template <int ALG, int DC, int DV, int CRW, int VRW, int NW>
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const FusedArgs A) {
     constexpr int CR = CRW * NW, VR = VRW * NW;
     constexpr int NPAD = VR * 64;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
 #pragma unroll
     for (int i = 0; i < VNW; ++i) vn_idx[i] = A.vn_tab[(w * VNW + i) * 64 + lane];
     // variable index of each owned slot (-1: padding): resident in registers where the budget allows, else re-read per frame
-    constexpr bool VMAP_RESIDENT = (NW == 1) || (ALG == ALG_MSA);
+    constexpr bool VMAP_RESIDENT = !SIM && ((NW == 1) || (ALG == ALG_MSA));
     int vmap_reg[VMAP_RESIDENT ? VRW : 1];
     if constexpr (VMAP_RESIDENT) {
 #pragma unroll
@@ -136,6 +145,14 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
     const uint32_t m0_marg = lds_base + (uint32_t)(w * VRW * 64) * 4;            // this wave's marginal rows
     const uint32_t my_sync = (uint32_t)(w == 0 ? A.sync_off0 : A.sync_off1);
     const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
+    // SIM: per-workgroup counters live in wave 0 (scalars + one histogram bin per lane), flushed once at the end
+    unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
+    u64 acc_tot = 0, acc_wec = 0, acc_bec = 0, acc_it = 0;
+    unsigned hist_lane = 0;
+    if constexpr (SIM) {
+#pragma unroll
+        for (int q = 0; q < VRW; ++q) valid |= (vslot[q * 64 + lane] >= 0) ? (1u << q) : 0u;
+    }
 
     // verdict exchange between the NW waves of a frame: each wave publishes "my checks see an unsatisfied syndrome" in a
     // padded c2v slot it owns (nobody else ever writes it; its own garbage write precedes in program order) -> barrier ->
@@ -189,15 +206,35 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
         }
         if (fr_s < 0) break;
         const u64 fr = (u64)fr_s;
-        const float* pf = A.priors + fr * n;
-
         float prior[VRW];
         float c2v_old[CRW][DC];
         unsigned xb = 0;  // bit q = hard decision of variable slot (w*VRW + q, lane)
+        if constexpr (SIM) {
+            // channel + LLR in the kernel: the workgroup draws the frame's noise block by block (one Philox block = 4
+            // consecutive variables, exactly as k_biawgn does) and drops every prior into the LDS slot of its variable
+            for (int blk = threadIdx.x; blk * 4 < n; blk += 64 * NW) {
+                const Philox4 ph = philox_word_block(A.seed, A.stream, A.frame0 + fr, (uint32_t)blk);
+                float z[4];
+                box_muller<float>(ph.w[0], ph.w[1], z[0], z[1]);
+                box_muller<float>(ph.w[2], ph.w[3], z[2], z[3]);
+                const int4 sl = *reinterpret_cast<const int4*>(A.slot_of_var + blk * 4);
+                const int slots[4] = {sl.x, sl.y, sl.z, sl.w};
 #pragma unroll
-        for (int q = 0; q < VRW; ++q) {
-            const int v = vmap_of(q);
-            prior[q] = v >= 0 ? pf[v] : 0.0f;
+                for (int t = 0; t < 4; ++t) {
+                    const float y = A.sim_mean + A.sim_sigma * z[t];
+                    if (blk * 4 + t < n) reinterpret_cast<float*>(smem)[slots[t]] = -(A.sim_k * y);
+                }
+            }
+            if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) prior[q] = lds_marg[q * 64 + lane];  // padded slots: stale words, never used
+        } else {
+            const float* pf = A.priors + fr * n;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                const int v = vmap_of(q);
+                prior[q] = v >= 0 ? pf[v] : 0.0f;
+            }
         }
 #pragma unroll
         for (int r = 0; r < CRW; ++r)
@@ -206,7 +243,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
 
         int it = 0;
         bool left_at_0 = false;
-        if (A.y0 != nullptr) {
+        if (!SIM && A.y0 != nullptr) {
             // iteration-0 test of the received hard word (src/bpa.py:20,29): park it in the marg area as -+1
             const uint8_t* yf = A.y0 + fr * n;
 #pragma unroll
@@ -353,12 +390,43 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                 ++it;
             }
         }
-        if (w == 0 && lane == 0) A.iters[fr] = it;
-        uint8_t* xf = A.xhat + fr * n;
+        if constexpr (SIM) {
+            // errors against the all-`codeword` word (src/main.py:41-45), counted from the decision bits
+            const unsigned wrong = (A.codeword ? ~xb : xb) & valid;
+            int err = 0;
 #pragma unroll
-        for (int q = 0; q < VRW; ++q) {
-            const int v = vmap_of(q);
-            if (v >= 0) xf[v] = (uint8_t)((xb >> q) & 1u);
+            for (int q = 0; q < VRW; ++q) err += __popcll(__ballot((wrong >> q) & 1u));
+            if constexpr (NW > 1) {
+                if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + my_sync) = err;
+                __syncthreads();
+                err = *reinterpret_cast<volatile int32_t*>(smem + A.sync_off0) + *reinterpret_cast<volatile int32_t*>(smem + A.sync_off1);
+            }
+            err = __builtin_amdgcn_readfirstlane(err);  // wave-uniform: keep the accumulators in scalar registers
+            acc_tot += 1;
+            acc_wec += err > 0;
+            acc_bec += (u64)err;
+            acc_it += (u64)it;
+            const int bin = it < A.hist_bins ? it : A.hist_bins - 1;
+            hist_lane += (lane == bin) ? 1u : 0u;
+        } else {
+            if (w == 0 && lane == 0) A.iters[fr] = it;
+            uint8_t* xf = A.xhat + fr * n;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                const int v = vmap_of(q);
+                if (v >= 0) xf[v] = (uint8_t)((xb >> q) & 1u);
+            }
+        }
+    }
+    if constexpr (SIM) {
+        if (w == 0) {
+            if (lane == 0) {
+                atomicAdd(&A.counters[0], acc_tot);
+                atomicAdd(&A.counters[1], acc_wec);
+                atomicAdd(&A.counters[2], acc_bec);
+                atomicAdd(&A.counters[3], acc_it);
+            }
+            if (lane < A.hist_bins && hist_lane) atomicAdd(&A.counters[4 + lane], (u64)hist_lane);
         }
     }
 }
@@ -372,12 +440,14 @@ int upload_vec(const std::vector<T>& h, T** d) {
 
 struct ShapeEntry {
     int alg, DC, DV, CRW, VRW, NW;
-    const void* kernel;
+    const void* kernel;      // decode: priors in, decisions out
+    const void* kernel_sim;  // simulate: noise in the kernel, counters out
 };
 
 template <int ALG, int DC, int DV, int CRW, int VRW, int NW>
 constexpr ShapeEntry shape_entry() {
-    return ShapeEntry{ALG, DC, DV, CRW, VRW, NW, (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW>};
+    return ShapeEntry{ALG, DC, DV, CRW, VRW, NW, (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW, false>,
+                      (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW, true>};
 }
 
 // instantiated shapes, (3,6)-regular codes, min-sum and sum-product (fp32).  Preference order = table order:
@@ -546,6 +616,11 @@ int fused_plan_create(Decoder* d) {
     LDPC_TRY(upload_vec(cn_tab, &p->d_cn_tab));
     LDPC_TRY(upload_vec(vn_tab, &p->d_vn_tab));
     LDPC_TRY(upload_vec(var_of_slot, &p->d_var_of_slot));
+    {
+        std::vector<int32_t> sov(var_slot.begin(), var_slot.end());
+        while (sov.size() % 4) sov.push_back(0);
+        LDPC_TRY(upload_vec(sov, &p->d_slot_of_var));
+    }
     LDPC_TRY(upload_vec(cn_active, &p->d_cn_active));
     LDPC_HIP_TRY(hipMalloc((void**)&p->d_next, 8 * 64));  // 8 frame counters, one cache line apart
     hipDeviceProp_t prop;
@@ -556,6 +631,7 @@ int fused_plan_create(Decoder* d) {
     if (const char* wenv = std::getenv("LDPC_FUSED_WAVES")) cap = atoi(wenv) > 0 ? atoi(wenv) : cap;  // experiment knob
     p->groups_per_cu = by_lds < cap ? by_lds : cap;
     LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel_sim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
     p->ok = p->groups_per_cu >= 1;
     return LDPC_OK;
 }
@@ -563,10 +639,52 @@ int fused_plan_create(Decoder* d) {
 void fused_plan_destroy(Decoder* d) {
     FusedPlan* p = d->fused;
     if (!p) return;
-    for (void* q : {(void*)p->d_cn_tab, (void*)p->d_vn_tab, (void*)p->d_var_of_slot, (void*)p->d_cn_active, (void*)p->d_next})
+    for (void* q : {(void*)p->d_cn_tab, (void*)p->d_vn_tab, (void*)p->d_var_of_slot, (void*)p->d_slot_of_var, (void*)p->d_cn_active, (void*)p->d_next})
         if (q) (void)hipFree(q);
     delete p;
     d->fused = nullptr;
+}
+
+static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t max_iter, uint32_t flags, hipStream_t st) {
+    FusedPlan* p = d->fused;
+    if (B >= ((int64_t)1 << 31)) {
+        set_error("fused backend: at most 2^31-1 frames per call");
+        return LDPC_E_ARG;
+    }
+    const ShapeEntry& shape = kShapes[p->shape];
+    const Code* c = d->code;
+    LDPC_HIP_TRY(hipMemsetAsync(p->d_next, 0, 8 * 64, st));
+    long long groups = (long long)p->num_cu * p->groups_per_cu;
+    if (groups > B) groups = B;
+    a.B = B;
+    a.n = c->n;
+    a.max_iter = max_iter > 0 ? max_iter : 100000;
+    a.flags = flags;
+    a.cn_tab = p->d_cn_tab;
+    a.vn_tab = p->d_vn_tab;
+    a.var_of_slot = p->d_var_of_slot;
+    a.slot_of_var = p->d_slot_of_var;
+    a.cn_active = p->d_cn_active;
+    a.next_frame = p->d_next;
+    a.sync_off0 = p->sync_off[0];
+    a.sync_off1 = p->sync_off[1];
+    a.zero_row = p->zero_row;
+    void* args[] = {&a};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (d->profile) {
+        LDPC_TRY(prof_event(d, 0, &e0));
+        LDPC_TRY(prof_event(d, 1, &e1));
+        LDPC_HIP_TRY(hipEventRecord(e0, st));
+    }
+    LDPC_HIP_TRY(hipLaunchKernel(sim ? shape.kernel_sim : shape.kernel, dim3((unsigned)groups), dim3(64 * shape.NW), args, p->lds_bytes, st));
+    if (d->profile) {
+        LDPC_HIP_TRY(hipEventRecord(e1, st));
+        LDPC_HIP_TRY(hipStreamSynchronize(st));
+        LDPC_TRY(prof_collect(d, {{2, e0, e1}}));
+    }
+    d->last_sweeps = max_iter;
+    d->last_backend = BK_FUSED;
+    return LDPC_OK;
 }
 
 int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
@@ -581,48 +699,35 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
         set_error("priors pointer is null");
         return LDPC_E_ARG;
     }
-    if (B >= ((int64_t)1 << 31)) {
-        set_error("fused backend: at most 2^31-1 frames per call");
-        return LDPC_E_ARG;
-    }
-    const ShapeEntry& shape = kShapes[p->shape];
-    const Code* c = d->code;
-    LDPC_HIP_TRY(hipMemsetAsync(p->d_next, 0, 8 * 64, st));
-    long long groups = (long long)p->num_cu * p->groups_per_cu;
-    if (groups > B) groups = B;
-    FusedArgs a;
+    FusedArgs a{};
     a.priors = (const float*)priors;
     a.y0 = y0;
-    a.B = B;
-    a.n = c->n;
-    a.max_iter = max_iter > 0 ? max_iter : 100000;
-    a.flags = flags;
-    a.cn_tab = p->d_cn_tab;
-    a.vn_tab = p->d_vn_tab;
-    a.var_of_slot = p->d_var_of_slot;
-    a.cn_active = p->d_cn_active;
     a.xhat = xhat;
     a.iters = iters;
-    a.next_frame = p->d_next;
-    a.sync_off0 = p->sync_off[0];
-    a.sync_off1 = p->sync_off[1];
-    a.zero_row = p->zero_row;
-    void* args[] = {&a};
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (d->profile) {
-        LDPC_TRY(prof_event(d, 0, &e0));
-        LDPC_TRY(prof_event(d, 1, &e1));
-        LDPC_HIP_TRY(hipEventRecord(e0, st));
-    }
-    LDPC_HIP_TRY(hipLaunchKernel(shape.kernel, dim3((unsigned)groups), dim3(64 * shape.NW), args, p->lds_bytes, st));
-    if (d->profile) {
-        LDPC_HIP_TRY(hipEventRecord(e1, st));
-        LDPC_HIP_TRY(hipStreamSynchronize(st));
-        LDPC_TRY(prof_collect(d, {{2, e0, e1}}));
-    }
-    d->last_sweeps = max_iter;
-    d->last_backend = BK_FUSED;
-    return LDPC_OK;
+    return fused_launch(d, a, false, B, max_iter, flags, st);
+}
+
+// channel -> LLR -> decode -> count in ONE kernel (BI-AWGN, all-`codeword` word): priors never touch HBM.
+bool fused_simulate_supported(const Decoder* d, int channel, int hist_bins) {
+    return fused_supported(d) && channel == CH_BIAWGN && hist_bins >= 1 && hist_bins <= 64;
+}
+
+int fused_simulate(Decoder* d, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
+                   int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st) {
+    if (B <= 0) return LDPC_OK;
+    const double var = pow(10.0, -param / 10.0);  // src/biawgn.py:10 -- same host arithmetic as channel_generate()
+    const double sigma = sqrt(var), k = 2.0 / var;
+    FusedArgs a{};
+    a.sim_mean = (float)(2 * codeword - 1);
+    a.sim_sigma = (float)sigma;
+    a.sim_k = (float)k;
+    a.seed = seed;
+    a.frame0 = frame0;
+    a.stream = (unsigned)stream_id;
+    a.codeword = codeword;
+    a.hist_bins = hist_bins;
+    a.counters = (unsigned long long*)counters;
+    return fused_launch(d, a, true, B, max_iter, flags, st);
 }
 
 }  // namespace ldpc

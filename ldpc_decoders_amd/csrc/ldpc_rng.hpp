@@ -36,4 +36,32 @@ __host__ __device__ __forceinline__ Philox4 philox_word_block(uint64_t seed, uin
     return philox4x32_10(j, stream, (uint32_t)frame, (uint32_t)(frame >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
+// Box-Muller on a pair of Philox words: (w_a, w_b) -> two independent N(0,1).  Shared by the stand-alone channel kernel and
+// the fused simulate kernel so that both produce bit-identical noise.
+template <typename T>
+__device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, T& z0, T& z1);
+
+template <>
+__device__ __forceinline__ void box_muller<float>(uint32_t wa, uint32_t wb, float& z0, float& z1) {
+    // u = (w + 0.5) / 2^32 in (0,1); radius from the full 32 bits (tail to 6.7 sigma), angle from 32 bits
+    const float u1 = fmaf((float)wa, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    const float u2 = fmaf((float)wb, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    const float r = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincospif(2.0f * u2, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+template <>
+__device__ __forceinline__ void box_muller<double>(uint32_t wa, uint32_t wb, double& z0, double& z1) {
+    const double u1 = ((double)wa + 0.5) * 2.3283064365386963e-10;
+    const double u2 = ((double)wb + 0.5) * 2.3283064365386963e-10;
+    const double r = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
 }  // namespace ldpc
