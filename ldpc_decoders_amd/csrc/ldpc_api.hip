@@ -379,8 +379,8 @@ int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uin
         set_error("device channel kernels send the all-zero (0) or all-one (1) word; got codeword=%d", codeword);
         return LDPC_E_ARG;
     }
-    if (d->backend != BK_STREAM && fused_simulate_supported(d, channel, hist_bins))
-        return fused_simulate(d, param, codeword, seed, stream_id, frame0, B, max_iter, flags, hist_bins, counters, st);
+    if (d->backend != BK_STREAM && fused_simulate_supported(d, channel, param, hist_bins))
+        return fused_simulate(d, channel, param, codeword, seed, stream_id, frame0, B, max_iter, flags, hist_bins, counters, st);
     // bounded staging: priors for at most 2^17 frames at a time
     const int64_t step = (int64_t)1 << 17;
     const int64_t cap = B < step ? B : step;

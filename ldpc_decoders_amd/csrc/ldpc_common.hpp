@@ -111,8 +111,8 @@ int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, 
 int fused_plan_create(Decoder* d);
 void fused_plan_destroy(Decoder* d);
 bool fused_supported(const Decoder* d);
-bool fused_simulate_supported(const Decoder* d, int channel, int hist_bins);
-int fused_simulate(Decoder* d, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
+bool fused_simulate_supported(const Decoder* d, int channel, double param, int hist_bins);
+int fused_simulate(Decoder* d, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
                    int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st);
 int fused_info(const Decoder* d, double* out8);
 int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,

@@ -106,6 +106,9 @@ struct FusedArgs {
     unsigned long long seed, frame0;
     unsigned stream;
     int codeword, hist_bins;
+    int sim_channel;                 // CH_BIAWGN or CH_BSC
+    unsigned long long bsc_thr;     // BSC: flip <=> Philox word < thr   (src/bsc.py:16)
+    float bsc_llr;                  // BSC: prior = llr * (1 - 2y)        (src/bsc.py:21,25), llr > 0 here
     unsigned long long* counters;   // [4 + hist_bins] tot, wec, bec, iter_sum, histogram of sweeps
 };
 
@@ -214,20 +217,32 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
             // consecutive variables, exactly as k_biawgn does) and drops every prior into the LDS slot of its variable
             for (int blk = threadIdx.x; blk * 4 < n; blk += 64 * NW) {
                 const Philox4 ph = philox_word_block(A.seed, A.stream, A.frame0 + fr, (uint32_t)blk);
-                float z[4];
-                box_muller<float>(ph.w[0], ph.w[1], z[0], z[1]);
-                box_muller<float>(ph.w[2], ph.w[3], z[2], z[3]);
                 const int4 sl = *reinterpret_cast<const int4*>(A.slot_of_var + blk * 4);
                 const int slots[4] = {sl.x, sl.y, sl.z, sl.w};
+                float pri4[4];
+                if (A.sim_channel == CH_BIAWGN) {
+                    float z[4];
+                    box_muller<float>(ph.w[0], ph.w[1], z[0], z[1]);
+                    box_muller<float>(ph.w[2], ph.w[3], z[2], z[3]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float y = A.sim_mean + A.sim_sigma * z[t];
-                    if (blk * 4 + t < n) reinterpret_cast<float*>(smem)[slots[t]] = -(A.sim_k * y);
+                    for (int t = 0; t < 4; ++t) pri4[t] = -(A.sim_k * (A.sim_mean + A.sim_sigma * z[t]));
+                } else {  // BSC: same integer threshold and the same LLR expression as k_discrete
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int y = A.codeword ^ ((u64)ph.w[t] < A.bsc_thr ? 1 : 0);
+                        pri4[t] = A.bsc_llr * (float)(1 - 2 * y);
+                    }
                 }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (blk * 4 + t < n) reinterpret_cast<float*>(smem)[slots[t]] = pri4[t];
             }
             if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int q = 0; q < VRW; ++q) prior[q] = lds_marg[q * 64 + lane];  // padded slots: stale words, never used
+            for (int q = 0; q < VRW; ++q) {
+                prior[q] = lds_marg[q * 64 + lane];  // padded slots: stale words, never used
+                if (A.sim_channel == CH_BSC) xb |= (__float_as_uint(prior[q]) >> 31) << q;  // x_hat starts as the received word
+            }
         } else {
             const float* pf = A.priors + fr * n;
 #pragma unroll
@@ -350,7 +365,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                     });
                 });
                 const bool unsat = any_unsat(__ballot((synd & 0x80000000u) != 0u) != 0);  // NW > 1: contains the barrier
-                if (early && it > 0 && !unsat) break;
+                // it == 0: only the BSC checks the received word itself (src/bpa.py:20,29); in SIM mode marg holds +-llr there
+                if (early && (it > 0 || (SIM && A.sim_channel == CH_BSC)) && !unsat) break;
                 if constexpr (NW == 1) __builtin_amdgcn_wave_barrier();
                 // ---------------- variable phase
                 lds_set_m0(m0_marg);
@@ -708,11 +724,12 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
 }
 
 // channel -> LLR -> decode -> count in ONE kernel (BI-AWGN, all-`codeword` word): priors never touch HBM.
-bool fused_simulate_supported(const Decoder* d, int channel, int hist_bins) {
-    return fused_supported(d) && channel == CH_BIAWGN && hist_bins >= 1 && hist_bins <= 64;
+bool fused_simulate_supported(const Decoder* d, int channel, double param, int hist_bins) {
+    if (!fused_supported(d) || hist_bins < 1 || hist_bins > 64) return false;
+    return channel == CH_BIAWGN || (channel == CH_BSC && param > 0.0 && param < 0.5);  // BSC: needs llr > 0
 }
 
-int fused_simulate(Decoder* d, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
+int fused_simulate(Decoder* d, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
                    int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st) {
     if (B <= 0) return LDPC_OK;
     const double var = pow(10.0, -param / 10.0);  // src/biawgn.py:10 -- same host arithmetic as channel_generate()
@@ -726,6 +743,12 @@ int fused_simulate(Decoder* d, double param, int codeword, uint64_t seed, uint64
     a.stream = (unsigned)stream_id;
     a.codeword = codeword;
     a.hist_bins = hist_bins;
+    a.sim_channel = channel;
+    if (channel == CH_BSC) {
+        double t = ceil(param * 4294967296.0 - 0.5);  // same threshold as channel_generate()
+        a.bsc_thr = (unsigned long long)(t < 0 ? 0 : t);
+        a.bsc_llr = (float)(log(1.0 - param) - log(param));
+    }
     a.counters = (unsigned long long*)counters;
     return fused_launch(d, a, true, B, max_iter, flags, st);
 }
