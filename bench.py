@@ -172,7 +172,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fp:
                 tj = json.load(fp)
-            key = {"stream_check_pass": "stream:k_cn", "stream_variable_pass": "stream:k_vn", "fused_decode": "fused:k_fused_msa"}[kind]
+            key = {"stream_check_pass": "stream:k_cn", "stream_variable_pass": "stream:k_vn", "fused_decode": "sim:k_fused_bp"}[kind]
             for k, v in tj.items():
                 if k.startswith(key) and args.batch == 65536 and args.code == "1200_3_6_rand_ldpc_1" and abs(args.snr - 1.0) < 1e-9:
                     traffic = int(v)

@@ -17,6 +17,10 @@ for BK in fused stream; do
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_fused_SQ -o p -- python3 $R/tools/prof_fused.py --reps 1 > $OUT/pmc_fused_SQ.log 2>&1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/pmc_fused_SQ2 -o p -- python3 $R/tools/prof_fused.py --reps 1 > $OUT/pmc_fused_SQ2.log 2>&1
+# the bench step runs the fused SIMULATE kernel (noise + decode + count): its own PMC passes
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_sim_$C -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --points --no-profile > $OUT/pmc_sim_$C.log 2>&1
+done
 python3 $R/bench.py --steps 6 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
 python3 $R/bench.py --steps 4 --warmup 1 --backend stream --no-cpu-baseline > $OUT/bench_stream.json 2> $OUT/bench_stream.err
 find $OUT -name "*.db" -delete

@@ -55,6 +55,16 @@ for bk in ("fused", "stream"):
             traffic["%s:%s" % (bk, k)] = tot
             out.append("| %s | %d | %.0f | %.0f | %.4g |" % (k, len(f_), fa, wa, tot))
 
+# fused simulate kernel (what bench.py times): FETCH/WRITE per launch, corrected with the calibration factors above
+fs, ws = pmc("pmc_sim_FETCH_SIZE"), pmc("pmc_sim_WRITE_SIZE")
+for k in fs:
+    if k.startswith("k_fused"):
+        f_ = fs[k]["FETCH_SIZE"]; w_ = ws.get(k, {}).get("WRITE_SIZE", [0])
+        fa, wa = sum(f_) / len(f_), sum(w_) / max(len(w_), 1)
+        tot = fa * 1024 * 2.0 + wa * 1024 * 1.0
+        traffic["sim:%s" % k] = tot
+        out.append("\n## HBM traffic of the fused SIMULATE kernel (bench step)\n\n%s: %d launches, FETCH_SIZE %.0f KiB/launch (x2 correction), WRITE_SIZE %.0f KiB/launch -> %.4g bytes/launch" % (k, len(f_), fa, wa, tot))
+
 for d in ("pmc_fused_SQ", "pmc_fused_SQ2"):
     acc = pmc(d)
     for k, v in acc.items():
