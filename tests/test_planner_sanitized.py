@@ -1,0 +1,62 @@
+"""The LDS layout planner is host C++ (no GPU needed): build it with AddressSanitizer + UBSan and run it on the golden
+(3,6) n=1200 code -- checks memory safety of the annealer / edge colouring and that the plan beats the trivial placement."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ldpc_decoders_amd", "csrc")
+
+HARNESS = r'''
+#include "ldpc_layout.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+using namespace ldpc;
+namespace ldpc { void set_error(const char*, ...) {} const char* last_error() { return ""; } }
+int main(int argc, char** argv) {
+    std::ifstream f(argv[1]); std::string line; Code c; std::vector<std::vector<int>> rows; int n = 0;
+    while (std::getline(f, line)) { std::istringstream is(line); std::vector<int> r; int v; while (is >> v) { r.push_back(v - 1); n = std::max(n, v); } if (!r.empty()) rows.push_back(r); }
+    c.m = (int)rows.size(); c.n = n; c.row_ptr.assign(c.m + 1, 0); c.col_ptr.assign(c.n + 1, 0);
+    for (int i = 0; i < c.m; ++i) { std::sort(rows[i].begin(), rows[i].end()); for (int v : rows[i]) { c.edge_chk.push_back(i); c.edge_var.push_back(v); c.col_ptr[v + 1]++; } c.row_ptr[i + 1] = (int)c.edge_var.size(); }
+    c.E = (int64_t)c.edge_var.size(); for (int v = 0; v < c.n; ++v) c.col_ptr[v + 1] += c.col_ptr[v];
+    c.col_edge.assign(c.E, 0); std::vector<int> fill(c.col_ptr.begin(), c.col_ptr.end() - 1);
+    for (int k = 0; k < c.E; ++k) c.col_edge[fill[c.edge_var[k]]++] = k;
+    const int CR = atoi(argv[2]), VR = atoi(argv[3]);
+    FusedLayout L; plan_fused_layout(c, 6, 3, CR, VR, 0x1200, 0.3, &L);
+    // the plan must be a permutation of slots and of the positions inside every check
+    std::vector<int> seen(CR * 64, 0); for (int s : L.chk_slot) { if (s < 0 || s >= CR * 64 || seen[s]++) return 2; }
+    std::vector<int> seenv(VR * 64, 0); for (int s : L.var_slot) { if (s < 0 || s >= VR * 64 || seenv[s]++) return 3; }
+    for (int cc = 0; cc < c.m; ++cc) { int mask = 0; for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) mask |= 1 << L.edge_pos[k]; if (mask != 63) return 4; }
+    printf("%.0f %.0f %.0f\n", L.base_cycles, L.extra_cycles_identity, L.extra_cycles_planned);
+    return 0;
+}
+'''
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("cr,vr", [(10, 19), (10, 20)])
+def test_layout_planner_under_asan(tmp_path, cr, vr):
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no host C++ compiler")
+    src = tmp_path / "harness.cpp"
+    src.write_text(HARNESS)
+    exe = str(tmp_path / "harness")
+    # host-only build of the planner: the HIP header is only needed for types in ldpc_common.hpp -> use hipcc's host pass
+    hipcc = "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", CSRC, "-x", "hip",
+           "--offload-arch=gfx950", str(src), os.path.join(CSRC, "ldpc_layout.hip"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("sanitized host build unavailable here: " + r.stderr[-300:])
+    code_file = os.path.join(ROOT, "tests", "golden", "codes", "1200_3_6_rand_ldpc_1.txt")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([exe, code_file, str(cr), str(vr)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    base, ident, planned = (float(v) for v in out.stdout.split())
+    assert base == 2.0 * (cr * 6 + vr * 3) and planned < 0.5 * ident
