@@ -44,6 +44,7 @@ struct FusedPlan {
     unsigned long long* d_cn_active = nullptr;  // [CR] lanes holding a real check in round R
     unsigned long long* d_next = nullptr;       // frame dispenser
     int sync_off[2] = {0, 0};          // NW = 2: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
+    int msync_off[2] = {0, 0};         // NW = 2: byte offset of a padded marginal slot owned by wave w (end-of-sweep hand-off)
     int zero_row = 0;                  // 1: the c2v area ends with an always-zero row
     size_t lds_bytes = 0;
     int groups_per_cu = 0, num_cu = 0;
@@ -80,6 +81,13 @@ __device__ __forceinline__ void lds_st_tid(float v) {
 }
 __device__ __forceinline__ void lds_set_m0(uint32_t base) { asm volatile("s_mov_b32 m0, %0" ::"s"(base) : "memory"); }
 
+// Workgroup barrier that also drains this wave's LDS queue: the ds_write_addtid stores above are inline asm, invisible to
+// the compiler's s_waitcnt insertion, so a plain __syncthreads() may reach s_barrier with such stores still in flight.
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
 __device__ __forceinline__ float lds_ld(const unsigned char* base, uint32_t byte_off) {
@@ -100,6 +108,7 @@ struct FusedArgs {
     int32_t* iters;
     u64* next_frame;
     int sync_off0, sync_off1, zero_row;
+    int msync_off0, msync_off1;      // NW = 2: byte offset of a padded MARGINAL slot owned by wave w (end-of-sweep hand-off)
     // fused simulate (SIM kernels): BI-AWGN noise generated in the kernel, errors counted in the kernel
     const int32_t* slot_of_var;     // [n rounded up to 4] LDS dword index (marg area) of each variable
     float sim_mean, sim_sigma, sim_k;  // y = mean + sigma z ; prior = -(k y), k = 2/sigma^2   (src/biawgn.py:17-28)
@@ -117,6 +126,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
     constexpr int CR = CRW * NW, VR = VRW * NW;
     constexpr int NPAD = VR * 64;
     constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VRW * DV + 1) / 2;
+    constexpr int VG_BEC = 2;  // variable rounds per pipeline stage of the erasure decoder
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int w = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
@@ -147,12 +157,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
     const uint32_t m0_c2v = lds_base + (uint32_t)(NPAD + w * CRW * DC * 64) * 4;  // this wave's c2v rows
     const uint32_t m0_marg = lds_base + (uint32_t)(w * VRW * 64) * 4;            // this wave's marginal rows
     const uint32_t my_sync = (uint32_t)(w == 0 ? A.sync_off0 : A.sync_off1);
+    const uint32_t my_msync = (uint32_t)(w == 0 ? A.msync_off0 : A.msync_off1);
     const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
     // SIM: per-workgroup counters live in wave 0 (scalars + one histogram bin per lane), flushed once at the end
     unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
     u64 acc_tot = 0, acc_wec = 0, acc_bec = 0, acc_it = 0;
     unsigned hist_lane = 0;
-    if constexpr (SIM) {
+    if constexpr (SIM || ALG == ALG_BEC) {
 #pragma unroll
         for (int q = 0; q < VRW; ++q) valid |= (vslot[q * 64 + lane] >= 0) ? (1u << q) : 0u;
     }
@@ -165,10 +176,37 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
             return mine;
         } else {
             if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_sync) = mine ? 1u : 0u;
-            __syncthreads();
+            wg_barrier();
             const uint32_t v0 = *reinterpret_cast<volatile uint32_t*>(smem + A.sync_off0);
             const uint32_t v1 = *reinterpret_cast<volatile uint32_t*>(smem + A.sync_off1);
             return (v0 | v1) != 0u;
+        }
+    };
+
+    // second hand-off channel: values produced at the END of a variable phase (or after the last sweep) travel through a
+    // padded MARGINAL slot each wave owns -- those are next written in the following variable phase, i.e. behind a
+    // barrier, whereas the c2v hand-off words are overwritten by the very next check phase.
+    auto exchange_or = [&](uint32_t mine) -> uint32_t {  // OR of the words of all waves (contains one barrier)
+        if constexpr (NW == 1) {
+            return mine;
+        } else {
+            if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_msync) = mine;
+            wg_barrier();
+            return *reinterpret_cast<volatile uint32_t*>(smem + A.msync_off0) | *reinterpret_cast<volatile uint32_t*>(smem + A.msync_off1);
+        }
+    };
+    // frame error counts after the last sweep: through whichever pair of hand-off words the sweep loop did NOT just use for
+    // its exit verdict (the other wave may still be reading that one): marginal slots for the LLR decoders, c2v slots for
+    // the erasure decoder
+    auto exchange_add = [&](int mine) -> int {
+        if constexpr (NW == 1) {
+            return mine;
+        } else {
+            const uint32_t mine_off = ALG == ALG_BEC ? my_sync : my_msync;
+            const int o0 = ALG == ALG_BEC ? A.sync_off0 : A.msync_off0, o1 = ALG == ALG_BEC ? A.sync_off1 : A.msync_off1;
+            if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + mine_off) = mine;
+            wg_barrier();
+            return *reinterpret_cast<volatile int32_t*>(smem + o0) + *reinterpret_cast<volatile int32_t*>(smem + o1);
         }
     };
 
@@ -199,12 +237,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
         if constexpr (NW == 1) {
             fr_s = next_frame();
         } else {
-            __syncthreads();  // the verdict slots of the previous frame have been read by everybody
+            wg_barrier();  // the verdict slots of the previous frame have been read by everybody
             if (w == 0) {
                 const long long f0 = next_frame();
                 if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + A.sync_off0) = (int32_t)f0;
             }
-            __syncthreads();
+            wg_barrier();
             fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(smem + A.sync_off0));
         }
         if (fr_s < 0) break;
@@ -226,22 +264,33 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                     box_muller<float>(ph.w[2], ph.w[3], z[2], z[3]);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) pri4[t] = -(A.sim_k * (A.sim_mean + A.sim_sigma * z[t]));
-                } else {  // BSC: same integer threshold and the same LLR expression as k_discrete
+                } else if (A.sim_channel == CH_BSC) {  // same integer threshold and the same LLR expression as k_discrete
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int y = A.codeword ^ ((u64)ph.w[t] < A.bsc_thr ? 1 : 0);
                         pri4[t] = A.bsc_llr * (float)(1 - 2 * y);
                     }
+                } else {  // BEC: erased where the word is below the threshold; ternary message {-1 (bit 0), +1 (bit 1), 0 (erased)}
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pri4[t] = (u64)ph.w[t] < A.bsc_thr ? 0.0f : (A.codeword ? 1.0f : -1.0f);
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     if (blk * 4 + t < n) reinterpret_cast<float*>(smem)[slots[t]] = pri4[t];
             }
-            if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q = 0; q < VRW; ++q) {
                 prior[q] = lds_marg[q * 64 + lane];  // padded slots: stale words, never used
                 if (A.sim_channel == CH_BSC) xb |= (__float_as_uint(prior[q]) >> 31) << q;  // x_hat starts as the received word
+            }
+        } else if constexpr (ALG == ALG_BEC) {
+            const uint8_t* yf = A.y0 + fr * n;  // received symbols {0,1,2}; message {-1,+1,0}[y] (src/bec.py:76,85)
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                const int v = vmap_of(q);
+                const int y = v >= 0 ? (int)yf[v] : 2;
+                prior[q] = y == 0 ? -1.0f : (y == 1 ? 1.0f : 0.0f);
             }
         } else {
             const float* pf = A.priors + fr * n;
@@ -258,7 +307,101 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
 
         int it = 0;
         bool left_at_0 = false;
-        if (!SIM && A.y0 != nullptr) {
+
+        unsigned xe = 0;  // erasure decoder: bit q = variable slot (q, lane) still erased (xb then holds the known ones)
+        if constexpr (ALG == ALG_BEC) {
+            // Ternary message passing with the reference's two exits (src/bec.py:96-97,120): "no erasure left" before a
+            // sweep, "x_hat did not change" after it.  `it` counts executed sweeps (the one that finds no change included).
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                lds_marg[q * 64 + lane] = prior[q];
+                xb |= (prior[q] > 0.0f) ? (1u << q) : 0u;
+                xe |= (prior[q] == 0.0f) ? (1u << q) : 0u;
+            }
+            xe &= valid;
+            bool erased_any = exchange_or(__ballot(xe != 0u) != 0 ? 1u : 0u) != 0u;  // NW > 1: the barrier also publishes marg
+            if constexpr (NW == 1) __builtin_amdgcn_wave_barrier();
+            int updates = 0;  // the reference's iter_count: sweeps that changed x_hat
+            for (;;) {
+                if (max_iter > 0 && updates >= max_iter) break;
+                if (early && !erased_any) break;
+                lds_set_m0(m0_c2v);
+                float mg[2][DC];
+#pragma unroll
+                for (int j = 0; j < DC; ++j) mg[0][j] = lds_ld(smem, half_of<CRW * DC>(cn_idx, j));
+                static_for<0, CRW>([&](auto R_) {
+                    constexpr int r = decltype(R_)::value;
+                    if constexpr (r + 1 < CRW) {
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_ld(smem, half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    float sgn[DC];
+                    float n_erased = 0.0f, n_ones = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) {
+                        const float dlt = mg[r & 1][j] - c2v_old[r][j];           // v2c = sign(marginal - c2v)  (src/bec.py:116)
+                        sgn[j] = dlt > 0.0f ? 1.0f : (dlt < 0.0f ? -1.0f : 0.0f);
+                        n_erased += 1.0f - __builtin_fabsf(sgn[j]);
+                        n_ones += sgn[j] > 0.0f ? 1.0f : 0.0f;
+                    }
+                    const float fill = ((int)n_ones & 1) ? 1.0f : -1.0f;  // parity of the known ones (src/bec.py:110-112)
+                    static_for<0, DC>([&](auto J_) {
+                        constexpr int j = decltype(J_)::value;
+                        // 0 erasures: echo; > 1: nothing known; exactly 1: the erased edge learns the parity of the others
+                        const float c = n_erased == 0.0f ? sgn[j] : (n_erased > 1.0f ? 0.0f : (sgn[j] == 0.0f ? fill : 0.0f));
+                        c2v_old[r][j] = c;
+                        lds_st_tid<(r * DC + j) * 256>(c);
+                    });
+                });
+                if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
+                lds_set_m0(m0_marg);
+                unsigned nb = 0, ne = 0;
+                float cv[2][VG_BEC][DV];
+#pragma unroll
+                for (int u = 0; u < VG_BEC; ++u)
+#pragma unroll
+                    for (int j = 0; j < DV; ++j)
+                        if (u < VRW) cv[0][u][j] = lds_ld(smem, half_of<VRW * DV>(vn_idx, u * DV + j));
+                static_for<0, (VRW + VG_BEC - 1) / VG_BEC>([&](auto G_) {
+                    constexpr int g = decltype(G_)::value;
+                    if constexpr (g + 1 < (VRW + VG_BEC - 1) / VG_BEC) {
+#pragma unroll
+                        for (int u = 0; u < VG_BEC; ++u)
+#pragma unroll
+                            for (int j = 0; j < DV; ++j)
+                                if ((g + 1) * VG_BEC + u < VRW)
+                                    cv[(g + 1) & 1][u][j] = lds_ld(smem, half_of<VRW * DV>(vn_idx, ((g + 1) * VG_BEC + u) * DV + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, VG_BEC>([&](auto U_) {
+                        constexpr int u = decltype(U_)::value;
+                        constexpr int q = g * VG_BEC + u;
+                        if constexpr (q < VRW) {
+                            float sm = cv[g & 1][u][0];
+#pragma unroll
+                            for (int j = 1; j < DV; ++j) sm += cv[g & 1][u][j];
+                            const float m1 = prior[q] + sm;  // small integers: exact
+                            lds_st_tid<q * 256>(m1);
+                            nb |= (m1 > 0.0f) ? (1u << q) : 0u;
+                            ne |= (m1 == 0.0f) ? (1u << q) : 0u;
+                        }
+                    });
+                });
+                ++it;
+                const unsigned chg = ((nb ^ xb) | (ne ^ xe)) & valid;
+                ne &= valid;
+                // bit 0: some decision changed, bit 1: some variable is still erased (barrier inside for NW > 1)
+                const uint32_t verdict = exchange_or((__ballot(chg != 0u) != 0 ? 1u : 0u) | (__ballot(ne != 0u) != 0 ? 2u : 0u));
+                if constexpr (NW == 1) __builtin_amdgcn_wave_barrier();
+                if (early && !(verdict & 1u)) break;  // stopping set: x_hat stays (it equals the new word anyway)
+                xb = nb;
+                xe = ne;
+                erased_any = (verdict & 2u) != 0u;
+                ++updates;
+            }
+        }
+        if (ALG != ALG_BEC && !SIM && A.y0 != nullptr) {
             // iteration-0 test of the received hard word (src/bpa.py:20,29): park it in the marg area as -+1
             const uint8_t* yf = A.y0 + fr * n;
 #pragma unroll
@@ -268,7 +411,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                 lds_marg[q * 64 + lane] = one ? -1.0f : 1.0f;
                 xb |= one ? (1u << q) : 0u;
             }
-            if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
             u64 unsat = 0;
 #pragma unroll
             for (int r = 0; r < CRW; ++r) {
@@ -278,12 +421,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                 if constexpr (DC % 2 == 0) unsat |= par; else unsat |= par & cn_active[r];
             }
             left_at_0 = early && !any_unsat(unsat != 0);
-            if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
         }
-        if (!left_at_0) {
+        if (ALG != ALG_BEC && !left_at_0) {
 #pragma unroll
             for (int q = 0; q < VRW; ++q) lds_marg[q * 64 + lane] = prior[q];
-            if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+            if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
             // The sweep is one software-pipelined stream of LDS traffic: the gathers of check round r+1 (variable
             // group g+1) are issued before round r (group g) is computed, so a wave always has a full round of
             // ds_reads in flight while it does arithmetic.
@@ -402,21 +545,17 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                         }
                     });
                 });
-                if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+                if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
                 ++it;
             }
         }
         if constexpr (SIM) {
             // errors against the all-`codeword` word (src/main.py:41-45), counted from the decision bits
-            const unsigned wrong = (A.codeword ? ~xb : xb) & valid;
+            const unsigned wrong = ((A.codeword ? ~xb : xb) | xe) & valid;  // an unresolved erasure counts as a bit error
             int err = 0;
 #pragma unroll
             for (int q = 0; q < VRW; ++q) err += __popcll(__ballot((wrong >> q) & 1u));
-            if constexpr (NW > 1) {
-                if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + my_sync) = err;
-                __syncthreads();
-                err = *reinterpret_cast<volatile int32_t*>(smem + A.sync_off0) + *reinterpret_cast<volatile int32_t*>(smem + A.sync_off1);
-            }
+            err = exchange_add(err);
             err = __builtin_amdgcn_readfirstlane(err);  // wave-uniform: keep the accumulators in scalar registers
             acc_tot += 1;
             acc_wec += err > 0;
@@ -430,7 +569,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
 #pragma unroll
             for (int q = 0; q < VRW; ++q) {
                 const int v = vmap_of(q);
-                if (v >= 0) xf[v] = (uint8_t)((xb >> q) & 1u);
+                if (v >= 0) xf[v] = ((xe >> q) & 1u) ? (uint8_t)2 : (uint8_t)((xb >> q) & 1u);
             }
         }
     }
@@ -469,9 +608,9 @@ constexpr ShapeEntry shape_entry() {
 // instantiated shapes, (3,6)-regular codes, min-sum and sum-product (fp32).  Preference order = table order:
 // two waves per frame for n <= 1280 (fully regular codes only: no room for the zero row), else one wave per frame.
 const ShapeEntry kShapes[] = {
-    shape_entry<ALG_MSA, 6, 3, 4, 8, 1>(),   shape_entry<ALG_SPA, 6, 3, 4, 8, 1>(),    // m <= 256, n <= 512
-    shape_entry<ALG_MSA, 6, 3, 5, 10, 2>(),  shape_entry<ALG_SPA, 6, 3, 5, 10, 2>(),   // m <= 640, n <= 1280, 2 waves/frame
-    shape_entry<ALG_MSA, 6, 3, 10, 19, 1>(), shape_entry<ALG_SPA, 6, 3, 10, 19, 1>(),  // m <= 640, n <= 1216, 1 wave/frame
+    shape_entry<ALG_MSA, 6, 3, 4, 8, 1>(),   shape_entry<ALG_SPA, 6, 3, 4, 8, 1>(),   shape_entry<ALG_BEC, 6, 3, 4, 8, 1>(),    // m <= 256, n <= 512
+    shape_entry<ALG_MSA, 6, 3, 5, 10, 2>(),  shape_entry<ALG_SPA, 6, 3, 5, 10, 2>(),  shape_entry<ALG_BEC, 6, 3, 5, 10, 2>(),   // m <= 640, n <= 1280, 2 waves/frame
+    shape_entry<ALG_MSA, 6, 3, 10, 19, 1>(), shape_entry<ALG_SPA, 6, 3, 10, 19, 1>(), shape_entry<ALG_BEC, 6, 3, 10, 19, 1>(),  // m <= 640, n <= 1216, 1 wave/frame
 };
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
@@ -498,7 +637,7 @@ int fused_plan_create(Decoder* d) {
     const Code* c = d->code;
     d->fused = new FusedPlan();
     FusedPlan* p = d->fused;
-    if ((d->alg != ALG_MSA && d->alg != ALG_SPA) || d->dtype != DT_F32) return LDPC_OK;  // the rest stays on the streaming backend
+    if (d->alg != ALG_BEC && d->dtype != DT_F32) return LDPC_OK;  // fp64 message arithmetic stays on the streaming backend
     if (c->min_dc != c->max_dc) return LDPC_OK;
     const bool full_dv = c->min_dv == c->max_dv;  // every variable has all its DV edges: no zero row needed
     int force_nw = 0;
@@ -624,6 +763,11 @@ int fused_plan_create(Decoder* d) {
                     if (!((cn_active[R] >> lane) & 1ull)) found = (int)c2v_base + ((R * DC + DC - 1) * 64 + lane) * 4;
             if (found < 0) return LDPC_OK;  // (plan stays !ok -> streaming backend; practically unreachable)
             p->sync_off[wv] = found;
+            int mfound = -1;
+            for (int s = wv * VRW * 64; s < (wv + 1) * VRW * 64 && mfound < 0; ++s)
+                if (var_of_slot[s] < 0) mfound = s * 4;
+            if (mfound < 0) return LDPC_OK;
+            p->msync_off[wv] = mfound;
         }
     }
     p->lds_bytes = (size_t)(NPAD + (CR * DC + p->zero_row) * 64) * 4;
@@ -684,6 +828,8 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
     a.next_frame = p->d_next;
     a.sync_off0 = p->sync_off[0];
     a.sync_off1 = p->sync_off[1];
+    a.msync_off0 = p->msync_off[0];
+    a.msync_off1 = p->msync_off[1];
     a.zero_row = p->zero_row;
     void* args[] = {&a};
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -711,8 +857,8 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
         return LDPC_E_UNSUPPORTED;
     }
     if (B <= 0) return LDPC_OK;
-    if (!priors) {
-        set_error("priors pointer is null");
+    if (d->alg == ALG_BEC ? !y0 : !priors) {
+        set_error(d->alg == ALG_BEC ? "erasure decoder needs the received symbols (y0)" : "priors pointer is null");
         return LDPC_E_ARG;
     }
     FusedArgs a{};
@@ -726,6 +872,7 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
 // channel -> LLR -> decode -> count in ONE kernel (BI-AWGN, all-`codeword` word): priors never touch HBM.
 bool fused_simulate_supported(const Decoder* d, int channel, double param, int hist_bins) {
     if (!fused_supported(d) || hist_bins < 1 || hist_bins > 64) return false;
+    if (d->alg == ALG_BEC) return channel == CH_BEC;
     return channel == CH_BIAWGN || (channel == CH_BSC && param > 0.0 && param < 0.5);  // BSC: needs llr > 0
 }
 
@@ -744,10 +891,10 @@ int fused_simulate(Decoder* d, int channel, double param, int codeword, uint64_t
     a.codeword = codeword;
     a.hist_bins = hist_bins;
     a.sim_channel = channel;
-    if (channel == CH_BSC) {
+    if (channel == CH_BSC || channel == CH_BEC) {
         double t = ceil(param * 4294967296.0 - 0.5);  // same threshold as channel_generate()
         a.bsc_thr = (unsigned long long)(t < 0 ? 0 : t);
-        a.bsc_llr = (float)(log(1.0 - param) - log(param));
+        a.bsc_llr = channel == CH_BSC ? (float)(log(1.0 - param) - log(param)) : 0.0f;
     }
     a.counters = (unsigned long long*)counters;
     return fused_launch(d, a, true, B, max_iter, flags, st);

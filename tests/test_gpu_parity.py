@@ -266,3 +266,30 @@ def test_fused_variants_ragged_and_iteration0(nw, monkeypatch):
     h = bpa.MSA(code, max_iter=3, precision="f32", backend="fused").handle
     x3, i3 = h.decode_device(torch.from_numpy(pri).cuda(), None, 3, flags=1)
     assert (i3.cpu().numpy() == 3).all()
+
+
+@pytest.mark.parametrize("nw", ["1", "2"])
+def test_fused_erasure_decoder_variants(nw, monkeypatch):
+    # fused erasure decoder (1 and 2 wavefronts per frame) against the C oracle incl. stopping sets, max_iter cuts and the
+    # fused simulate counters (channel + decode + count in one kernel) -- repeated to shake out hand-off races
+    import torch
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    monkeypatch.setenv("LDPC_FUSED_NW", nw)
+    g, code = _code("1200_3_6_rand_ldpc_1")
+    h = DecoderHandle(code, "BEC", "f32", "fused")
+    assert h.fused_info()["waves_per_frame"] == float(nw)
+    for rep in range(3):
+        _, y = h.channel_device("bec", 0.41, rep & 1, 77 + rep, 2, 5000 * rep, 1500)
+        yh = y.cpu().numpy()
+        for mi in (50, 2):
+            xh, it = h.decode_device(None, y, mi)
+            xo, io = C.bec_decode(g, yh, mi)
+            assert (xh.cpu().numpy() == xo).all() and (it.cpu().numpy() == io).all()
+        cnt = torch.zeros(4 + 51, dtype=torch.int64, device="cuda")
+        h.simulate("bec", 0.41, rep & 1, 77 + rep, 2, 5000 * rep, 1500, 50, cnt, hist_bins=51)
+        xo, io = C.bec_decode(g, yh, 50)
+        err = (xo != (rep & 1)).sum(axis=1)
+        c = cnt.cpu().numpy()
+        assert (c[0], c[1], c[2], c[3]) == (1500, (err > 0).sum(), err.sum(), io.sum())
+        assert (c[4:] == np.bincount(np.minimum(io, 50), minlength=51)).all()

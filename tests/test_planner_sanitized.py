@@ -50,7 +50,7 @@ def test_layout_planner_under_asan(tmp_path, cr, vr):
     # host-only build of the planner: the HIP header is only needed for types in ldpc_common.hpp -> use hipcc's host pass
     hipcc = "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", CSRC, "-x", "hip",
-           "--offload-arch=gfx950", str(src), os.path.join(CSRC, "ldpc_layout.hip"), "-o", exe]
+           "--offload-arch=gfx950", "--cuda-host-only", str(src), os.path.join(CSRC, "ldpc_layout.hip"), "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip("sanitized host build unavailable here: " + r.stderr[-300:])

@@ -16,12 +16,15 @@ ap.add_argument("--alg", default="MSA")
 a = ap.parse_args()
 g, code = load_code(a.code)
 h = DecoderHandle(code, a.alg, a.precision, a.backend)
-pri, _ = h.channel_device("biawgn", a.snr, 0, 1, 0, 0, a.batch)
-xh, it = h.decode_device(pri, None, 50)
+if a.alg == "BEC":
+    pri, y = h.channel_device("bec", a.snr, 0, 1, 0, 0, a.batch)  # --snr carries the erasure probability
+else:
+    pri, y = h.channel_device("biawgn", a.snr, 0, 1, 0, 0, a.batch)
+xh, it = h.decode_device(pri, y, 50)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.reps):
-    h.decode_device(pri, None, 50, xhat=xh, iters=it)
+    h.decode_device(pri, y, 50, xhat=xh, iters=it)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.reps
 # known-size 4 B/lane copy (calibration of FETCH_SIZE / WRITE_SIZE): 1 GiB in, 1 GiB out
