@@ -29,8 +29,23 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 
 
 def load_code(name):
-    from helpers import golden_edges
+    """Golden fixture name, or a generated ensemble member: 'gen:reg:<n>:<l>:<r>' / 'gen:irg:<n>' (BASELINE configs 4-5)."""
+    from ldpc_decoders_amd import codes
     from ldpc_decoders_amd.codes import Code
+
+    if name.startswith("gen:"):
+        parts = name.split(":")
+        rng = np.random.RandomState(20261002)
+        if parts[1] == "reg":
+            code = codes.rand_reg_ldpc(int(parts[2]), int(parts[3]), int(parts[4]), rng)
+        else:
+            code = codes.rand_irregular_ldpc(int(parts[2]), codes.LAMBDA_RHO_X5_HALF_RATE, 6, rng)
+
+        class G:  # graph view for the C oracle
+            m, n, E, chk, var = code.m, code.n, code.E, code.edge_chk, code.edge_var
+
+        return G, code
+    from helpers import golden_edges
 
     g = golden_edges(name)
     return g, Code.from_edges(g.m, g.n, g.chk, g.var)
