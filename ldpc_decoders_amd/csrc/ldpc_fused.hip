@@ -121,12 +121,16 @@ struct FusedArgs {
     unsigned long long* counters;   // [4 + hist_bins] tot, wec, bec, iter_sum, histogram of sweeps
 };
 
-template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM>
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const FusedArgs A) {
+    static_assert(VRX == 0 || NW == 1, "wide variable rounds (irregular codes) are built for one wave per frame");
+    constexpr int VNK = VRX * DVX + (VRW - VRX) * DV;  // gathers of a variable phase: wide rounds first, then narrow ones
+    constexpr int VN0 = VRX * DVX;                      // first gather index of the narrow rounds
     constexpr int CR = CRW * NW, VR = VRW * NW;
     constexpr int NPAD = VR * 64;
-    constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VRW * DV + 1) / 2;
+    constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
     constexpr int VG_BEC = 2;  // variable rounds per pipeline stage of the erasure decoder
+    constexpr int VRN = VRW - VRX;  // narrow variable rounds (DV gathers); they follow the VRX wide rounds
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int w = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
@@ -163,9 +167,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
     unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
     u64 acc_tot = 0, acc_wec = 0, acc_bec = 0, acc_it = 0;
     unsigned hist_lane = 0;
-    if constexpr (SIM || ALG == ALG_BEC) {
+    unsigned dummy = 0;  // bit q: slot (q, lane) is the "certain" slot that pads short check rows (var_of_slot == -2)
+    if constexpr (SIM || ALG == ALG_BEC || VRX > 0) {
 #pragma unroll
-        for (int q = 0; q < VRW; ++q) valid |= (vslot[q * 64 + lane] >= 0) ? (1u << q) : 0u;
+        for (int q = 0; q < VRW; ++q) {
+            valid |= (vslot[q * 64 + lane] >= 0) ? (1u << q) : 0u;
+            dummy |= (vslot[q * 64 + lane] == -2) ? (1u << q) : 0u;
+        }
     }
 
     // verdict exchange between the NW waves of a frame: each wave publishes "my checks see an unsatisfied syndrome" in a
@@ -300,6 +308,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                 prior[q] = v >= 0 ? pf[v] : 0.0f;
             }
         }
+        if constexpr (VRX > 0) {
+            // the padding slot of short check rows is a variable known with certainty: +inf LLR (bit 0) for the LLR decoders --
+            // it never wins a minimum, adds nothing to a join and has sign 0 -- and -inf (a known 0) for the erasure decoder
+#pragma unroll
+            for (int q = 0; q < VRW; ++q)
+                if ((dummy >> q) & 1u) prior[q] = ALG == ALG_BEC ? -__builtin_huge_valf() : __builtin_huge_valf();
+        }
 #pragma unroll
         for (int r = 0; r < CRW; ++r)
 #pragma unroll
@@ -357,34 +372,54 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                 if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
                 lds_set_m0(m0_marg);
                 unsigned nb = 0, ne = 0;
+                auto finish_var = [&](auto Q_, float sm) {
+                    constexpr int q = decltype(Q_)::value;
+                    const float m1 = prior[q] + sm;  // small integers: exact
+                    lds_st_tid<q * 256>(m1);
+                    nb |= (m1 > 0.0f) ? (1u << q) : 0u;
+                    ne |= (m1 == 0.0f) ? (1u << q) : 0u;
+                };
+                if constexpr (VRX > 0) {
+                    float cw[2][DVX];
+#pragma unroll
+                    for (int j = 0; j < DVX; ++j) cw[0][j] = lds_ld(smem, half_of<VNK>(vn_idx, j));
+                    static_for<0, VRX>([&](auto Q_) {
+                        constexpr int q = decltype(Q_)::value;
+                        if constexpr (q + 1 < VRX) {
+#pragma unroll
+                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = lds_ld(smem, half_of<VNK>(vn_idx, (q + 1) * DVX + j));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        float sw = cw[q & 1][0];
+#pragma unroll
+                        for (int j = 1; j < DVX; ++j) sw += cw[q & 1][j];
+                        finish_var(Q_, sw);
+                    });
+                }
                 float cv[2][VG_BEC][DV];
 #pragma unroll
                 for (int u = 0; u < VG_BEC; ++u)
 #pragma unroll
                     for (int j = 0; j < DV; ++j)
-                        if (u < VRW) cv[0][u][j] = lds_ld(smem, half_of<VRW * DV>(vn_idx, u * DV + j));
-                static_for<0, (VRW + VG_BEC - 1) / VG_BEC>([&](auto G_) {
+                        if (u < VRN) cv[0][u][j] = lds_ld(smem, half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                static_for<0, (VRN + VG_BEC - 1) / VG_BEC>([&](auto G_) {
                     constexpr int g = decltype(G_)::value;
-                    if constexpr (g + 1 < (VRW + VG_BEC - 1) / VG_BEC) {
+                    if constexpr (g + 1 < (VRN + VG_BEC - 1) / VG_BEC) {
 #pragma unroll
                         for (int u = 0; u < VG_BEC; ++u)
 #pragma unroll
                             for (int j = 0; j < DV; ++j)
-                                if ((g + 1) * VG_BEC + u < VRW)
-                                    cv[(g + 1) & 1][u][j] = lds_ld(smem, half_of<VRW * DV>(vn_idx, ((g + 1) * VG_BEC + u) * DV + j));
+                                if ((g + 1) * VG_BEC + u < VRN)
+                                    cv[(g + 1) & 1][u][j] = lds_ld(smem, half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG_BEC + u) * DV + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     static_for<0, VG_BEC>([&](auto U_) {
                         constexpr int u = decltype(U_)::value;
-                        constexpr int q = g * VG_BEC + u;
-                        if constexpr (q < VRW) {
+                        if constexpr (g * VG_BEC + u < VRN) {
                             float sm = cv[g & 1][u][0];
 #pragma unroll
                             for (int j = 1; j < DV; ++j) sm += cv[g & 1][u][j];
-                            const float m1 = prior[q] + sm;  // small integers: exact
-                            lds_st_tid<q * 256>(m1);
-                            nb |= (m1 > 0.0f) ? (1u << q) : 0u;
-                            ne |= (m1 == 0.0f) ? (1u << q) : 0u;
+                            finish_var(std::integral_constant<int, VRX + g * VG_BEC + u>{}, sm);
                         }
                     });
                 });
@@ -431,7 +466,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
             // group g+1) are issued before round r (group g) is computed, so a wave always has a full round of
             // ds_reads in flight while it does arithmetic.
             constexpr int VG = (ALG == ALG_MSA && NW == 1) ? 4 : 2;  // variable rounds per pipeline stage (register budget)
-            constexpr int NVG = (VRW + VG - 1) / VG;
+            constexpr int NVG = (VRN + VG - 1) / VG;
             for (;;) {
                 if (max_iter > 0 && it >= max_iter) break;
                 lds_set_m0(m0_c2v);
@@ -514,12 +549,37 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                 // ---------------- variable phase
                 lds_set_m0(m0_marg);
                 xb = 0;
+                // one variable: ordered sum from +0.0 (as scipy; keeps -0.0 out of the marginals), prior last, decision bit
+                auto finish_var = [&](auto Q_, float s) {
+                    constexpr int q = decltype(Q_)::value;
+                    const float m1 = prior[q] + s;
+                    lds_st_tid<q * 256>(m1);
+                    // decision: (m1 < 0); for min-sum the sign bit itself (m1 is never -0.0 and never NaN for finite priors)
+                    if constexpr (ALG == ALG_MSA) xb |= (__float_as_uint(m1) >> 31) << q; else xb |= (m1 < 0.0f) ? (1u << q) : 0u;
+                };
+                if constexpr (VRX > 0) {  // wide rounds of irregular codes: DVX gathers per variable, one round per stage
+                    float cw[2][DVX];
+#pragma unroll
+                    for (int j = 0; j < DVX; ++j) cw[0][j] = lds_ld(smem, half_of<VNK>(vn_idx, j));
+                    static_for<0, VRX>([&](auto Q_) {
+                        constexpr int q = decltype(Q_)::value;
+                        if constexpr (q + 1 < VRX) {
+#pragma unroll
+                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = lds_ld(smem, half_of<VNK>(vn_idx, (q + 1) * DVX + j));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        float sw = 0.0f + cw[q & 1][0];
+#pragma unroll
+                        for (int j = 1; j < DVX; ++j) sw += cw[q & 1][j];
+                        finish_var(Q_, sw);
+                    });
+                }
                 float cv[2][VG][DV];
 #pragma unroll
                 for (int u = 0; u < VG; ++u)
 #pragma unroll
                     for (int j = 0; j < DV; ++j)
-                        if (u < VRW) cv[0][u][j] = lds_ld(smem, half_of<VRW * DV>(vn_idx, u * DV + j));
+                        if (u < VRN) cv[0][u][j] = lds_ld(smem, half_of<VNK>(vn_idx, VN0 + u * DV + j));
                 static_for<0, NVG>([&](auto G_) {
                     constexpr int g = decltype(G_)::value;
                     if constexpr (g + 1 < NVG) {
@@ -527,21 +587,17 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
                         for (int u = 0; u < VG; ++u)
 #pragma unroll
                             for (int j = 0; j < DV; ++j)
-                                if ((g + 1) * VG + u < VRW)
-                                    cv[(g + 1) & 1][u][j] = lds_ld(smem, half_of<VRW * DV>(vn_idx, ((g + 1) * VG + u) * DV + j));
+                                if ((g + 1) * VG + u < VRN)
+                                    cv[(g + 1) & 1][u][j] = lds_ld(smem, half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG + u) * DV + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     static_for<0, VG>([&](auto U_) {
                         constexpr int u = decltype(U_)::value;
-                        constexpr int q = g * VG + u;
-                        if constexpr (q < VRW) {
-                            float s = 0.0f + cv[g & 1][u][0];  // as scipy: accumulate from +0.0 (keeps -0.0 out of the marginals)
+                        if constexpr (g * VG + u < VRN) {
+                            float sn = 0.0f + cv[g & 1][u][0];
 #pragma unroll
-                            for (int j = 1; j < DV; ++j) s += cv[g & 1][u][j];
-                            const float m1 = prior[q] + s;
-                            lds_st_tid<q * 256>(m1);
-                            // decision bit: (m1 < 0); for min-sum the sign bit itself (m1 is never -0.0 and never NaN for finite priors)
-                            if constexpr (ALG == ALG_MSA) xb |= (__float_as_uint(m1) >> 31) << q; else xb |= (m1 < 0.0f) ? (1u << q) : 0u;
+                            for (int j = 1; j < DV; ++j) sn += cv[g & 1][u][j];
+                            finish_var(std::integral_constant<int, VRX + g * VG + u>{}, sn);
                         }
                     });
                 });
@@ -594,15 +650,15 @@ int upload_vec(const std::vector<T>& h, T** d) {
 }
 
 struct ShapeEntry {
-    int alg, DC, DV, CRW, VRW, NW;
+    int alg, DC, DV, CRW, VRW, NW, VRX, DVX;  // VRX wide variable rounds of DVX gathers (irregular codes), 0 for regular
     const void* kernel;      // decode: priors in, decisions out
     const void* kernel_sim;  // simulate: noise in the kernel, counters out
 };
 
-template <int ALG, int DC, int DV, int CRW, int VRW, int NW>
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, int VRX = 0, int DVX = DV>
 constexpr ShapeEntry shape_entry() {
-    return ShapeEntry{ALG, DC, DV, CRW, VRW, NW, (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW, false>,
-                      (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW, true>};
+    return ShapeEntry{ALG, DC, DV, CRW, VRW, NW, VRX, DVX, (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW, false, VRX, DVX>,
+                      (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW, true, VRX, DVX>};
 }
 
 // instantiated shapes, (3,6)-regular codes, min-sum and sum-product (fp32).  Preference order = table order:
@@ -611,6 +667,8 @@ const ShapeEntry kShapes[] = {
     shape_entry<ALG_MSA, 6, 3, 4, 8, 1>(),   shape_entry<ALG_SPA, 6, 3, 4, 8, 1>(),   shape_entry<ALG_BEC, 6, 3, 4, 8, 1>(),    // m <= 256, n <= 512
     shape_entry<ALG_MSA, 6, 3, 5, 10, 2>(),  shape_entry<ALG_SPA, 6, 3, 5, 10, 2>(),  shape_entry<ALG_BEC, 6, 3, 5, 10, 2>(),   // m <= 640, n <= 1280, 2 waves/frame
     shape_entry<ALG_MSA, 6, 3, 10, 19, 1>(), shape_entry<ALG_SPA, 6, 3, 10, 19, 1>(), shape_entry<ALG_BEC, 6, 3, 10, 19, 1>(),  // m <= 640, n <= 1216, 1 wave/frame
+    // irregular: check degrees <= 6 (short rows padded by a "certain" variable), variable degrees <= 8 (at most 256 above 3)
+    shape_entry<ALG_MSA, 6, 3, 10, 19, 1, 4, 8>(), shape_entry<ALG_SPA, 6, 3, 10, 19, 1, 4, 8>(), shape_entry<ALG_BEC, 6, 3, 10, 19, 1, 4, 8>(),
 };
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
@@ -638,16 +696,24 @@ int fused_plan_create(Decoder* d) {
     d->fused = new FusedPlan();
     FusedPlan* p = d->fused;
     if (d->alg != ALG_BEC && d->dtype != DT_F32) return LDPC_OK;  // fp64 message arithmetic stays on the streaming backend
-    if (c->min_dc != c->max_dc) return LDPC_OK;
     const bool full_dv = c->min_dv == c->max_dv;  // every variable has all its DV edges: no zero row needed
+    const bool short_rows = c->min_dc != c->max_dc;
+    if (c->min_dc < 1) return LDPC_OK;
     int force_nw = 0;
     if (const char* e = std::getenv("LDPC_FUSED_NW")) force_nw = atoi(e);
     int si = -1;
     for (int i = 0; i < kNumShapes && si < 0; ++i) {
         const ShapeEntry& s = kShapes[i];
         const int CR = s.CRW * s.NW, VR = s.VRW * s.NW;
-        if (s.alg != d->alg || c->max_dc != s.DC || c->max_dv > s.DV || c->m > CR * 64 || c->n > VR * 64) continue;
+        if (s.alg != d->alg || c->max_dc != s.DC || c->m > CR * 64 || c->n + (short_rows ? 1 : 0) > VR * 64) continue;
         if (force_nw && s.NW != force_nw) continue;
+        if (s.VRX == 0) {
+            if (short_rows || c->max_dv > s.DV) continue;
+        } else {
+            int wide = 0;
+            for (int v = 0; v < c->n; ++v) wide += (c->col_ptr[v + 1] - c->col_ptr[v]) > s.DV;
+            if (c->max_dv > s.DVX || wide > s.VRX * 64) continue;
+        }
         if (s.NW > 1 && (!full_dv || c->max_dv != s.DV || CR * 64 - c->m < s.NW)) continue;  // needs padded check slots for the hand-off
         si = i;
     }
@@ -655,6 +721,8 @@ int fused_plan_create(Decoder* d) {
     const ShapeEntry& shape = kShapes[si];
     const int DC = shape.DC, DV = shape.DV, NW = shape.NW, CRW = shape.CRW, VRW = shape.VRW;
     const int CR = CRW * NW, VR = VRW * NW, NPAD = VR * 64;
+    VarRounds vr;
+    vr.VR = VR; vr.DV = DV; vr.vrx = shape.VRX; vr.dvx = shape.DVX;
     p->shape = si; p->DC = DC; p->DV = DV; p->CR = CR; p->VR = VR; p->NW = NW;
     p->zero_row = (NW == 1) ? 1 : 0;
 
@@ -663,22 +731,23 @@ int fused_plan_create(Decoder* d) {
     const char* mode = std::getenv("LDPC_FUSED_LAYOUT");
     const char* ms = std::getenv("LDPC_FUSED_PLAN_MS");
     if (mode && std::string(mode) == "identity") {
-        identity_layout(*c, DC, DV, &L);
+        identity_layout(*c, DC, vr, &L);
         if (NW > 1) {  // spread the checks / variables evenly over the waves so that every wave keeps padded slots
             for (int cc = 0; cc < c->m; ++cc) L.chk_slot[cc] = (int)((int64_t)cc * CR * 64 / c->m);
             for (int v = 0; v < c->n; ++v) L.var_slot[v] = (int)((int64_t)v * NPAD / c->n);
         }
-        L.base_cycles = 2.0 * (CR * DC + VR * DV);
-        L.extra_cycles_identity = L.extra_cycles_planned = layout_extra_cycles(*c, DC, DV, CR, VR, L);
+        L.base_cycles = 2.0 * (CR * DC + vr.total_gathers());
+        L.extra_cycles_identity = L.extra_cycles_planned = layout_extra_cycles(*c, DC, CR, vr, L);
     } else {
-        plan_fused_layout(*c, DC, DV, CR, VR, 0x1200u, ms ? atof(ms) * 1e-3 : 0.6, &L);
+        plan_fused_layout(*c, DC, CR, vr, 0x1200u, ms ? atof(ms) * 1e-3 : 0.6, &L);
     }
     p->extra_identity = L.extra_cycles_identity;
     p->extra_planned = L.extra_cycles_planned;
     p->base_cycles = L.base_cycles;
     const std::vector<int>&chk_slot = L.chk_slot, &var_slot = L.var_slot, &edge_pos = L.edge_pos, &var_pos = L.var_pos;
 
-    const int CNW = (CRW * DC + 1) / 2, VNW = (VRW * DV + 1) / 2;
+    const int VNK = vr.total_gathers() / NW;  // gathers of one wave's variable phase (wide rounds exist only for NW == 1)
+    const int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
     std::vector<uint32_t> cn_tab((size_t)NW * CNW * 64, 0), vn_tab((size_t)NW * VNW * 64, 0);
     std::vector<int32_t> var_of_slot((size_t)NPAD, -1);
     std::vector<u64> cn_active((size_t)CR, 0);
@@ -689,23 +758,40 @@ int fused_plan_create(Decoder* d) {
         w = (k & 1) ? ((w & 0x0000ffffu) | (val << 16)) : ((w & 0xffff0000u) | val);
     };
     const uint32_t c2v_base = (uint32_t)NPAD * 4;
-    std::vector<int64_t> cn_addr((size_t)CR * DC * 64, -1), vn_addr((size_t)VR * DV * 64, -1);  // byte offsets, -1 = padded lane
+    std::vector<int64_t> cn_addr((size_t)CR * DC * 64, -1), vn_addr((size_t)vr.total_gathers() * 64, -1);  // byte offsets, -1 = padded lane
     for (int v = 0; v < c->n; ++v) var_of_slot[var_slot[v]] = v;
+    // short check rows are padded with reads of one "certain" variable slot (marked -2): +-inf marginal, see the kernel
+    int certain_slot = -1;
+    if (short_rows) {
+        for (int s = NPAD - 1; s >= 0 && certain_slot < 0; --s)
+            if (var_of_slot[s] == -1) certain_slot = s;
+        if (certain_slot < 0) return LDPC_OK;
+        var_of_slot[certain_slot] = -2;
+    }
     for (int cc = 0; cc < c->m; ++cc) {
         const int R = chk_slot[cc] / 64, lane = chk_slot[cc] % 64;
         cn_active[R] |= 1ull << lane;
-        for (int k = c->row_ptr[cc]; k < c->row_ptr[cc + 1]; ++k)
+        unsigned used = 0;
+        for (int k = c->row_ptr[cc]; k < c->row_ptr[cc + 1]; ++k) {
             cn_addr[(size_t)(R * DC + edge_pos[k]) * 64 + lane] = (int64_t)var_slot[c->edge_var[k]] * 4;
+            used |= 1u << edge_pos[k];
+        }
+        for (int j = 0; j < DC; ++j)
+            if (!((used >> j) & 1u)) cn_addr[(size_t)(R * DC + j) * 64 + lane] = (int64_t)certain_slot * 4;
     }
     for (int v = 0; v < c->n; ++v) {
         const int Q = var_slot[v] / 64, lane = var_slot[v] % 64;
         // a real variable with fewer than DV edges sums the always-zero row for the missing ones (NW == 1 shapes only)
         if (p->zero_row)
-            for (int j = 0; j < DV; ++j) vn_addr[(size_t)(Q * DV + j) * 64 + lane] = c2v_base + (int64_t)(CR * DC * 64 + lane) * 4;
+            for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = c2v_base + (int64_t)(CR * DC * 64 + lane) * 4;
         for (int pidx = c->col_ptr[v]; pidx < c->col_ptr[v + 1]; ++pidx) {
             const int k = c->col_edge[pidx], cs = chk_slot[c->edge_chk[k]];
-            vn_addr[(size_t)(Q * DV + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(((cs / 64) * DC + edge_pos[k]) * 64 + cs % 64) * 4;
+            vn_addr[(size_t)(vr.first_gather(Q) + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(((cs / 64) * DC + edge_pos[k]) * 64 + cs % 64) * 4;
         }
+    }
+    if (certain_slot >= 0) {  // the certain slot sums nothing: every gather reads the zero row
+        const int Q = certain_slot / 64, lane = certain_slot % 64;
+        for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = c2v_base + (int64_t)(CR * DC * 64 + lane) * 4;
     }
     // padded lanes may read anything: let them repeat an address of their own half-wave (LDS broadcast, no extra cycle)
     auto fill_padding = [](std::vector<int64_t>& addr, int64_t fallback) {
@@ -751,8 +837,8 @@ int fused_plan_create(Decoder* d) {
     fill_padding(vn_addr, c2v_base);
     for (int K = 0; K < CR * DC; ++K)
         for (int lane = 0; lane < 64; ++lane) put16(cn_tab, CNW, CRW * DC, K, lane, (uint32_t)cn_addr[(size_t)K * 64 + lane]);
-    for (int K = 0; K < VR * DV; ++K)
-        for (int lane = 0; lane < 64; ++lane) put16(vn_tab, VNW, VRW * DV, K, lane, (uint32_t)vn_addr[(size_t)K * 64 + lane]);
+    for (int K = 0; K < vr.total_gathers(); ++K)
+        for (int lane = 0; lane < 64; ++lane) put16(vn_tab, VNW, VNK, K, lane, (uint32_t)vn_addr[(size_t)K * 64 + lane]);
     if (NW > 1) {
         // hand-off words: for each wave the c2v slot (position dc-1) of one of its padded check lanes, in its LAST round
         // that has one (so the wave's own garbage write to it precedes the verdict write in program order)

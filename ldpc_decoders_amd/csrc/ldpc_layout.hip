@@ -31,11 +31,18 @@ inline int bank_of_slot(int s) { return s & 31; }
 
 }  // namespace
 
-void identity_layout(const Code& c, int DC, int DV, FusedLayout* L) {
+void identity_layout(const Code& c, int DC, const VarRounds& vr, FusedLayout* L) {
     L->chk_slot.resize(c.m);
     L->var_slot.resize(c.n);
     std::iota(L->chk_slot.begin(), L->chk_slot.end(), 0);
-    std::iota(L->var_slot.begin(), L->var_slot.end(), 0);
+    // variables: those that need a wide round first into the wide slots, the others into the narrow slots in index order
+    // (spilling into left-over wide slots when the narrow ones are full)
+    const int wide_slots = vr.vrx * 64;
+    int next_wide = 0, next_narrow = wide_slots;
+    for (int v = 0; v < c.n; ++v)
+        if (c.col_ptr[v + 1] - c.col_ptr[v] > vr.DV) L->var_slot[v] = next_wide++;
+    for (int v = 0; v < c.n; ++v)
+        if (c.col_ptr[v + 1] - c.col_ptr[v] <= vr.DV) L->var_slot[v] = next_narrow < vr.VR * 64 ? next_narrow++ : next_wide++;
     L->edge_pos.assign(c.E, 0);
     L->var_pos.assign(c.E, 0);
     for (int cc = 0; cc < c.m; ++cc)
@@ -44,7 +51,7 @@ void identity_layout(const Code& c, int DC, int DV, FusedLayout* L) {
         for (int p = c.col_ptr[v]; p < c.col_ptr[v + 1]; ++p) L->var_pos[c.col_edge[p]] = p - c.col_ptr[v];
 }
 
-double layout_extra_cycles(const Code& c, int DC, int DV, int CR, int VR, const FusedLayout& L) {
+double layout_extra_cycles(const Code& c, int DC, int CR, const VarRounds& vr, const FusedLayout& L) {
     // address seen by lane `lane` of gather instruction (round, position); -1 == padded lane (free to broadcast)
     double extra = 0;
     auto group_cost = [](const int* addr32) {
@@ -61,7 +68,7 @@ double layout_extra_cycles(const Code& c, int DC, int DV, int CR, int VR, const 
         }
         return mx - 1;
     };
-    std::vector<int> cn((size_t)CR * DC * 64, -1), vn((size_t)VR * DV * 64, -1);
+    std::vector<int> cn((size_t)CR * DC * 64, -1), vn((size_t)vr.total_gathers() * 64, -1);
     for (int cc = 0; cc < c.m; ++cc)
         for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) {
             const int s = L.chk_slot[cc];
@@ -69,17 +76,18 @@ double layout_extra_cycles(const Code& c, int DC, int DV, int CR, int VR, const 
         }
     for (int k = 0; k < c.E; ++k) {
         const int vs = L.var_slot[c.edge_var[k]], cs = L.chk_slot[c.edge_chk[k]];
-        vn[(size_t)((vs / 64) * DV + L.var_pos[k]) * 64 + vs % 64] = ((cs / 64) * DC + L.edge_pos[k]) * 64 + cs % 64;
+        vn[(size_t)(vr.first_gather(vs / 64) + L.var_pos[k]) * 64 + vs % 64] = ((cs / 64) * DC + L.edge_pos[k]) * 64 + cs % 64;
     }
     for (size_t i = 0; i < cn.size(); i += 32) extra += group_cost(&cn[i]);
     for (size_t i = 0; i < vn.size(); i += 32) extra += group_cost(&vn[i]);
     return extra;
 }
 
-void plan_fused_layout(const Code& c, int DC, int DV, int CR, int VR, uint64_t seed, double budget_s, FusedLayout* L) {
-    identity_layout(c, DC, DV, L);
-    L->base_cycles = 2.0 * (CR * DC + VR * DV);
-    L->extra_cycles_identity = layout_extra_cycles(c, DC, DV, CR, VR, *L);
+void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint64_t seed, double budget_s, FusedLayout* L) {
+    identity_layout(c, DC, vr, L);
+    L->base_cycles = 2.0 * (CR * DC + vr.total_gathers());
+    L->extra_cycles_identity = layout_extra_cycles(c, DC, CR, vr, *L);
+    const int VR = vr.VR, DV = vr.DV, DVM = std::max(vr.DV, vr.dvx);
     const int NGC = 2 * CR, NGV = 2 * VR, m = c.m, n = c.n;
     const int64_t E = c.E;
     Rng rng(seed);
@@ -93,16 +101,18 @@ void plan_fused_layout(const Code& c, int DC, int DV, int CR, int VR, uint64_t s
         chk_at[(size_t)cgrp[cc] * 32 + cbank[cc]] = cc;
     }
     for (int v = 0; v < n; ++v) {
-        vgrp[v] = group_of_slot(v);
-        vbank[v] = bank_of_slot(v);
+        vgrp[v] = group_of_slot(L->var_slot[v]);
+        vbank[v] = bank_of_slot(L->var_slot[v]);
         var_at[(size_t)vgrp[v] * 32 + vbank[v]] = v;
     }
+    // placement constraint: a variable with more than DV edges only fits a slot of a wide round (group g = 2*round + half)
+    auto fits = [&](int v, int s) { return v < 0 || c.col_ptr[v + 1] - c.col_ptr[v] <= DV || (s / 32) / 2 < vr.vrx; };
     std::vector<int> edge_vj(E);  // canonical index of edge k in its variable's list
     for (int v = 0; v < n; ++v)
         for (int p = c.col_ptr[v]; p < c.col_ptr[v + 1]; ++p) edge_vj[c.col_edge[p]] = p - c.col_ptr[v];
     auto vpos = [&](int v, int j) { return (j < 2 && vflip[v] && (c.col_ptr[v + 1] - c.col_ptr[v]) >= 2) ? 1 - j : j; };
 
-    std::vector<int> cnA((size_t)NGC * 32, 0), cnB((size_t)NGV * DV * 32, 0);
+    std::vector<int> cnA((size_t)NGC * 32, 0), cnB((size_t)NGV * DVM * 32, 0);
     long cost = 0;
     auto addA = [&](int gc, int bv, int d) {
         int& x = cnA[(size_t)gc * 32 + bv];
@@ -111,7 +121,7 @@ void plan_fused_layout(const Code& c, int DC, int DV, int CR, int VR, uint64_t s
         cost += std::max(0, x - DC);
     };
     auto addB = [&](int gv, int pos, int bc, int d) {
-        int& x = cnB[((size_t)gv * DV + pos) * 32 + bc];
+        int& x = cnB[((size_t)gv * DVM + pos) * 32 + bc];
         cost -= std::max(0, x - 1);
         x += d;
         cost += std::max(0, x - 1);
@@ -178,7 +188,7 @@ void plan_fused_layout(const Code& c, int DC, int DV, int CR, int VR, uint64_t s
         int a = 0, b = 0;
         if (kind < 45) {
             a = rng.below(nvs); b = rng.below(nvs);
-            if (a == b || (var_at[a] < 0 && var_at[b] < 0)) continue;
+            if (a == b || (var_at[a] < 0 && var_at[b] < 0) || !fits(var_at[a], b) || !fits(var_at[b], a)) continue;
             swap_vars(a, b);
         } else if (kind < 85) {
             a = rng.below(ncs); b = rng.below(ncs);
@@ -276,10 +286,10 @@ void plan_fused_layout(const Code& c, int DC, int DV, int CR, int VR, uint64_t s
         }
         for (int k : edges) L->edge_pos[k] = colour_of[eidx(k)];
     }
-    L->extra_cycles_planned = layout_extra_cycles(c, DC, DV, CR, VR, *L);
+    L->extra_cycles_planned = layout_extra_cycles(c, DC, CR, vr, *L);
     if (L->extra_cycles_planned >= L->extra_cycles_identity) {  // never ship a layout worse than the trivial one
         const double id_cost = L->extra_cycles_identity;
-        identity_layout(c, DC, DV, L);
+        identity_layout(c, DC, vr, L);
         L->extra_cycles_planned = id_cost;
     }
 }

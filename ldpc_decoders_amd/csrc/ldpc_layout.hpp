@@ -34,10 +34,21 @@ struct FusedLayout {
     double base_cycles = 0;  // conflict-free LDS cycles of the gathers per sweep (one per half-wave instruction)
 };
 
-// exact conflict model: sum over gather instructions and half-waves of (max distinct-address multiplicity - 1)
-double layout_extra_cycles(const Code& c, int DC, int DV, int CR, int VR, const FusedLayout& L);
+// Variable rounds come in two widths: the first `vrx` rounds gather `dvx` messages per variable ("wide" rounds, for the
+// high-degree variables of irregular codes), the remaining VR - vrx rounds gather DV.  vrx = 0 for regular codes.
+struct VarRounds {
+    int VR = 0, DV = 0, vrx = 0, dvx = 0;
+    int width(int q) const { return q < vrx ? dvx : DV; }
+    int first_gather(int q) const { return q < vrx ? q * dvx : vrx * dvx + (q - vrx) * DV; }  // index of (q, position 0)
+    int total_gathers() const { return vrx * dvx + (VR - vrx) * DV; }
+};
 
-void identity_layout(const Code& c, int DC, int DV, FusedLayout* L);
-void plan_fused_layout(const Code& c, int DC, int DV, int CR, int VR, uint64_t seed, double budget_s, FusedLayout* L);
+// exact conflict model: sum over gather instructions and half-waves of (max distinct-address multiplicity - 1)
+double layout_extra_cycles(const Code& c, int DC, int CR, const VarRounds& vr, const FusedLayout& L);
+
+// trivial placement: checks in index order; variables in index order, except that variables with more than DV edges are
+// moved into the wide rounds (the only placement constraint)
+void identity_layout(const Code& c, int DC, const VarRounds& vr, FusedLayout* L);
+void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint64_t seed, double budget_s, FusedLayout* L);
 
 }  // namespace ldpc

@@ -27,11 +27,18 @@ int main(int argc, char** argv) {
     c.col_edge.assign(c.E, 0); std::vector<int> fill(c.col_ptr.begin(), c.col_ptr.end() - 1);
     for (int k = 0; k < c.E; ++k) c.col_edge[fill[c.edge_var[k]]++] = k;
     const int CR = atoi(argv[2]), VR = atoi(argv[3]);
-    FusedLayout L; plan_fused_layout(c, 6, 3, CR, VR, 0x1200, 0.3, &L);
+    VarRounds vr; vr.VR = VR; vr.DV = 3; vr.vrx = atoi(argv[4]); vr.dvx = vr.vrx ? 8 : 3;
+    FusedLayout L; plan_fused_layout(c, 6, CR, vr, 0x1200, 0.3, &L);
+    for (int v = 0; v < c.n; ++v)  // placement constraint: more than 3 edges only in the wide rounds
+        if (c.col_ptr[v + 1] - c.col_ptr[v] > 3 && L.var_slot[v] / 64 >= vr.vrx) return 5;
     // the plan must be a permutation of slots and of the positions inside every check
     std::vector<int> seen(CR * 64, 0); for (int s : L.chk_slot) { if (s < 0 || s >= CR * 64 || seen[s]++) return 2; }
     std::vector<int> seenv(VR * 64, 0); for (int s : L.var_slot) { if (s < 0 || s >= VR * 64 || seenv[s]++) return 3; }
-    for (int cc = 0; cc < c.m; ++cc) { int mask = 0; for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) mask |= 1 << L.edge_pos[k]; if (mask != 63) return 4; }
+    for (int cc = 0; cc < c.m; ++cc) {
+        int mask = 0, cnt = 0;
+        for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) { if (L.edge_pos[k] < 0 || L.edge_pos[k] > 5 || (mask >> L.edge_pos[k]) & 1) return 4; mask |= 1 << L.edge_pos[k]; ++cnt; }
+        if (cnt == 6 && mask != 63) return 4;
+    }
     printf("%.0f %.0f %.0f\n", L.base_cycles, L.extra_cycles_identity, L.extra_cycles_planned);
     return 0;
 }
@@ -39,8 +46,9 @@ int main(int argc, char** argv) {
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("cr,vr", [(10, 19), (10, 20)])
-def test_layout_planner_under_asan(tmp_path, cr, vr):
+@pytest.mark.parametrize("code_name,cr,vr,vrx", [("1200_3_6_rand_ldpc_1", 10, 19, 0), ("1200_3_6_rand_ldpc_1", 10, 20, 0),
+                                                   ("1200_rho_x5_rand_ldpc_5", 10, 19, 4)])
+def test_layout_planner_under_asan(tmp_path, code_name, cr, vr, vrx):
     cxx = shutil.which("g++")
     if cxx is None:
         pytest.skip("no host C++ compiler")
@@ -53,10 +61,12 @@ def test_layout_planner_under_asan(tmp_path, cr, vr):
            "--offload-arch=gfx950", "--cuda-host-only", str(src), os.path.join(CSRC, "ldpc_layout.hip"), "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        if "error:" in r.stderr and "ldpc_" in r.stderr:
+            pytest.fail("planner harness does not compile: " + r.stderr[-1500:])
         pytest.skip("sanitized host build unavailable here: " + r.stderr[-300:])
-    code_file = os.path.join(ROOT, "tests", "golden", "codes", "1200_3_6_rand_ldpc_1.txt")
+    code_file = os.path.join(ROOT, "tests", "golden", "codes", code_name + ".txt")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
-    out = subprocess.run([exe, code_file, str(cr), str(vr)], capture_output=True, text=True, env=env, timeout=300)
+    out = subprocess.run([exe, code_file, str(cr), str(vr), str(vrx)], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     base, ident, planned = (float(v) for v in out.stdout.split())
-    assert base == 2.0 * (cr * 6 + vr * 3) and planned < 0.5 * ident
+    assert base == 2.0 * (cr * 6 + vrx * 8 + (vr - vrx) * 3) and planned < 0.6 * ident
