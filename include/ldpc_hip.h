@@ -33,6 +33,7 @@ enum { LDPC_ALG_MSA = 0, LDPC_ALG_SPA = 1, LDPC_ALG_BEC = 2 };      /* decoder s
 enum { LDPC_DTYPE_F32 = 0, LDPC_DTYPE_F64 = 1 };                     /* message arithmetic                             */
 enum { LDPC_BACKEND_AUTO = 0, LDPC_BACKEND_STREAM = 1, LDPC_BACKEND_FUSED = 2 };
 enum { LDPC_CH_BIAWGN = 0, LDPC_CH_BSC = 1, LDPC_CH_BEC = 2 };       /* channel selector: src/models.py:3               */
+enum { LDPC_CH_RAW_OBSERVATION = 0x100 };  /* or-ed into LDPC_CH_BIAWGN for ldpc_channel: write y itself, not -2y/sigma^2 */
 enum { LDPC_FLAG_NO_EARLY_EXIT = 1 };                                /* NOT reference behaviour: run exactly max_iter   */
 enum { LDPC_E_ARG = -1, LDPC_E_HIP = -2, LDPC_E_GRAPH = -3, LDPC_E_UNSUPPORTED = -4, LDPC_E_NOMEM = -5 };
 
@@ -91,7 +92,8 @@ int ldpc_decode_host(ldpc_decoder_t dec, const void* priors, const uint8_t* y0, 
 /* Channel.send + LLR for frames [frame0, frame0+B) of the all-`codeword` word, Philox4x32-10 keyed by
  * (seed, stream_id, global frame index) -- biawgn.Channel.send/LLR.decode (src/biawgn.py:13-28),
  * bsc (src/bsc.py:11-25), bec.Channel.send (src/bec.py:11-18).  priors_dev [B,n] (`dtype`; NULL for BEC),
- * y_dev [B,n] uint8 (BSC: received bits, BEC: symbols; may be NULL for BI-AWGN). */
+ * y_dev [B,n] uint8 (BSC: received bits, BEC: symbols; may be NULL for BI-AWGN).  priors_dev may be NULL for the BSC.
+ * LDPC_CH_BIAWGN | LDPC_CH_RAW_OBSERVATION writes the received values y into priors_dev instead of their LLRs. */
 int ldpc_channel(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0,
                  int64_t B, int32_t n, void* priors_dev, uint8_t* y_dev, void* stream);
 
@@ -100,6 +102,29 @@ int ldpc_channel(int channel, int dtype, double param, int codeword, uint64_t se
  * `sent_dev` is the transmitted word [n] or NULL for the all-`codeword` word; iters_dev may be NULL. */
 int ldpc_count_errors(const uint8_t* xhat_dev, const uint8_t* sent_dev, int codeword, const int32_t* iters_dev, int64_t B,
                       int32_t n, int32_t hist_bins, int64_t* counters_dev, void* stream);
+
+/* ---- Maximum-likelihood decoding of the short codes by codebook search -----------------------------------------
+ * Replaces biawgn.ML (src/biawgn.py:66-78), bsc.ML (src/bsc.py:63-75) and bec.ML (src/bec.py:21-36).  `codebook` is
+ * Code.cb (src/codes.py:11-14): [K, n] bytes in {0,1}, host pointer, K <= 2^20 words of n <= 64 bits. */
+typedef struct ldpc_ml_s* ldpc_ml_t;
+int ldpc_ml_create(int device, const uint8_t* codebook, int64_t K, int32_t n, ldpc_ml_t* out);
+int ldpc_ml_destroy(ldpc_ml_t ml);
+/* ML.decode for B frames.  y_dev: [B,n] observations -- double or float per `dtype` for LDPC_CH_BIAWGN, uint8 symbols
+ * ({0,1}, 2 = erased) for LDPC_CH_BSC / LDPC_CH_BEC.  coef2 (host) holds the constants the upstream constructor
+ * computes: {2*noise_var, unused} for BI-AWGN, {log p, log(1-p)} for BSC / BEC.  The log-likelihood of every
+ * codeword is evaluated in fp64 in the upstream operation order (including numpy's summation order), so its maximum
+ * (best_dev, [B] double) and the set of maximisers (ties_dev [B] = how many; tie_mask_dev [B, ceil(K/32)] uint32,
+ * bit k of word k/32 = codeword k attains the maximum) are bit-identical to upstream's.  The pick among the
+ * maximisers (math_utils.arg_max_rand, src/math_utils.py:72-74) is maximiser number floor(pick[f] * ties / 2^32) in
+ * codebook order, the first one if pick_dev is NULL; index_dev [B] int32 and xhat_dev [B,n] uint8 receive it.  Every
+ * output pointer may be NULL. */
+int ldpc_ml_decode(ldpc_ml_t ml, int channel, int dtype, const double* coef2, const void* y_dev, int64_t B,
+                   const uint32_t* pick_dev, int32_t* index_dev, int32_t* ties_dev, uint32_t* tie_mask_dev, double* best_dev,
+                   uint8_t* xhat_dev, void* stream);
+/* Channel.send + ML.decode + the counters of main.test for frames [frame0, frame0+B) of the all-`codeword` word; same
+ * Philox keying as ldpc_channel, the tie-break word is block 0xFFFFFFFF of the frame.  Accumulates tot/wec/bec. */
+int ldpc_ml_simulate(ldpc_ml_t ml, int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id,
+                     uint64_t frame0, int64_t B, int64_t* counters_dev, void* stream);
 
 /* Profiling aid: coalesced 4-byte-per-lane device copy of a known size, used to calibrate the profiler's HBM byte
  * counters for the access width of the streaming kernels. */

@@ -175,3 +175,61 @@ class DecoderHandle:
         b, s = ctypes.c_int(0), ctypes.c_int(0)
         _lib.check(_lib.load().ldpc_decoder_last_stats(self.h, ctypes.byref(b), ctypes.byref(s)))
         return _lib.BACKEND_NAME.get(b.value, "?"), s.value
+
+
+class MlHandle:
+    """Codebook of a short code resident in HBM + the exhaustive-search kernels (``ldpc_ml_*``)."""
+
+    def __init__(self, codebook, channel, precision="f64", device=None):
+        lib = _lib.load()
+        self.cb = np.ascontiguousarray(codebook, dtype=np.uint8)
+        self.K, self.n = self.cb.shape
+        self.W = (self.K + 31) // 32
+        self.channel, self.precision = channel, precision
+        self.device = current_device() if device is None else device
+        h = ctypes.c_void_p()
+        _lib.check(lib.ldpc_ml_create(self.device, self.cb.ctypes.data, self.K, self.n, ctypes.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.load().ldpc_ml_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def obs_dtype(self):
+        import torch
+
+        if self.channel != "biawgn":
+            return torch.uint8
+        return torch.float64 if self.precision == "f64" else torch.float32
+
+    def decode_device(self, y, coef, pick=None, want_mask=True):
+        """y: contiguous CUDA tensor [B,n] (observations / symbols) -> dict of CUDA tensors: index, ties, best, xhat[, tie_mask]."""
+        import torch
+
+        if not y.is_cuda or not y.is_contiguous() or y.dtype != self.obs_dtype() or y.shape[1] != self.n:
+            raise ValueError("y must be a contiguous CUDA tensor [B,%d] of dtype %s" % (self.n, self.obs_dtype()))
+        B = y.shape[0]
+        out = dict(index=torch.empty(B, dtype=torch.int32, device=y.device), ties=torch.empty(B, dtype=torch.int32, device=y.device),
+                   best=torch.empty(B, dtype=torch.float64, device=y.device),
+                   xhat=torch.empty((B, self.n), dtype=torch.uint8, device=y.device))
+        if want_mask:
+            out["tie_mask"] = torch.empty((B, self.W), dtype=torch.int32, device=y.device)
+        c2 = (ctypes.c_double * 2)(float(coef[0]), float(coef[1]))
+        st = torch.cuda.current_stream(y.device).cuda_stream
+        _lib.check(_lib.load().ldpc_ml_decode(self.h, _lib.CHANNEL[self.channel], _lib.DTYPE[self.precision], c2, y.data_ptr(), B,
+                                              None if pick is None else pick.data_ptr(), out["index"].data_ptr(),
+                                              out["ties"].data_ptr(), out["tie_mask"].data_ptr() if want_mask else None,
+                                              out["best"].data_ptr(), out["xhat"].data_ptr(), st))
+        return out
+
+    def simulate(self, channel, param, codeword, seed, stream_id, frame0, B, max_iter, counters, flags=0, hist_bins=0):
+        """Same call shape as DecoderHandle.simulate (max_iter / flags / hist_bins have no meaning here)."""
+        import torch
+
+        st = torch.cuda.current_stream(counters.device).cuda_stream
+        _lib.check(_lib.load().ldpc_ml_simulate(self.h, _lib.CHANNEL[channel], _lib.DTYPE[self.precision], float(param), int(codeword),
+                                                int(seed), int(stream_id), int(frame0), int(B), counters.data_ptr(), st))

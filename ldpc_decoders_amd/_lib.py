@@ -15,6 +15,7 @@ DTYPE = {"f32": 0, "f64": 1}
 BACKEND = {"auto": 0, "stream": 1, "fused": 2}
 BACKEND_NAME = {v: k for k, v in BACKEND.items()}
 CHANNEL = {"biawgn": 0, "bsc": 1, "bec": 2}
+CH_RAW_OBSERVATION = 0x100
 FLAG_NO_EARLY_EXIT = 1
 CNT_TOT, CNT_WEC, CNT_BEC, CNT_ITER_SUM, CNT_HIST0 = 0, 1, 2, 3, 4
 
@@ -43,6 +44,11 @@ SIGNATURES = {
     "ldpc_debug_copy4": (_c.c_int, [_P, _P, _c.c_int64, _P]),
     "ldpc_simulate": (_c.c_int, [_P, _c.c_int, _c.c_double, _c.c_int, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_int64,
                                  _c.c_int32, _c.c_uint32, _c.c_int32, _P, _P]),
+    "ldpc_ml_create": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int32, _c.POINTER(_P)]),
+    "ldpc_ml_destroy": (_c.c_int, [_P]),
+    "ldpc_ml_decode": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _P, _c.c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "ldpc_ml_simulate": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_uint64, _c.c_uint64, _c.c_uint64,
+                                    _c.c_int64, _P, _P]),
 }
 
 _lib = None

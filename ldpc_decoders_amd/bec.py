@@ -48,3 +48,6 @@ class SPA:
 
 class MSA(SPA):
     pass
+
+
+from .ml import BecML as ML  # noqa: E402  (src/bec.py: class ML)

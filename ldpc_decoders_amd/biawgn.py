@@ -45,3 +45,6 @@ class MSA(LLR):
 
     def __init__(self, snr_in_db, _code, **kwargs):
         super().__init__(snr_in_db, bpa.MSA(_code, **kwargs))
+
+
+from .ml import BiawgnML as ML  # noqa: E402  (src/biawgn.py: class ML)

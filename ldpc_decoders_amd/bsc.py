@@ -47,3 +47,6 @@ class MSA(LLR):
 
     def __init__(self, p, _code, **kwargs):
         super().__init__(p, bpa.MSA(_code, **kwargs))
+
+
+from .ml import BscML as ML  # noqa: E402  (src/bsc.py: class ML)

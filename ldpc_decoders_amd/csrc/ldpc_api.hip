@@ -401,4 +401,37 @@ int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uin
     return LDPC_OK;
 }
 
+// ---- maximum-likelihood decoder (ldpc_ml.hip) ----
+int ldpc_ml_create(int device, const uint8_t* codebook, int64_t K, int32_t n, ldpc_ml_t* out) {
+    MlDecoder* d = nullptr;
+    LDPC_TRY(ml_create(device, codebook, K, n, &d));
+    *out = (ldpc_ml_t)d;
+    return LDPC_OK;
+}
+
+int ldpc_ml_destroy(ldpc_ml_t h) {
+    ml_destroy((MlDecoder*)h);
+    return LDPC_OK;
+}
+
+int ldpc_ml_decode(ldpc_ml_t h, int channel, int dtype, const double* coef2, const void* y_dev, int64_t B,
+                   const uint32_t* pick_dev, int32_t* index_dev, int32_t* ties_dev, uint32_t* tie_mask_dev, double* best_dev,
+                   uint8_t* xhat_dev, void* stream) {
+    if (!h || !coef2 || !y_dev || B < 0 || dtype < 0 || dtype > 1) {
+        set_error("ldpc_ml_decode: bad arguments");
+        return LDPC_E_ARG;
+    }
+    return ml_decode((MlDecoder*)h, channel, dtype, coef2, y_dev, B, pick_dev, index_dev, ties_dev, tie_mask_dev, best_dev, xhat_dev,
+                     (hipStream_t)stream);
+}
+
+int ldpc_ml_simulate(ldpc_ml_t h, int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id,
+                     uint64_t frame0, int64_t B, int64_t* counters_dev, void* stream) {
+    if (!h || !counters_dev || B < 0 || dtype < 0 || dtype > 1 || (codeword != 0 && codeword != 1)) {
+        set_error("ldpc_ml_simulate: bad arguments");
+        return LDPC_E_ARG;
+    }
+    return ml_simulate((MlDecoder*)h, channel, dtype, param, codeword, seed, stream_id, frame0, B, counters_dev, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -138,6 +138,12 @@ int channel_generate(int channel, int dtype, double param, int codeword, uint64_
         set_error("device channel kernels send the all-zero (0) or all-one (1) word; got codeword=%d", codeword);
         return LDPC_E_ARG;
     }
+    const bool raw = (channel & CH_RAW_OBSERVATION) != 0;
+    channel &= ~CH_RAW_OBSERVATION;
+    if (raw && channel != CH_BIAWGN) {
+        set_error("the raw-observation flag applies to the BI-AWGN channel only");
+        return LDPC_E_ARG;
+    }
     const int bpf = (n + 3) / 4;
     const int64_t threads = B * bpf;
     const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
@@ -147,7 +153,7 @@ int channel_generate(int channel, int dtype, double param, int codeword, uint64_
             return LDPC_E_ARG;
         }
         const double var = pow(10.0, -param / 10.0);  // src/biawgn.py:10
-        const double sigma = sqrt(var), k = 2.0 / var;
+        const double sigma = sqrt(var), k = raw ? -1.0 : 2.0 / var;  // the kernel writes -(k*y): k = -1 hands over y itself
         if (dtype == DT_F64)
             hipLaunchKernelGGL(k_biawgn<double>, grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors);
         else

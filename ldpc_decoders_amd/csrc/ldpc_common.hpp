@@ -26,6 +26,7 @@ enum Alg : int { ALG_MSA = 0, ALG_SPA = 1, ALG_BEC = 2 };
 enum DType : int { DT_F32 = 0, DT_F64 = 1 };
 enum Backend : int { BK_AUTO = 0, BK_STREAM = 1, BK_FUSED = 2 };
 enum Channel : int { CH_BIAWGN = 0, CH_BSC = 1, CH_BEC = 2 };
+constexpr int CH_RAW_OBSERVATION = 0x100;  // or-ed into the channel id: BI-AWGN writes y itself instead of the LLR -2y/sigma^2
 
 constexpr int TILE = 64;  // frames per tile == wavefront width on gfx950
 
@@ -123,6 +124,16 @@ int channel_generate(int channel, int dtype, double param, int codeword, uint64_
                      uint64_t frame0, int64_t B, int32_t n, void* priors, uint8_t* y, hipStream_t st);
 int count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const int32_t* iters, int64_t B, int32_t n,
                  int32_t max_iter_hist, int64_t* counters, hipStream_t st);
+
+// ---- maximum-likelihood decoder of the short codes (ldpc_ml.hip) ------------------------------------
+struct MlDecoder;
+int ml_create(int device, const uint8_t* codebook, int64_t K, int32_t n, MlDecoder** out);
+void ml_destroy(MlDecoder* d);
+void ml_info(const MlDecoder* d, int64_t* K, int32_t* n, int32_t* W);
+int ml_decode(MlDecoder* d, int channel, int dtype, const double* coef, const void* y, int64_t B, const uint32_t* pick,
+              int32_t* index, int32_t* ties, uint32_t* tie_mask, double* best, uint8_t* xhat, hipStream_t st);
+int ml_simulate(MlDecoder* d, int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id,
+                uint64_t frame0, int64_t B, int64_t* counters, hipStream_t st);
 
 int debug_copy4(const void* src, void* dst, int64_t nbytes, hipStream_t st);
 

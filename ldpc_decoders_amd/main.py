@@ -65,10 +65,13 @@ def test(args, comm=None):
                 x = code.cb[0]
             else:
                 x = np.zeros(code_n, dtype=np.int64) + args.codeword
-            c = run_point_exact(channel, decoder, x, args.min_wec, chunk=1 if code_n < 64 else 32, on_progress=progress,
+            # one frame per call keeps numpy's stream in the reference's order (send, [ML pick], send, ..)
+            c = run_point_exact(channel, decoder, x, args.min_wec, chunk=1 if (code_n < 64 or args.decoder == "ML") else 32, on_progress=progress,
                                 pick_word=pick)
         else:
             handle = decoder.handle if hasattr(decoder, "handle") else decoder.dec.handle
+            if args.codeword not in (0, 1):
+                raise SystemExit("the device channel sends the all-zero or all-one word; use --exact for other --codeword values")
             sim = DeviceSimulator(handle, args.channel, args.max_iter, args.codeword, args.seed, comm)
             c = sim.run_point(param, stream_id=pi, min_wec=args.min_wec, batch_per_rank=args.batch, on_progress=progress)
         results[param] = log_status(c, final=True)
