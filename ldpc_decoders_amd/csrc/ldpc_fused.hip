@@ -21,8 +21,11 @@
 //
 // Arithmetic identical to the streaming backend / reference (src/bpa.py:17-63, 86-102): the leave-one-out minimum
 // equals "second minimum at the first arg-min, first minimum elsewhere"; min/compare/negate/add/sub only.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <numeric>
 #include <type_traits>
 
@@ -49,6 +52,7 @@ struct FusedPlan {
     size_t lds_bytes = 0;
     int groups_per_cu = 0, num_cu = 0;
     double extra_identity = 0, extra_planned = 0, base_cycles = 0;
+    bool plan_from_store = false;      // layout read from a stored plan file instead of annealed now
 };
 
 namespace {
@@ -674,6 +678,30 @@ constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
 }  // namespace
 
+// directories searched for stored layout plans: $LDPC_FUSED_PLAN_DIR (colon-separated), then <package>/plans next to csrc/
+static std::vector<std::string> plan_dirs() {
+    std::vector<std::string> dirs;
+    if (const char* e = std::getenv("LDPC_FUSED_PLAN_DIR")) {
+        std::string s(e);
+        size_t a = 0;
+        while (a <= s.size()) {
+            const size_t b = s.find(':', a);
+            const std::string d = s.substr(a, b == std::string::npos ? std::string::npos : b - a);
+            if (!d.empty()) dirs.push_back(d);
+            if (b == std::string::npos) break;
+            a = b + 1;
+        }
+    }
+    Dl_info info;
+    if (dladdr((const void*)&plan_dirs, &info) && info.dli_fname) {
+        std::string lib(info.dli_fname);
+        const size_t slash = lib.rfind('/');
+        const std::string here = slash == std::string::npos ? std::string(".") : lib.substr(0, slash);
+        dirs.push_back(here + "/../plans");
+    }
+    return dirs;
+}
+
 bool fused_supported(const Decoder* d) { return d->fused && d->fused->ok; }
 
 int fused_info(const Decoder* d, double* out8) {
@@ -729,7 +757,6 @@ int fused_plan_create(Decoder* d) {
     // ---- layout: check c -> slot (R, lane), variable v -> slot, edge positions (ldpc_layout.hpp)
     FusedLayout L;
     const char* mode = std::getenv("LDPC_FUSED_LAYOUT");
-    const char* ms = std::getenv("LDPC_FUSED_PLAN_MS");
     if (mode && std::string(mode) == "identity") {
         identity_layout(*c, DC, vr, &L);
         if (NW > 1) {  // spread the checks / variables evenly over the waves so that every wave keeps padded slots
@@ -739,7 +766,24 @@ int fused_plan_create(Decoder* d) {
         L.base_cycles = 2.0 * (CR * DC + vr.total_gathers());
         L.extra_cycles_identity = L.extra_cycles_planned = layout_extra_cycles(*c, DC, CR, vr, L);
     } else {
-        plan_fused_layout(*c, DC, CR, vr, 0x1200u, ms ? atof(ms) * 1e-3 : 0.6, &L);
+        // stored plan (a long annealing run done once, ldpc_layout.hpp "plan store") or a short run now
+        const uint64_t key = layout_key(*c, DC, CR, vr, NW);
+        char name[40];
+        snprintf(name, sizeof(name), "%016llx.plan", (unsigned long long)key);
+        bool loaded = false;
+        const bool use_store = !(mode && std::string(mode) == "replan");
+        for (const std::string& dir : plan_dirs()) {
+            if (!use_store || loaded) break;
+            loaded = layout_load(dir + "/" + name, key, *c, DC, CR, vr, &L);
+        }
+        if (!loaded) {
+            long moves = kDefaultPlanMoves;
+            if (const char* e = std::getenv("LDPC_FUSED_PLAN_MOVES")) moves = atol(e);
+            else if (const char* ms = std::getenv("LDPC_FUSED_PLAN_MS")) moves = (long)(atof(ms) * 4000.0);
+            plan_fused_layout(*c, DC, CR, vr, 0x1200u, moves, &L);
+            if (const char* out = std::getenv("LDPC_FUSED_PLAN_SAVE")) (void)layout_save(std::string(out) + "/" + name, key, *c, L);
+        }
+        p->plan_from_store = loaded;
     }
     p->extra_identity = L.extra_cycles_identity;
     p->extra_planned = L.extra_cycles_planned;

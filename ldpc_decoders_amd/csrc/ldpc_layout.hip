@@ -83,7 +83,7 @@ double layout_extra_cycles(const Code& c, int DC, int CR, const VarRounds& vr, c
     return extra;
 }
 
-void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint64_t seed, double budget_s, FusedLayout* L) {
+void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint64_t seed, long moves, FusedLayout* L) {
     identity_layout(c, DC, vr, L);
     L->base_cycles = 2.0 * (CR * DC + vr.total_gathers());
     L->extra_cycles_identity = layout_extra_cycles(c, DC, CR, vr, *L);
@@ -169,6 +169,8 @@ void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint6
     };
 
     // ---- annealing
+    // the schedule is a function of the move count only, so a plan depends on (code, shape, seed, moves) and not on the
+    // machine it was computed on
     const auto t_start = std::chrono::steady_clock::now();
     auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     const int nvs = NGV * 32, ncs = NGC * 32;
@@ -176,13 +178,9 @@ void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint6
     const double T_end = 0.08;
     long best = cost;
     std::vector<int> b_cgrp = cgrp, b_cbank = cbank, b_vgrp = vgrp, b_vbank = vbank, b_vflip = vflip;
-    const long max_moves = 60000000;
+    const long max_moves = moves < 1 ? 1 : moves;
     for (long it = 0; it < max_moves && best > 0; ++it) {
-        if ((it & 4095) == 0) {
-            const double el = elapsed();
-            if (el > budget_s) break;
-            T = 1.5 * std::pow(T_end / 1.5, el / budget_s);
-        }
+        if ((it & 4095) == 0) T = 1.5 * std::pow(T_end / 1.5, (double)it / (double)max_moves);
         const long before = cost;
         const int kind = rng.below(100);
         int a = 0, b = 0;
@@ -292,6 +290,95 @@ void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint6
         identity_layout(c, DC, vr, L);
         L->extra_cycles_planned = id_cost;
     }
+}
+
+// ---- plan store ---------------------------------------------------------------------------------------------------
+namespace {
+constexpr uint64_t kPlanMagic = 0x314e4c5043504c44ull;  // "DLPCPLN1"
+constexpr uint32_t kPlannerVersion = 1;                 // bump when slot numbering / position semantics change
+inline uint64_t fnv(uint64_t h, const void* p, size_t nbytes) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < nbytes; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+    return h;
+}
+}  // namespace
+
+uint64_t layout_key(const Code& c, int DC, int CR, const VarRounds& vr, int NW) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    const int32_t hdr[10] = {(int32_t)kPlannerVersion, c.m, c.n, DC, CR, vr.VR, vr.DV, vr.vrx, vr.dvx, NW};
+    h = fnv(h, hdr, sizeof(hdr));
+    h = fnv(h, c.edge_chk.data(), c.edge_chk.size() * sizeof(int32_t));
+    h = fnv(h, c.edge_var.data(), c.edge_var.size() * sizeof(int32_t));
+    return h;
+}
+
+bool layout_valid(const Code& c, int DC, int CR, const VarRounds& vr, const FusedLayout& L) {
+    const size_t E = (size_t)c.E;
+    if (L.chk_slot.size() != (size_t)c.m || L.var_slot.size() != (size_t)c.n || L.edge_pos.size() != E || L.var_pos.size() != E) return false;
+    std::vector<char> seen_c((size_t)CR * 64, 0), seen_v((size_t)vr.VR * 64, 0);
+    for (int s : L.chk_slot) {
+        if (s < 0 || s >= CR * 64 || seen_c[s]++) return false;
+    }
+    for (int v = 0; v < c.n; ++v) {
+        const int s = L.var_slot[v];
+        if (s < 0 || s >= vr.VR * 64 || seen_v[s]++) return false;
+        if (c.col_ptr[v + 1] - c.col_ptr[v] > vr.width(s / 64)) return false;
+    }
+    for (int cc = 0; cc < c.m; ++cc) {  // positions inside a check: distinct, below DC
+        unsigned mask = 0;
+        for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) {
+            const int p = L.edge_pos[k];
+            if (p < 0 || p >= DC || ((mask >> p) & 1u)) return false;
+            mask |= 1u << p;
+        }
+    }
+    for (int v = 0; v < c.n; ++v) {  // positions inside a variable: a permutation of 0..deg-1 that only swaps the first two
+        const int deg = c.col_ptr[v + 1] - c.col_ptr[v];
+        for (int j = 0; j < deg; ++j) {
+            const int p = L.var_pos[c.col_edge[c.col_ptr[v] + j]];
+            const bool ok = (j >= 2) ? (p == j) : (deg >= 2 ? (p == j || p == 1 - j) : p == j);
+            if (!ok) return false;
+        }
+        if (deg >= 2 && L.var_pos[c.col_edge[c.col_ptr[v]]] == L.var_pos[c.col_edge[c.col_ptr[v] + 1]]) return false;
+    }
+    return true;
+}
+
+bool layout_save(const std::string& path, uint64_t key, const Code& c, const FusedLayout& L) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const uint64_t hdr[3] = {kPlanMagic, key, (uint64_t)c.E};
+    const int32_t dims[2] = {c.m, c.n};
+    const double info[3] = {L.base_cycles, L.extra_cycles_identity, L.extra_cycles_planned};
+    bool ok = fwrite(hdr, sizeof(hdr), 1, f) == 1 && fwrite(dims, sizeof(dims), 1, f) == 1 && fwrite(info, sizeof(info), 1, f) == 1;
+    auto put = [&](const std::vector<int>& v) { ok = ok && (v.empty() || fwrite(v.data(), sizeof(int), v.size(), f) == v.size()); };
+    put(L.chk_slot); put(L.var_slot); put(L.edge_pos); put(L.var_pos);
+    ok = (fclose(f) == 0) && ok;
+    return ok;
+}
+
+bool layout_load(const std::string& path, uint64_t key, const Code& c, int DC, int CR, const VarRounds& vr, FusedLayout* L) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint64_t hdr[3];
+    int32_t dims[2];
+    double info[3];
+    FusedLayout T;
+    bool ok = fread(hdr, sizeof(hdr), 1, f) == 1 && fread(dims, sizeof(dims), 1, f) == 1 && fread(info, sizeof(info), 1, f) == 1;
+    ok = ok && hdr[0] == kPlanMagic && hdr[1] == key && hdr[2] == (uint64_t)c.E && dims[0] == c.m && dims[1] == c.n;
+    auto get = [&](std::vector<int>& v, size_t cnt) {
+        if (!ok) return;
+        v.resize(cnt);
+        ok = cnt == 0 || fread(v.data(), sizeof(int), cnt, f) == cnt;
+    };
+    get(T.chk_slot, (size_t)c.m); get(T.var_slot, (size_t)c.n); get(T.edge_pos, (size_t)c.E); get(T.var_pos, (size_t)c.E);
+    fclose(f);
+    if (!ok || !layout_valid(c, DC, CR, vr, T)) return false;
+    T.base_cycles = 2.0 * (CR * DC + vr.total_gathers());
+    T.extra_cycles_identity = info[1];
+    T.extra_cycles_planned = layout_extra_cycles(c, DC, CR, vr, T);  // recomputed, never trusted
+    *L = T;
+    return true;
 }
 
 }  // namespace ldpc

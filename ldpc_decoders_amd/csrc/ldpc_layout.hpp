@@ -18,6 +18,7 @@
 // slots / two check slots / flip a variable's first two positions), then edge-colours every check group.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "ldpc_common.hpp"
@@ -49,6 +50,18 @@ double layout_extra_cycles(const Code& c, int DC, int CR, const VarRounds& vr, c
 // trivial placement: checks in index order; variables in index order, except that variables with more than DV edges are
 // moved into the wide rounds (the only placement constraint)
 void identity_layout(const Code& c, int DC, const VarRounds& vr, FusedLayout* L);
-void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint64_t seed, double budget_s, FusedLayout* L);
+// `moves` = annealing steps (about 4 M per second on one host core); the result is a deterministic function of the arguments
+constexpr long kDefaultPlanMoves = 2500000;
+void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint64_t seed, long moves, FusedLayout* L);
+
+
+// ---- plan store ---------------------------------------------------------------------------------------------------
+// A plan is a pure function of (H, shape, planner version), so long annealing runs can be done once and kept: files
+// <key>.plan, looked up in $LDPC_FUSED_PLAN_DIR (colon-separated) and then in the `plans` directory next to the package's
+// csrc/ (tools/plan_codes.py writes them).  A file that does not validate against the code is ignored.
+uint64_t layout_key(const Code& c, int DC, int CR, const VarRounds& vr, int NW);
+bool layout_valid(const Code& c, int DC, int CR, const VarRounds& vr, const FusedLayout& L);
+bool layout_load(const std::string& path, uint64_t key, const Code& c, int DC, int CR, const VarRounds& vr, FusedLayout* L);
+bool layout_save(const std::string& path, uint64_t key, const Code& c, const FusedLayout& L);
 
 }  // namespace ldpc

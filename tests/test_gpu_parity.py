@@ -3,6 +3,8 @@
 Bars: min-sum (fp64, and fp32 on exactly representable priors) and the erasure decoder are BIT-EXACT in hard decisions
 and iteration counts; sum-product is held to a stated tolerance (libm / fp32 rounding differs from numpy's).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -293,3 +295,34 @@ def test_fused_erasure_decoder_variants(nw, monkeypatch):
         c = cnt.cpu().numpy()
         assert (c[0], c[1], c[2], c[3]) == (1500, (err > 0).sum(), err.sum(), io.sum())
         assert (c[4:] == np.bincount(np.minimum(io, 50), minlength=51)).all()
+
+
+def test_layout_plan_store(monkeypatch, tmp_path):
+    # the LDS placement only moves data around: shipped plan (ldpc_decoders_amd/plans), a plan annealed now, a plan saved and
+    # read back, and the trivial placement all give the same bits as the oracle
+    from ldpc_decoders_amd import bpa
+
+    g, code = _code("1200_3_6_rand_ldpc_1")
+    rng = np.random.RandomState(5)
+    y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(1.8)), (200, g.n))
+    pri = O.biawgn_priors(y, 1.8).astype(np.float32)
+    xo, io = C.bp_decode(g, "MSA", None, pri, 50, dtype=np.float32)
+
+    def run():
+        dec = bpa.MSA(code, max_iter=50, precision="f32", backend="fused")
+        xhat, iters = dec.decode_batch(None, pri)
+        assert (xhat == xo).all() and (iters == io).all()
+        return dec.handle.fused_info()["conflict_cycles_planned"]
+
+    shipped = run()
+    monkeypatch.setenv("LDPC_FUSED_LAYOUT", "replan")
+    monkeypatch.setenv("LDPC_FUSED_PLAN_MOVES", "400000")
+    monkeypatch.setenv("LDPC_FUSED_PLAN_SAVE", str(tmp_path))
+    fresh = run()
+    assert len(os.listdir(str(tmp_path))) == 1 and shipped < 60 < fresh < 400
+    monkeypatch.delenv("LDPC_FUSED_LAYOUT")
+    monkeypatch.delenv("LDPC_FUSED_PLAN_SAVE")
+    monkeypatch.setenv("LDPC_FUSED_PLAN_DIR", str(tmp_path))  # searched before the package's own plans
+    assert run() == fresh
+    monkeypatch.setenv("LDPC_FUSED_LAYOUT", "identity")
+    assert run() > 400

@@ -28,7 +28,25 @@ int main(int argc, char** argv) {
     for (int k = 0; k < c.E; ++k) c.col_edge[fill[c.edge_var[k]]++] = k;
     const int CR = atoi(argv[2]), VR = atoi(argv[3]);
     VarRounds vr; vr.VR = VR; vr.DV = 3; vr.vrx = atoi(argv[4]); vr.dvx = vr.vrx ? 8 : 3;
-    FusedLayout L; plan_fused_layout(c, 6, CR, vr, 0x1200, 0.3, &L);
+    FusedLayout L; plan_fused_layout(c, 6, CR, vr, 0x1200, 1200000, &L);
+    {   // plan store: round trip, and a damaged file is refused
+        const uint64_t key = layout_key(c, 6, CR, vr, 1);
+        const std::string path = std::string(argv[5]) + "/rt.plan";
+        FusedLayout M;
+        if (!layout_valid(c, 6, CR, vr, L) || !layout_save(path, key, c, L) || !layout_load(path, key, c, 6, CR, vr, &M)) return 6;
+        if (M.chk_slot != L.chk_slot || M.var_slot != L.var_slot || M.edge_pos != L.edge_pos || M.var_pos != L.var_pos ||
+            M.extra_cycles_planned != L.extra_cycles_planned) return 7;
+        if (layout_load(path, key + 1, c, 6, CR, vr, &M)) return 8;
+        FusedLayout D = L; std::swap(D.var_slot[0], D.var_slot[1]); D.var_slot[2] = D.var_slot[3];  // duplicate slot
+        if (layout_valid(c, 6, CR, vr, D) || !layout_save(path, key, c, D) || layout_load(path, key, c, 6, CR, vr, &M)) return 9;
+    }
+    if (argc > 6) {  // a shipped plan for this code / shape: must load and beat the short run
+        char name[64]; snprintf(name, sizeof(name), "/%016llx.plan", (unsigned long long)layout_key(c, 6, CR, vr, atoi(argv[7])));
+        FusedLayout S;
+        if (!layout_load(std::string(argv[6]) + name, layout_key(c, 6, CR, vr, atoi(argv[7])), c, 6, CR, vr, &S)) return 10;
+        if (S.extra_cycles_planned >= L.extra_cycles_planned) return 11;
+        printf("stored %.0f\n", S.extra_cycles_planned);
+    }
     for (int v = 0; v < c.n; ++v)  // placement constraint: more than 3 edges only in the wide rounds
         if (c.col_ptr[v + 1] - c.col_ptr[v] > 3 && L.var_slot[v] / 64 >= vr.vrx) return 5;
     // the plan must be a permutation of slots and of the positions inside every check
@@ -46,9 +64,9 @@ int main(int argc, char** argv) {
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("code_name,cr,vr,vrx", [("1200_3_6_rand_ldpc_1", 10, 19, 0), ("1200_3_6_rand_ldpc_1", 10, 20, 0),
-                                                   ("1200_rho_x5_rand_ldpc_5", 10, 19, 4)])
-def test_layout_planner_under_asan(tmp_path, code_name, cr, vr, vrx):
+@pytest.mark.parametrize("code_name,cr,vr,vrx,nw", [("1200_3_6_rand_ldpc_1", 10, 19, 0, 1), ("1200_3_6_rand_ldpc_1", 10, 20, 0, 2),
+                                                      ("1200_rho_x5_rand_ldpc_5", 10, 19, 4, 1)])
+def test_layout_planner_under_asan(tmp_path, code_name, cr, vr, vrx, nw):
     cxx = shutil.which("g++")
     if cxx is None:
         pytest.skip("no host C++ compiler")
@@ -66,7 +84,11 @@ def test_layout_planner_under_asan(tmp_path, code_name, cr, vr, vrx):
         pytest.skip("sanitized host build unavailable here: " + r.stderr[-300:])
     code_file = os.path.join(ROOT, "tests", "golden", "codes", code_name + ".txt")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
-    out = subprocess.run([exe, code_file, str(cr), str(vr), str(vrx)], capture_output=True, text=True, env=env, timeout=300)
+    plans = os.path.join(ROOT, "ldpc_decoders_amd", "plans")
+    out = subprocess.run([exe, code_file, str(cr), str(vr), str(vrx), str(tmp_path), plans, str(nw)], capture_output=True, text=True,
+                         env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    base, ident, planned = (float(v) for v in out.stdout.split())
-    assert base == 2.0 * (cr * 6 + vrx * 8 + (vr - vrx) * 3) and planned < 0.6 * ident
+    lines = out.stdout.strip().splitlines()
+    stored = float(lines[0].split()[1])  # conflict cycles of the shipped plan (ldpc_decoders_amd/plans), recomputed on load
+    base, ident, planned = (float(v) for v in lines[1].split())
+    assert base == 2.0 * (cr * 6 + vrx * 8 + (vr - vrx) * 3) and planned < 0.6 * ident and stored < planned
