@@ -17,7 +17,9 @@
 //   * variable phase: marginal = prior + ((0 + c_a) + c_b) + c_c in ascending edge order (dv LDS gathers), write marg.
 //   NW = 1: LDS is private to the wave and DS operations of one wave execute in order, so the phases need no barrier.
 //   NW = 2: twice the resident waves per CU (the kernel is latency-bound at 2 waves per SIMD); one s_barrier after each
-//           phase, the syndrome verdicts of the two waves are exchanged through padded c2v slots each wave owns.
+//           phase, the syndrome verdicts of the waves are exchanged through padded c2v slots each wave owns.
+//   NW = 4: codes up to m = 1536 / n = 2816 (48 KB of LDS per frame, 3 frames per CU), same hand-off scheme.
+//           (NW = 4 with 3 check rounds per wave was measured for n = 1200: slower than NW = 2, 4.15 vs 3.74 ms.)
 //
 // Arithmetic identical to the streaming backend / reference (src/bpa.py:17-63, 86-102): the leave-one-out minimum
 // equals "second minimum at the first arg-min, first minimum elsewhere"; min/compare/negate/add/sub only.
@@ -46,8 +48,8 @@ struct FusedPlan {
     int32_t* d_slot_of_var = nullptr;  // [n rounded up to 4] slot (LDS dword index) of a variable
     unsigned long long* d_cn_active = nullptr;  // [CR] lanes holding a real check in round R
     unsigned long long* d_next = nullptr;       // frame dispenser
-    int sync_off[2] = {0, 0};          // NW = 2: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
-    int msync_off[2] = {0, 0};         // NW = 2: byte offset of a padded marginal slot owned by wave w (end-of-sweep hand-off)
+    int sync_off[4] = {0, 0, 0, 0};    // NW > 1: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
+    int msync_off[4] = {0, 0, 0, 0};   // NW > 1: byte offset of a padded marginal slot owned by wave w (end-of-sweep hand-off)
     int zero_row = 0;                  // 1: the c2v area ends with an always-zero row
     size_t lds_bytes = 0;
     int groups_per_cu = 0, num_cu = 0;
@@ -111,8 +113,9 @@ struct FusedArgs {
     uint8_t* xhat;
     int32_t* iters;
     u64* next_frame;
-    int sync_off0, sync_off1, zero_row;
-    int msync_off0, msync_off1;      // NW = 2: byte offset of a padded MARGINAL slot owned by wave w (end-of-sweep hand-off)
+    int zero_row;
+    int sync_off[4];                 // NW > 1: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
+    int msync_off[4];                // NW > 1: byte offset of a padded MARGINAL slot owned by wave w (end-of-sweep hand-off)
     // fused simulate (SIM kernels): BI-AWGN noise generated in the kernel, errors counted in the kernel
     const int32_t* slot_of_var;     // [n rounded up to 4] LDS dword index (marg area) of each variable
     float sim_mean, sim_sigma, sim_k;  // y = mean + sigma z ; prior = -(k y), k = 2/sigma^2   (src/biawgn.py:17-28)
@@ -126,7 +129,7 @@ struct FusedArgs {
 };
 
 template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const FusedArgs A) {
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fused_bp(const FusedArgs A) {
     static_assert(VRX == 0 || NW == 1, "wide variable rounds (irregular codes) are built for one wave per frame");
     constexpr int VNK = VRX * DVX + (VRW - VRX) * DV;  // gathers of a variable phase: wide rounds first, then narrow ones
     constexpr int VN0 = VRX * DVX;                      // first gather index of the narrow rounds
@@ -164,8 +167,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
     const uint32_t m0_c2v = lds_base + (uint32_t)(NPAD + w * CRW * DC * 64) * 4;  // this wave's c2v rows
     const uint32_t m0_marg = lds_base + (uint32_t)(w * VRW * 64) * 4;            // this wave's marginal rows
-    const uint32_t my_sync = (uint32_t)(w == 0 ? A.sync_off0 : A.sync_off1);
-    const uint32_t my_msync = (uint32_t)(w == 0 ? A.msync_off0 : A.msync_off1);
+    const uint32_t my_sync = (uint32_t)A.sync_off[w];
+    const uint32_t my_msync = (uint32_t)A.msync_off[w];
     const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
     // SIM: per-workgroup counters live in wave 0 (scalars + one histogram bin per lane), flushed once at the end
     unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
@@ -189,9 +192,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
         } else {
             if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_sync) = mine ? 1u : 0u;
             wg_barrier();
-            const uint32_t v0 = *reinterpret_cast<volatile uint32_t*>(smem + A.sync_off0);
-            const uint32_t v1 = *reinterpret_cast<volatile uint32_t*>(smem + A.sync_off1);
-            return (v0 | v1) != 0u;
+            uint32_t v = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) v |= *reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[i]);
+            return v != 0u;
         }
     };
 
@@ -204,7 +208,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
         } else {
             if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_msync) = mine;
             wg_barrier();
-            return *reinterpret_cast<volatile uint32_t*>(smem + A.msync_off0) | *reinterpret_cast<volatile uint32_t*>(smem + A.msync_off1);
+            uint32_t v = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) v |= *reinterpret_cast<volatile uint32_t*>(smem + A.msync_off[i]);
+            return v;
         }
     };
     // frame error counts after the last sweep: through whichever pair of hand-off words the sweep loop did NOT just use for
@@ -215,10 +222,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
             return mine;
         } else {
             const uint32_t mine_off = ALG == ALG_BEC ? my_sync : my_msync;
-            const int o0 = ALG == ALG_BEC ? A.sync_off0 : A.msync_off0, o1 = ALG == ALG_BEC ? A.sync_off1 : A.msync_off1;
             if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + mine_off) = mine;
             wg_barrier();
-            return *reinterpret_cast<volatile int32_t*>(smem + o0) + *reinterpret_cast<volatile int32_t*>(smem + o1);
+            int sum = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) sum += *reinterpret_cast<volatile int32_t*>(smem + (ALG == ALG_BEC ? A.sync_off[i] : A.msync_off[i]));
+            return sum;
         }
     };
 
@@ -252,10 +261,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 4) void k_fused_bp(const Fus
             wg_barrier();  // the verdict slots of the previous frame have been read by everybody
             if (w == 0) {
                 const long long f0 = next_frame();
-                if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + A.sync_off0) = (int32_t)f0;
+                if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + A.sync_off[0]) = (int32_t)f0;
             }
             wg_barrier();
-            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(smem + A.sync_off0));
+            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0]));
         }
         if (fr_s < 0) break;
         const u64 fr = (u64)fr_s;
@@ -673,6 +682,8 @@ const ShapeEntry kShapes[] = {
     shape_entry<ALG_MSA, 6, 3, 10, 19, 1>(), shape_entry<ALG_SPA, 6, 3, 10, 19, 1>(), shape_entry<ALG_BEC, 6, 3, 10, 19, 1>(),  // m <= 640, n <= 1216, 1 wave/frame
     // irregular: check degrees <= 6 (short rows padded by a "certain" variable), variable degrees <= 8 (at most 256 above 3)
     shape_entry<ALG_MSA, 6, 3, 10, 19, 1, 4, 8>(), shape_entry<ALG_SPA, 6, 3, 10, 19, 1, 4, 8>(), shape_entry<ALG_BEC, 6, 3, 10, 19, 1, 4, 8>(),
+    // four waves per frame: m <= 1536, n <= 2816 (48 KB of LDS per frame, 3 frames per CU) -- e.g. the (3,6) Margulis code n = 2640
+    shape_entry<ALG_MSA, 6, 3, 6, 11, 4>(),  shape_entry<ALG_SPA, 6, 3, 6, 11, 4>(),  shape_entry<ALG_BEC, 6, 3, 6, 11, 4>(),
 };
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
@@ -956,10 +967,10 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
     a.slot_of_var = p->d_slot_of_var;
     a.cn_active = p->d_cn_active;
     a.next_frame = p->d_next;
-    a.sync_off0 = p->sync_off[0];
-    a.sync_off1 = p->sync_off[1];
-    a.msync_off0 = p->msync_off[0];
-    a.msync_off1 = p->msync_off[1];
+    for (int i = 0; i < 4; ++i) {
+        a.sync_off[i] = p->sync_off[i];
+        a.msync_off[i] = p->msync_off[i];
+    }
     a.zero_row = p->zero_row;
     void* args[] = {&a};
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -239,7 +239,7 @@ def test_ragged_and_edge_batches():
         dec.decode_batch(None, pri[:, :-1])
 
 
-@pytest.mark.parametrize("nw", ["1", "2"])
+@pytest.mark.parametrize("nw", ["1", "2", "4"])
 def test_fused_variants_ragged_and_iteration0(nw, monkeypatch):
     # both fused kernels (1 and 2 wavefronts per frame) on tiny / ragged batches, with and without the iteration-0 word
     from ldpc_decoders_amd import bpa, bsc
@@ -270,7 +270,7 @@ def test_fused_variants_ragged_and_iteration0(nw, monkeypatch):
     assert (i3.cpu().numpy() == 3).all()
 
 
-@pytest.mark.parametrize("nw", ["1", "2"])
+@pytest.mark.parametrize("nw", ["1", "2", "4"])
 def test_fused_erasure_decoder_variants(nw, monkeypatch):
     # fused erasure decoder (1 and 2 wavefronts per frame) against the C oracle incl. stopping sets, max_iter cuts and the
     # fused simulate counters (channel + decode + count in one kernel) -- repeated to shake out hand-off races

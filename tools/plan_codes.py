@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CODES = ["1200_3_6_rand_ldpc_1", "1200_3_6_ldpc", "512_3_6_rand_ldpc_2", "1200_rho_x5_rand_ldpc_5"]
+CODES = ["1200_3_6_rand_ldpc_1", "1200_3_6_ldpc", "512_3_6_rand_ldpc_2", "1200_rho_x5_rand_ldpc_5", "margulis"]
 
 CHILD = r"""
 import os, sys, time
