@@ -92,7 +92,7 @@ __device__ __forceinline__ void cn_spa(double (&v)[DCMAX], int deg) {
 // Exactly the same quantity as the reference's tanh product (and as the phi-domain statement of the oracle,
 // bp_oracle.spa_phi_check_update); small D (all other edges reliable) keeps full relative precision up to |LLR| ~ 88,
 // D -> 1 (an unreliable edge) gives |c2v| -> 0 with absolute error ~1e-7.  Unlike the reference it has no 0/0 at
-// v2c == 0 (src/bpa.py:74 TODO) and no +-inf / NaN artefacts below |LLR| ~ 88.
+// v2c == 0 (src/bpa.py:74 TODO) and no +-inf / NaN artefacts: above |LLR| ~ 88 the check messages saturate (finite).
 // Agreement with the fp64 reference is a TOLERANCE (tests/test_gpu_parity.py), not bit-exactness.
 // 4 transcendental-unit operations per edge (exp2, rcp, rcp, log2).
 __device__ __forceinline__ float spa_d_of_llr(float a) {  // a = |v2c| >= 0  ->  1 - tanh(a/2)
@@ -100,7 +100,10 @@ __device__ __forceinline__ float spa_d_of_llr(float a) {  // a = |v2c| >= 0  -> 
     return (2.0f * u) * __builtin_amdgcn_rcpf(1.0f + u);                   // v_rcp_f32, ~1 ulp
 }
 __device__ __forceinline__ float spa_join(float x, float y) { return fmaf(-x, y, x) + y; }  // 1 - (1-x)(1-y)
-__device__ __forceinline__ float spa_llr_of_d(float D) {  // 2 atanh(1 - D) = ln((2 - D) / D); D == 0 -> +inf
+__device__ __forceinline__ float spa_llr_of_d(float D) {  // 2 atanh(1 - D) = ln((2 - D) / D)
+    // D underflows to 0 once every other edge of the check is beyond |LLR| ~ 88: saturate there (|c2v| <= 88.03) instead of
+    // returning +inf, which would turn the next v2c = marginal - c2v into inf - inf = NaN and poison the frame
+    D = fmaxf(D, 1.17549435e-38f);
     return 0.69314718055994530942f * __builtin_amdgcn_logf((2.0f - D) * __builtin_amdgcn_rcpf(D));  // v_log_f32 is log2
 }
 

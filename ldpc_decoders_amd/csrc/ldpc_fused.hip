@@ -51,6 +51,7 @@ struct FusedPlan {
     int sync_off[4] = {0, 0, 0, 0};    // NW > 1: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
     int msync_off[4] = {0, 0, 0, 0};   // NW > 1: byte offset of a padded marginal slot owned by wave w (end-of-sweep hand-off)
     int zero_row = 0;                  // 1: the c2v area ends with an always-zero row
+    int sys_off = 0;                   // NW = 16: byte offset of the system row
     size_t lds_bytes = 0;
     int groups_per_cu = 0, num_cu = 0;
     double extra_identity = 0, extra_planned = 0, base_cycles = 0;
@@ -99,6 +100,20 @@ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { r
 __device__ __forceinline__ float lds_ld(const unsigned char* base, uint32_t byte_off) {
     return *reinterpret_cast<const float*>(base + byte_off);
 }
+// gather through a table entry: a 16-bit LDS byte offset, or (BIG: frames beyond 64 KB of LDS) a 16-bit dword index
+template <bool BIG>
+__device__ __forceinline__ float lds_gat(const unsigned char* base, uint32_t entry) {
+    return *reinterpret_cast<const float*>(base + (BIG ? (entry << 2) : entry));
+}
+// c2v store of the BIG shape: ds_write_addtid reaches M0[15:0] + 16-bit offset only, so rows beyond that use an address
+// register (lane-contiguous all the same; 4 instead of 2 store-path cycles)
+// Two rows per instruction: ds_write2st64_b32 stores a at vaddr + R0*256 and b at vaddr + R1*256 (offsets in units of 64 dwords
+// == one lane-contiguous row); three source dwords -> 6 store-path cycles for two rows.
+template <int R0, int R1>
+__device__ __forceinline__ void lds_st2_rows(uint32_t vaddr, float a, float b) {
+    static_assert(R0 >= 0 && R0 < 256 && R1 >= 0 && R1 < 256, "8-bit row offsets");
+    asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(vaddr), "v"(a), "v"(b), "n"(R0), "n"(R1) : "memory");
+}
 
 struct FusedArgs {
     const float* priors;
@@ -114,8 +129,9 @@ struct FusedArgs {
     int32_t* iters;
     u64* next_frame;
     int zero_row;
-    int sync_off[4];                 // NW > 1: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
-    int msync_off[4];                // NW > 1: byte offset of a padded MARGINAL slot owned by wave w (end-of-sweep hand-off)
+    int sync_off[4];                 // 1 < NW <= 4: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
+    int msync_off[4];                // 1 < NW <= 4: byte offset of a padded MARGINAL slot owned by wave w (end-of-sweep hand-off)
+    int sys_off;                     // NW = 16: byte offset of the system row (last marginal row, never written by the sweeps)
     // fused simulate (SIM kernels): BI-AWGN noise generated in the kernel, errors counted in the kernel
     const int32_t* slot_of_var;     // [n rounded up to 4] LDS dword index (marg area) of each variable
     float sim_mean, sim_sigma, sim_k;  // y = mean + sigma z ; prior = -(k y), k = 2/sigma^2   (src/biawgn.py:17-28)
@@ -129,14 +145,18 @@ struct FusedArgs {
 };
 
 template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fused_bp(const FusedArgs A) {
-    static_assert(VRX == 0 || NW == 1, "wide variable rounds (irregular codes) are built for one wave per frame");
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 4 ? 3 : 4)) void k_fused_bp(const FusedArgs A) {
+    // BIG: a frame takes the whole LDS of a CU (160 KB) and a 16-wave workgroup.  Table entries are dword indices, c2v stores
+    // use an address register, and the LAST marginal row is a system row that no sweep writes: dwords [0,16) hand-off
+    // channel A (one word per wave), [16,32) channel B, [32] frame hand-out, [33] always zero (target of missing edges).
+    constexpr bool BIG = NW > 4;
+    static_assert(VRX == 0 || NW == 1 || BIG, "wide variable rounds: one wave per frame, or the 16-wave shape");
     constexpr int VNK = VRX * DVX + (VRW - VRX) * DV;  // gathers of a variable phase: wide rounds first, then narrow ones
     constexpr int VN0 = VRX * DVX;                      // first gather index of the narrow rounds
     constexpr int CR = CRW * NW, VR = VRW * NW;
     constexpr int NPAD = VR * 64;
     constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
-    constexpr int VG_BEC = 2;  // variable rounds per pipeline stage of the erasure decoder
+    constexpr int VG_BEC = NW > 4 ? 1 : 2;  // variable rounds per pipeline stage of the erasure decoder
     constexpr int VRN = VRW - VRX;  // narrow variable rounds (DV gathers); they follow the VRX wide rounds
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -153,7 +173,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
 #pragma unroll
     for (int i = 0; i < VNW; ++i) vn_idx[i] = A.vn_tab[(w * VNW + i) * 64 + lane];
     // variable index of each owned slot (-1: padding): resident in registers where the budget allows, else re-read per frame
-    constexpr bool VMAP_RESIDENT = !SIM && ((NW == 1) || (ALG == ALG_MSA));
+    constexpr bool VMAP_RESIDENT = !SIM && !BIG && ((NW == 1) || (ALG == ALG_MSA));
     int vmap_reg[VMAP_RESIDENT ? VRW : 1];
     if constexpr (VMAP_RESIDENT) {
 #pragma unroll
@@ -163,12 +183,18 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
         if constexpr (VMAP_RESIDENT) return vmap_reg[q]; else return vslot[q * 64 + lane];
     };
     if (A.zero_row && w == 0) reinterpret_cast<float*>(smem)[NPAD + CR * DC * 64 + lane] = 0.0f;  // the always-zero row
+    const bool own_last = !(BIG && w == NW - 1);  // wave NW-1 of the BIG shape never writes its last row (the system row)
+    auto sysw = [&](int i) { return reinterpret_cast<volatile uint32_t*>(smem + A.sys_off) + i; };
+    if constexpr (BIG) {
+        if (threadIdx.x == 0) *sysw(33) = 0u;  // published by the barrier at the top of the frame loop
+    }
 
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
     const uint32_t m0_c2v = lds_base + (uint32_t)(NPAD + w * CRW * DC * 64) * 4;  // this wave's c2v rows
     const uint32_t m0_marg = lds_base + (uint32_t)(w * VRW * 64) * 4;            // this wave's marginal rows
-    const uint32_t my_sync = (uint32_t)A.sync_off[w];
-    const uint32_t my_msync = (uint32_t)A.msync_off[w];
+    const uint32_t my_sync = (uint32_t)A.sync_off[BIG ? 0 : w];
+    const uint32_t my_msync = (uint32_t)A.msync_off[BIG ? 0 : w];
+    const uint32_t c2v_vaddr = m0_c2v + (uint32_t)lane * 4u;  // BIG: address register of the c2v stores
     const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
     // SIM: per-workgroup counters live in wave 0 (scalars + one histogram bin per lane), flushed once at the end
     unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
@@ -189,6 +215,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
     auto any_unsat = [&](bool mine) -> bool {
         if constexpr (NW == 1) {
             return mine;
+        } else if constexpr (BIG) {
+            if (lane == 0) *sysw(w) = mine ? 1u : 0u;
+            wg_barrier();
+            return __ballot(*sysw(lane & 15) != 0u) != 0;
         } else {
             if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_sync) = mine ? 1u : 0u;
             wg_barrier();
@@ -205,6 +235,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
     auto exchange_or = [&](uint32_t mine) -> uint32_t {  // OR of the words of all waves (contains one barrier)
         if constexpr (NW == 1) {
             return mine;
+        } else if constexpr (BIG) {
+            if (lane == 0) *sysw(16 + w) = mine;
+            wg_barrier();
+            const uint32_t v = *sysw(16 + (lane & 15));
+            return (__ballot((v & 1u) != 0u) != 0 ? 1u : 0u) | (__ballot((v & 2u) != 0u) != 0 ? 2u : 0u);
         } else {
             if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_msync) = mine;
             wg_barrier();
@@ -220,6 +255,14 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
     auto exchange_add = [&](int mine) -> int {
         if constexpr (NW == 1) {
             return mine;
+        } else if constexpr (BIG) {
+            constexpr int CH = ALG == ALG_BEC ? 0 : 16;  // the channel the sweep loop did not just use
+            if (lane == 0) *sysw(CH + w) = (uint32_t)mine;
+            wg_barrier();
+            int sum = lane < 16 ? (int)*sysw(CH + (lane & 15)) : 0;
+#pragma unroll
+            for (int o = 8; o; o >>= 1) sum += __shfl_xor(sum, o);
+            return __builtin_amdgcn_readfirstlane(sum);
         } else {
             const uint32_t mine_off = ALG == ALG_BEC ? my_sync : my_msync;
             if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + mine_off) = mine;
@@ -261,10 +304,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
             wg_barrier();  // the verdict slots of the previous frame have been read by everybody
             if (w == 0) {
                 const long long f0 = next_frame();
-                if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + A.sync_off[0]) = (int32_t)f0;
+                if (lane == 0) *(BIG ? sysw(32) : reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0])) = (uint32_t)(int32_t)f0;
             }
             wg_barrier();
-            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0]));
+            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*(BIG ? sysw(32) : reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0])));
         }
         if (fr_s < 0) break;
         const u64 fr = (u64)fr_s;
@@ -342,7 +385,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
             // sweep, "x_hat did not change" after it.  `it` counts executed sweeps (the one that finds no change included).
 #pragma unroll
             for (int q = 0; q < VRW; ++q) {
-                lds_marg[q * 64 + lane] = prior[q];
+                if (q < VRW - 1 || own_last) lds_marg[q * 64 + lane] = prior[q];
                 xb |= (prior[q] > 0.0f) ? (1u << q) : 0u;
                 xe |= (prior[q] == 0.0f) ? (1u << q) : 0u;
             }
@@ -356,12 +399,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
                 lds_set_m0(m0_c2v);
                 float mg[2][DC];
 #pragma unroll
-                for (int j = 0; j < DC; ++j) mg[0][j] = lds_ld(smem, half_of<CRW * DC>(cn_idx, j));
+                for (int j = 0; j < DC; ++j) mg[0][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, j));
                 static_for<0, CRW>([&](auto R_) {
                     constexpr int r = decltype(R_)::value;
                     if constexpr (r + 1 < CRW) {
 #pragma unroll
-                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_ld(smem, half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
+                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     float sgn[DC];
@@ -379,8 +422,15 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
                         // 0 erasures: echo; > 1: nothing known; exactly 1: the erased edge learns the parity of the others
                         const float c = n_erased == 0.0f ? sgn[j] : (n_erased > 1.0f ? 0.0f : (sgn[j] == 0.0f ? fill : 0.0f));
                         c2v_old[r][j] = c;
-                        lds_st_tid<(r * DC + j) * 256>(c);
+                        if constexpr (!BIG) lds_st_tid<(r * DC + j) * 256>(c);
                     });
+                    if constexpr (BIG) {
+                        static_assert(!BIG || DC % 2 == 0, "paired row stores");
+                        static_for<0, DC / 2>([&](auto P_) {
+                            constexpr int pj = 2 * decltype(P_)::value;
+                            lds_st2_rows<r * DC + pj, r * DC + pj + 1>(c2v_vaddr, c2v_old[r][pj], c2v_old[r][pj + 1]);
+                        });
+                    }
                 });
                 if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
                 lds_set_m0(m0_marg);
@@ -388,19 +438,19 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
                 auto finish_var = [&](auto Q_, float sm) {
                     constexpr int q = decltype(Q_)::value;
                     const float m1 = prior[q] + sm;  // small integers: exact
-                    lds_st_tid<q * 256>(m1);
+                    if (q < VRW - 1 || own_last) lds_st_tid<q * 256>(m1);
                     nb |= (m1 > 0.0f) ? (1u << q) : 0u;
                     ne |= (m1 == 0.0f) ? (1u << q) : 0u;
                 };
                 if constexpr (VRX > 0) {
                     float cw[2][DVX];
 #pragma unroll
-                    for (int j = 0; j < DVX; ++j) cw[0][j] = lds_ld(smem, half_of<VNK>(vn_idx, j));
+                    for (int j = 0; j < DVX; ++j) cw[0][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, j));
                     static_for<0, VRX>([&](auto Q_) {
                         constexpr int q = decltype(Q_)::value;
                         if constexpr (q + 1 < VRX) {
 #pragma unroll
-                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = lds_ld(smem, half_of<VNK>(vn_idx, (q + 1) * DVX + j));
+                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, (q + 1) * DVX + j));
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         float sw = cw[q & 1][0];
@@ -414,7 +464,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
                 for (int u = 0; u < VG_BEC; ++u)
 #pragma unroll
                     for (int j = 0; j < DV; ++j)
-                        if (u < VRN) cv[0][u][j] = lds_ld(smem, half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                        if (u < VRN) cv[0][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + u * DV + j));
                 static_for<0, (VRN + VG_BEC - 1) / VG_BEC>([&](auto G_) {
                     constexpr int g = decltype(G_)::value;
                     if constexpr (g + 1 < (VRN + VG_BEC - 1) / VG_BEC) {
@@ -423,7 +473,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
 #pragma unroll
                             for (int j = 0; j < DV; ++j)
                                 if ((g + 1) * VG_BEC + u < VRN)
-                                    cv[(g + 1) & 1][u][j] = lds_ld(smem, half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG_BEC + u) * DV + j));
+                                    cv[(g + 1) & 1][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG_BEC + u) * DV + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     static_for<0, VG_BEC>([&](auto U_) {
@@ -456,7 +506,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
             for (int q = 0; q < VRW; ++q) {
                 const int v = vmap_of(q);
                 const bool one = v >= 0 && yf[v] != 0;
-                lds_marg[q * 64 + lane] = one ? -1.0f : 1.0f;
+                if (q < VRW - 1 || own_last) lds_marg[q * 64 + lane] = one ? -1.0f : 1.0f;
                 xb |= one ? (1u << q) : 0u;
             }
             if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
@@ -465,7 +515,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
             for (int r = 0; r < CRW; ++r) {
                 u64 par = 0;
 #pragma unroll
-                for (int j = 0; j < DC; ++j) par ^= __ballot(lds_ld(smem, half_of<CRW * DC>(cn_idx, r * DC + j)) < 0.0f);
+                for (int j = 0; j < DC; ++j) par ^= __ballot(lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, r * DC + j)) < 0.0f);
                 if constexpr (DC % 2 == 0) unsat |= par; else unsat |= par & cn_active[r];
             }
             left_at_0 = early && !any_unsat(unsat != 0);
@@ -473,12 +523,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
         }
         if (ALG != ALG_BEC && !left_at_0) {
 #pragma unroll
-            for (int q = 0; q < VRW; ++q) lds_marg[q * 64 + lane] = prior[q];
+            for (int q = 0; q < VRW; ++q) if (q < VRW - 1 || own_last) lds_marg[q * 64 + lane] = prior[q];
             if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
             // The sweep is one software-pipelined stream of LDS traffic: the gathers of check round r+1 (variable
             // group g+1) are issued before round r (group g) is computed, so a wave always has a full round of
             // ds_reads in flight while it does arithmetic.
-            constexpr int VG = (ALG == ALG_MSA && NW == 1) ? 4 : 2;  // variable rounds per pipeline stage (register budget)
+            constexpr int VG = BIG ? 1 : ((ALG == ALG_MSA && NW == 1) ? 4 : 2);  // variable rounds per pipeline stage (register budget)
             constexpr int NVG = (VRN + VG - 1) / VG;
             for (;;) {
                 if (max_iter > 0 && it >= max_iter) break;
@@ -487,12 +537,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
                 uint32_t synd = 0;  // bit 31: some owned check is unsatisfied by the previous decisions
                 float mg[2][DC];
 #pragma unroll
-                for (int j = 0; j < DC; ++j) mg[0][j] = lds_ld(smem, half_of<CRW * DC>(cn_idx, j));
+                for (int j = 0; j < DC; ++j) mg[0][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, j));
                 static_for<0, CRW>([&](auto R_) {
                     constexpr int r = decltype(R_)::value;
                     if constexpr (r + 1 < CRW) {
 #pragma unroll
-                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_ld(smem, half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
+                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this round's arithmetic
                     // Sign handling on the raw IEEE bits (bit 31), all in the vector ALU: row parity = XOR of the sign
@@ -552,8 +602,15 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
                         const float mag = ALG == ALG_MSA ? fminf(pre[j], suf[j]) : spa_llr_of_d(spa_join(pre[j], suf[j]));
                         const float c = __uint_as_float(__float_as_uint(mag) | ((vx ^ __float_as_uint(v[j])) & 0x80000000u));
                         c2v_old[r][j] = c;
-                        lds_st_tid<(r * DC + j) * 256>(c);
+                        if constexpr (!BIG) lds_st_tid<(r * DC + j) * 256>(c);
                     });
+                    if constexpr (BIG) {
+                        static_assert(!BIG || DC % 2 == 0, "paired row stores");
+                        static_for<0, DC / 2>([&](auto P_) {
+                            constexpr int pj = 2 * decltype(P_)::value;
+                            lds_st2_rows<r * DC + pj, r * DC + pj + 1>(c2v_vaddr, c2v_old[r][pj], c2v_old[r][pj + 1]);
+                        });
+                    }
                 });
                 const bool unsat = any_unsat(__ballot((synd & 0x80000000u) != 0u) != 0);  // NW > 1: contains the barrier
                 // it == 0: only the BSC checks the received word itself (src/bpa.py:20,29); in SIM mode marg holds +-llr there
@@ -566,19 +623,19 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
                 auto finish_var = [&](auto Q_, float s) {
                     constexpr int q = decltype(Q_)::value;
                     const float m1 = prior[q] + s;
-                    lds_st_tid<q * 256>(m1);
+                    if (q < VRW - 1 || own_last) lds_st_tid<q * 256>(m1);
                     // decision: (m1 < 0); for min-sum the sign bit itself (m1 is never -0.0 and never NaN for finite priors)
                     if constexpr (ALG == ALG_MSA) xb |= (__float_as_uint(m1) >> 31) << q; else xb |= (m1 < 0.0f) ? (1u << q) : 0u;
                 };
                 if constexpr (VRX > 0) {  // wide rounds of irregular codes: DVX gathers per variable, one round per stage
                     float cw[2][DVX];
 #pragma unroll
-                    for (int j = 0; j < DVX; ++j) cw[0][j] = lds_ld(smem, half_of<VNK>(vn_idx, j));
+                    for (int j = 0; j < DVX; ++j) cw[0][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, j));
                     static_for<0, VRX>([&](auto Q_) {
                         constexpr int q = decltype(Q_)::value;
                         if constexpr (q + 1 < VRX) {
 #pragma unroll
-                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = lds_ld(smem, half_of<VNK>(vn_idx, (q + 1) * DVX + j));
+                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, (q + 1) * DVX + j));
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         float sw = 0.0f + cw[q & 1][0];
@@ -592,7 +649,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
                 for (int u = 0; u < VG; ++u)
 #pragma unroll
                     for (int j = 0; j < DV; ++j)
-                        if (u < VRN) cv[0][u][j] = lds_ld(smem, half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                        if (u < VRN) cv[0][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + u * DV + j));
                 static_for<0, NVG>([&](auto G_) {
                     constexpr int g = decltype(G_)::value;
                     if constexpr (g + 1 < NVG) {
@@ -601,7 +658,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 2 ? 4 : 3)) void k_fu
 #pragma unroll
                             for (int j = 0; j < DV; ++j)
                                 if ((g + 1) * VG + u < VRN)
-                                    cv[(g + 1) & 1][u][j] = lds_ld(smem, half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG + u) * DV + j));
+                                    cv[(g + 1) & 1][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG + u) * DV + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     static_for<0, VG>([&](auto U_) {
@@ -684,6 +741,9 @@ const ShapeEntry kShapes[] = {
     shape_entry<ALG_MSA, 6, 3, 10, 19, 1, 4, 8>(), shape_entry<ALG_SPA, 6, 3, 10, 19, 1, 4, 8>(), shape_entry<ALG_BEC, 6, 3, 10, 19, 1, 4, 8>(),
     // four waves per frame: m <= 1536, n <= 2816 (48 KB of LDS per frame, 3 frames per CU) -- e.g. the (3,6) Margulis code n = 2640
     shape_entry<ALG_MSA, 6, 3, 6, 11, 4>(),  shape_entry<ALG_SPA, 6, 3, 6, 11, 4>(),  shape_entry<ALG_BEC, 6, 3, 6, 11, 4>(),
+    // sixteen waves per frame, the whole LDS of a CU (160 KB) for one frame: m <= 5120, n <= 10 175, check degrees <= 6,
+    // variable degrees <= 8 (at most 3072 above 3) -- the rate-1/2 irregular n = 10 000 ensemble
+    shape_entry<ALG_MSA, 6, 3, 5, 10, 16, 3, 8>(), shape_entry<ALG_SPA, 6, 3, 5, 10, 16, 3, 8>(), shape_entry<ALG_BEC, 6, 3, 5, 10, 16, 3, 8>(),
 };
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
@@ -744,16 +804,17 @@ int fused_plan_create(Decoder* d) {
     for (int i = 0; i < kNumShapes && si < 0; ++i) {
         const ShapeEntry& s = kShapes[i];
         const int CR = s.CRW * s.NW, VR = s.VRW * s.NW;
-        if (s.alg != d->alg || c->max_dc != s.DC || c->m > CR * 64 || c->n + (short_rows ? 1 : 0) > VR * 64) continue;
+        const bool big = s.NW > 4;  // one system row of variable slots is reserved
+        if (s.alg != d->alg || c->max_dc != s.DC || c->m > CR * 64 || c->n + (short_rows ? 1 : 0) > (VR - (big ? 1 : 0)) * 64) continue;
         if (force_nw && s.NW != force_nw) continue;
         if (s.VRX == 0) {
             if (short_rows || c->max_dv > s.DV) continue;
         } else {
             int wide = 0;
             for (int v = 0; v < c->n; ++v) wide += (c->col_ptr[v + 1] - c->col_ptr[v]) > s.DV;
-            if (c->max_dv > s.DVX || wide > s.VRX * 64) continue;
+            if (c->max_dv > s.DVX || wide > s.VRX * s.NW * 64) continue;
         }
-        if (s.NW > 1 && (!full_dv || c->max_dv != s.DV || CR * 64 - c->m < s.NW)) continue;  // needs padded check slots for the hand-off
+        if (s.NW > 1 && !big && (!full_dv || c->max_dv != s.DV || CR * 64 - c->m < s.NW)) continue;  // needs padded check slots for the hand-off
         si = i;
     }
     if (si < 0) return LDPC_OK;
@@ -761,7 +822,9 @@ int fused_plan_create(Decoder* d) {
     const int DC = shape.DC, DV = shape.DV, NW = shape.NW, CRW = shape.CRW, VRW = shape.VRW;
     const int CR = CRW * NW, VR = VRW * NW, NPAD = VR * 64;
     VarRounds vr;
-    vr.VR = VR; vr.DV = DV; vr.vrx = shape.VRX; vr.dvx = shape.DVX;
+    const bool BIG = NW > 4;
+    vr.VR = VR; vr.DV = DV; vr.vrx = shape.VRX; vr.dvx = shape.DVX; vr.nw = NW; vr.reserved = BIG ? 1 : 0;
+    p->sys_off = BIG ? (NPAD - 64) * 4 : 0;
     p->shape = si; p->DC = DC; p->DV = DV; p->CR = CR; p->VR = VR; p->NW = NW;
     p->zero_row = (NW == 1) ? 1 : 0;
 
@@ -770,7 +833,7 @@ int fused_plan_create(Decoder* d) {
     const char* mode = std::getenv("LDPC_FUSED_LAYOUT");
     if (mode && std::string(mode) == "identity") {
         identity_layout(*c, DC, vr, &L);
-        if (NW > 1) {  // spread the checks / variables evenly over the waves so that every wave keeps padded slots
+        if (NW > 1 && !BIG) {  // spread the checks / variables evenly over the waves so that every wave keeps padded slots
             for (int cc = 0; cc < c->m; ++cc) L.chk_slot[cc] = (int)((int64_t)cc * CR * 64 / c->m);
             for (int v = 0; v < c->n; ++v) L.var_slot[v] = (int)((int64_t)v * NPAD / c->n);
         }
@@ -818,7 +881,7 @@ int fused_plan_create(Decoder* d) {
     // short check rows are padded with reads of one "certain" variable slot (marked -2): +-inf marginal, see the kernel
     int certain_slot = -1;
     if (short_rows) {
-        for (int s = NPAD - 1; s >= 0 && certain_slot < 0; --s)
+        for (int s = (VR - vr.reserved) * 64 - 1; s >= 0 && certain_slot < 0; --s)
             if (var_of_slot[s] == -1) certain_slot = s;
         if (certain_slot < 0) return LDPC_OK;
         var_of_slot[certain_slot] = -2;
@@ -834,11 +897,13 @@ int fused_plan_create(Decoder* d) {
         for (int j = 0; j < DC; ++j)
             if (!((used >> j) & 1u)) cn_addr[(size_t)(R * DC + j) * 64 + lane] = (int64_t)certain_slot * 4;
     }
+    // where a missing edge reads its 0: the always-zero row behind the c2v area (one word per lane), or the zero word of the system row
+    auto zero_addr = [&](int lane) -> int64_t { return BIG ? (int64_t)p->sys_off + 33 * 4 : (int64_t)c2v_base + (int64_t)(CR * DC * 64 + lane) * 4; };
     for (int v = 0; v < c->n; ++v) {
         const int Q = var_slot[v] / 64, lane = var_slot[v] % 64;
-        // a real variable with fewer than DV edges sums the always-zero row for the missing ones (NW == 1 shapes only)
-        if (p->zero_row)
-            for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = c2v_base + (int64_t)(CR * DC * 64 + lane) * 4;
+        // a real variable with fewer edges than its round gathers sums zeros for the missing ones
+        if (p->zero_row || BIG)
+            for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = zero_addr(lane);
         for (int pidx = c->col_ptr[v]; pidx < c->col_ptr[v + 1]; ++pidx) {
             const int k = c->col_edge[pidx], cs = chk_slot[c->edge_chk[k]];
             vn_addr[(size_t)(vr.first_gather(Q) + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(((cs / 64) * DC + edge_pos[k]) * 64 + cs % 64) * 4;
@@ -846,7 +911,7 @@ int fused_plan_create(Decoder* d) {
     }
     if (certain_slot >= 0) {  // the certain slot sums nothing: every gather reads the zero row
         const int Q = certain_slot / 64, lane = certain_slot % 64;
-        for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = c2v_base + (int64_t)(CR * DC * 64 + lane) * 4;
+        for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = zero_addr(lane);
     }
     // padded lanes may read anything: let them repeat an address of their own half-wave (LDS broadcast, no extra cycle)
     auto fill_padding = [](std::vector<int64_t>& addr, int64_t fallback) {
@@ -891,10 +956,10 @@ int fused_plan_create(Decoder* d) {
     fill_padding(cn_addr, 0);
     fill_padding(vn_addr, c2v_base);
     for (int K = 0; K < CR * DC; ++K)
-        for (int lane = 0; lane < 64; ++lane) put16(cn_tab, CNW, CRW * DC, K, lane, (uint32_t)cn_addr[(size_t)K * 64 + lane]);
+        for (int lane = 0; lane < 64; ++lane) put16(cn_tab, CNW, CRW * DC, K, lane, (uint32_t)(cn_addr[(size_t)K * 64 + lane] >> (BIG ? 2 : 0)));
     for (int K = 0; K < vr.total_gathers(); ++K)
-        for (int lane = 0; lane < 64; ++lane) put16(vn_tab, VNW, VNK, K, lane, (uint32_t)vn_addr[(size_t)K * 64 + lane]);
-    if (NW > 1) {
+        for (int lane = 0; lane < 64; ++lane) put16(vn_tab, VNW, VNK, K, lane, (uint32_t)(vn_addr[(size_t)K * 64 + lane] >> (BIG ? 2 : 0)));
+    if (NW > 1 && !BIG) {
         // hand-off words: for each wave the c2v slot (position dc-1) of one of its padded check lanes, in its LAST round
         // that has one (so the wave's own garbage write to it precedes the verdict write in program order)
         for (int wv = 0; wv < NW; ++wv) {
@@ -912,7 +977,7 @@ int fused_plan_create(Decoder* d) {
         }
     }
     p->lds_bytes = (size_t)(NPAD + (CR * DC + p->zero_row) * 64) * 4;
-    if (p->lds_bytes > 65535) return LDPC_OK;  // 16-bit offsets
+    if (p->lds_bytes > (BIG ? (size_t)160 * 1024 : (size_t)65535)) return LDPC_OK;  // 16-bit byte offsets (dword indices for the 16-wave shape)
     LDPC_HIP_TRY(hipSetDevice(c->device));
     LDPC_TRY(upload_vec(cn_tab, &p->d_cn_tab));
     LDPC_TRY(upload_vec(vn_tab, &p->d_vn_tab));
@@ -972,6 +1037,7 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
         a.msync_off[i] = p->msync_off[i];
     }
     a.zero_row = p->zero_row;
+    a.sys_off = p->sys_off;
     void* args[] = {&a};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (d->profile) {

@@ -36,13 +36,17 @@ void identity_layout(const Code& c, int DC, const VarRounds& vr, FusedLayout* L)
     L->var_slot.resize(c.n);
     std::iota(L->chk_slot.begin(), L->chk_slot.end(), 0);
     // variables: those that need a wide round first into the wide slots, the others into the narrow slots in index order
-    // (spilling into left-over wide slots when the narrow ones are full)
-    const int wide_slots = vr.vrx * 64;
-    int next_wide = 0, next_narrow = wide_slots;
+    // (spilling into left-over wide slots when the narrow ones are full); reserved rounds stay empty
+    std::vector<int> wide_free, narrow_free;
+    for (int q = 0; q < vr.VR; ++q) {
+        if (!vr.usable(q)) continue;
+        for (int l = 0; l < 64; ++l) (vr.width(q) > vr.DV ? wide_free : narrow_free).push_back(q * 64 + l);
+    }
+    size_t next_wide = 0, next_narrow = 0;
     for (int v = 0; v < c.n; ++v)
-        if (c.col_ptr[v + 1] - c.col_ptr[v] > vr.DV) L->var_slot[v] = next_wide++;
+        if (c.col_ptr[v + 1] - c.col_ptr[v] > vr.DV) L->var_slot[v] = wide_free[next_wide++];
     for (int v = 0; v < c.n; ++v)
-        if (c.col_ptr[v + 1] - c.col_ptr[v] <= vr.DV) L->var_slot[v] = next_narrow < vr.VR * 64 ? next_narrow++ : next_wide++;
+        if (c.col_ptr[v + 1] - c.col_ptr[v] <= vr.DV) L->var_slot[v] = next_narrow < narrow_free.size() ? narrow_free[next_narrow++] : wide_free[next_wide++];
     L->edge_pos.assign(c.E, 0);
     L->var_pos.assign(c.E, 0);
     for (int cc = 0; cc < c.m; ++cc)
@@ -106,7 +110,7 @@ void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint6
         var_at[(size_t)vgrp[v] * 32 + vbank[v]] = v;
     }
     // placement constraint: a variable with more than DV edges only fits a slot of a wide round (group g = 2*round + half)
-    auto fits = [&](int v, int s) { return v < 0 || c.col_ptr[v + 1] - c.col_ptr[v] <= DV || (s / 32) / 2 < vr.vrx; };
+    auto fits = [&](int v, int s) { return v < 0 || (vr.usable((s / 32) / 2) && c.col_ptr[v + 1] - c.col_ptr[v] <= vr.width((s / 32) / 2)); };
     std::vector<int> edge_vj(E);  // canonical index of edge k in its variable's list
     for (int v = 0; v < n; ++v)
         for (int p = c.col_ptr[v]; p < c.col_ptr[v + 1]; ++p) edge_vj[c.col_edge[p]] = p - c.col_ptr[v];
@@ -307,6 +311,7 @@ uint64_t layout_key(const Code& c, int DC, int CR, const VarRounds& vr, int NW) 
     uint64_t h = 0xcbf29ce484222325ull;
     const int32_t hdr[10] = {(int32_t)kPlannerVersion, c.m, c.n, DC, CR, vr.VR, vr.DV, vr.vrx, vr.dvx, NW};
     h = fnv(h, hdr, sizeof(hdr));
+    if (vr.reserved) h = fnv(h, &vr.reserved, sizeof(vr.reserved));
     h = fnv(h, c.edge_chk.data(), c.edge_chk.size() * sizeof(int32_t));
     h = fnv(h, c.edge_var.data(), c.edge_var.size() * sizeof(int32_t));
     return h;
@@ -322,7 +327,7 @@ bool layout_valid(const Code& c, int DC, int CR, const VarRounds& vr, const Fuse
     for (int v = 0; v < c.n; ++v) {
         const int s = L.var_slot[v];
         if (s < 0 || s >= vr.VR * 64 || seen_v[s]++) return false;
-        if (c.col_ptr[v + 1] - c.col_ptr[v] > vr.width(s / 64)) return false;
+        if (!vr.usable(s / 64) || c.col_ptr[v + 1] - c.col_ptr[v] > vr.width(s / 64)) return false;
     }
     for (int cc = 0; cc < c.m; ++cc) {  // positions inside a check: distinct, below DC
         unsigned mask = 0;

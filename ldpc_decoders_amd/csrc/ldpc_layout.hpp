@@ -35,13 +35,21 @@ struct FusedLayout {
     double base_cycles = 0;  // conflict-free LDS cycles of the gathers per sweep (one per half-wave instruction)
 };
 
-// Variable rounds come in two widths: the first `vrx` rounds gather `dvx` messages per variable ("wide" rounds, for the
-// high-degree variables of irregular codes), the remaining VR - vrx rounds gather DV.  vrx = 0 for regular codes.
+// Variable rounds come in two widths: each wave owns VR/nw consecutive rounds, the first `vrx` of them gather `dvx` messages
+// per variable ("wide" rounds, for the high-degree variables of irregular codes), the others gather DV.  vrx = 0 for regular
+// codes.  `reserved` trailing rounds hold no variables (the system row of the 16-wave shape, ldpc_fused.hip).
 struct VarRounds {
     int VR = 0, DV = 0, vrx = 0, dvx = 0;
-    int width(int q) const { return q < vrx ? dvx : DV; }
-    int first_gather(int q) const { return q < vrx ? q * dvx : vrx * dvx + (q - vrx) * DV; }  // index of (q, position 0)
-    int total_gathers() const { return vrx * dvx + (VR - vrx) * DV; }
+    int nw = 1, reserved = 0;
+    int vrw() const { return VR / nw; }
+    int per_wave() const { return vrx * dvx + (vrw() - vrx) * DV; }
+    int width(int q) const { return (q % vrw()) < vrx ? dvx : DV; }
+    int first_gather(int q) const {  // index of (q, position 0) in the frame's list of variable-phase gathers
+        const int w = q / vrw(), l = q % vrw();
+        return w * per_wave() + (l < vrx ? l * dvx : vrx * dvx + (l - vrx) * DV);
+    }
+    int total_gathers() const { return nw * per_wave(); }
+    bool usable(int q) const { return q < VR - reserved; }
 };
 
 // exact conflict model: sum over gather instructions and half-waves of (max distinct-address multiplicity - 1)

@@ -1,5 +1,5 @@
-"""Parity at the sizes of BASELINE.json configs 4 and 5 (streaming backend; the reference itself cannot run these: its H is
-dense, SURVEY.md 8(c) 'limits of the oracle').  Checker = the C oracle, pinned to the reference at n <= 2640."""
+"""Parity at the sizes of BASELINE.json configs 4 and 5 (the reference itself cannot run these: its H is dense, SURVEY.md 8(c)
+'limits of the oracle').  Checker = the C oracle, pinned to the reference at n <= 2640."""
 import numpy as np
 import pytest
 
@@ -20,19 +20,56 @@ def _noise(rng, B, n, snr):
 
 
 def test_config4_irregular_n10000_msa():
-    # rate-1/2 irregular ensemble of src/ldpc.py (lambda from its LP design, rho = x^5), n = 10 000, min-sum
+    # rate-1/2 irregular ensemble of src/ldpc.py (lambda from its LP design, rho = x^5), n = 10 000, min-sum: the streaming
+    # backend (fp32 / fp64) and the 16-wave LDS-resident kernel (fp32, one frame per CU) against the C oracle
     from ldpc_decoders_amd import bpa, codes
 
     code = codes.rand_irregular_ldpc(10000, codes.LAMBDA_RHO_X5_HALF_RATE, 6, np.random.RandomState(4))
     assert code.n == 10000 and code.col_degrees().max() == 8 and set(np.unique(code.row_degrees())) <= {2, 4, 6}
-    pri = _noise(np.random.RandomState(1), 192, code.n, 1.2)
-    for prec, dt in (("f32", np.float32), ("f64", np.float64)):
-        dec = bpa.MSA(code, max_iter=50, precision=prec)
+    pri = _noise(np.random.RandomState(1), 192, code.n, 1.6)
+    for prec, dt, backend, used in (("f32", np.float32, "stream", "stream"), ("f64", np.float64, "auto", "stream"),
+                                    ("f32", np.float32, "auto", "fused")):
+        dec = bpa.MSA(code, max_iter=50, precision=prec, backend=backend)
         xhat, iters = dec.decode_batch(None, pri.astype(dt))
         xo, io = C.bp_decode(_G(code), "MSA", None, pri.astype(dt), 50, dtype=dt)
-        assert dec.handle.last_stats()[0] == "stream"
+        assert dec.handle.last_stats()[0] == used
         assert (xhat == xo).all() and (iters == io).all()
-        assert 1 < iters.mean() < 50  # early termination active, both converging and failing frames present
+        assert 1 < iters.mean() < 50 and (iters < 50).any() and (iters == 50).any()  # converging and failing frames present
+    info = dec.handle.fused_info()
+    assert info["waves_per_frame"] == 16 and info["lds_bytes_per_frame"] == 160 * 1024
+
+
+def test_config4_fused_erasure_sum_product_and_simulate():
+    # the other decoders of the 16-wave shape: erasure decoder (exact vs the C oracle, stopping sets included), sum-product
+    # (same arithmetic as the streaming kernels), and the fused simulate kernels (noise + decode + count) vs the streaming path
+    import torch
+    from ldpc_decoders_amd import bec, bpa, codes
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    code = codes.rand_irregular_ldpc(10000, codes.LAMBDA_RHO_X5_HALF_RATE, 6, np.random.RandomState(4))
+    rng = np.random.RandomState(3)
+    ye = (rng.random_sample((130, code.n)) < 0.44).astype(np.int64) * 2
+    ye[:3, :] = np.where(ye[:3, :] == 0, 1, 2)  # a few frames of the all-one word
+    ye[3] = 0
+    for mi in (50, 3):
+        dec = bec.SPA(0.44, code, max_iter=mi, backend="fused")
+        xe, ie = dec.decode_batch(ye)
+        xo, io = C.bec_decode(_G(code), ye, mi)
+        assert dec.handle.last_stats()[0] == "fused" and (xe == xo).all() and (ie == io).all()
+    assert (ie[:50] < 50).any()
+    pri = _noise(rng, 130, code.n, 1.7).astype(np.float32)
+    a, ia = bpa.SPA(code, max_iter=50, precision="f32", backend="fused").decode_batch(None, pri)
+    b, ib = bpa.SPA(code, max_iter=50, precision="f32", backend="stream").decode_batch(None, pri)
+    assert ((a == b).all(axis=1)).mean() >= 0.97 and (ia == ib).mean() >= 0.97
+    for alg, ch, prm in (("MSA", "biawgn", 1.6), ("BEC", "bec", 0.44), ("MSA", "bsc", 0.06)):
+        res = []
+        for be in ("fused", "stream"):
+            h = DecoderHandle(code, alg, "f32", be)
+            cnt = torch.zeros(4 + 51, dtype=torch.int64, device="cuda")
+            h.simulate(ch, prm, 0, 7, 1, 1000, 300, 50, cnt, hist_bins=51)
+            assert h.last_stats()[0] == be
+            res.append(cnt.cpu().numpy())
+        assert (res[0] == res[1]).all() and res[0][0] == 300 and 0 < res[0][1] < 300
 
 
 def test_config5_regular_n64800_msa_early_termination():

@@ -11,15 +11,21 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CODES = ["1200_3_6_rand_ldpc_1", "1200_3_6_ldpc", "512_3_6_rand_ldpc_2", "1200_rho_x5_rand_ldpc_5", "margulis"]
+CODES = ["1200_3_6_rand_ldpc_1", "1200_3_6_ldpc", "512_3_6_rand_ldpc_2", "1200_rho_x5_rand_ldpc_5", "margulis", "gen:irg:10000"]
 
 CHILD = r"""
 import os, sys, time
 sys.path.insert(0, %(root)r)
 from ldpc_decoders_amd import codes
 from ldpc_decoders_amd._device import DecoderHandle
+from bench import load_code
 t0 = time.time()
-h = DecoderHandle(codes.get_code(%(code)r), "MSA", "f32", "fused")
+code = load_code(%(code)r)[1] if %(code)r.startswith("gen:") else codes.get_code(%(code)r)  # gen:reg:<n>:<l>:<r> / gen:irg:<n> as in bench.py
+try:
+    h = DecoderHandle(code, "MSA", "f32", "fused")
+except Exception as e:  # no fused shape for this (code, LDPC_FUSED_NW): nothing to plan
+    print(%(code)r, "nw", os.environ.get("LDPC_FUSED_NW", "auto"), "skipped:", e, flush=True)
+    sys.exit(0)
 print(%(code)r, "nw", os.environ.get("LDPC_FUSED_NW", "auto"), "%%.0fs" %% (time.time() - t0), h.fused_info(), flush=True)
 """
 
