@@ -39,6 +39,25 @@ def test_config4_irregular_n10000_msa():
     assert info["waves_per_frame"] == 16 and info["lds_bytes_per_frame"] == 160 * 1024
 
 
+def test_config4_fused_layout_independent(monkeypatch):
+    # the trivial placement and a short annealing run give the same bits as the stored plan (placement only moves data)
+    from ldpc_decoders_amd import bpa, codes
+
+    code = codes.rand_irregular_ldpc(10000, codes.LAMBDA_RHO_X5_HALF_RATE, 6, np.random.RandomState(4))
+    pri = _noise(np.random.RandomState(5), 70, code.n, 1.6).astype(np.float32)
+    xo, io = C.bp_decode(_G(code), "MSA", None, pri, 30, dtype=np.float32)
+    seen = []
+    for layout, moves in (("identity", None), ("replan", "300000")):
+        monkeypatch.setenv("LDPC_FUSED_LAYOUT", layout)
+        if moves:
+            monkeypatch.setenv("LDPC_FUSED_PLAN_MOVES", moves)
+        dec = bpa.MSA(code, max_iter=30, precision="f32", backend="fused")
+        xhat, iters = dec.decode_batch(None, pri)
+        assert (xhat == xo).all() and (iters == io).all()
+        seen.append(dec.handle.fused_info()["conflict_cycles_planned"])
+    assert seen[0] > seen[1] > 0
+
+
 def test_config4_fused_erasure_sum_product_and_simulate():
     # the other decoders of the 16-wave shape: erasure decoder (exact vs the C oracle, stopping sets included), sum-product
     # (same arithmetic as the streaming kernels), and the fused simulate kernels (noise + decode + count) vs the streaming path
