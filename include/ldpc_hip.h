@@ -126,6 +126,21 @@ int ldpc_ml_decode(ldpc_ml_t ml, int channel, int dtype, const double* coef2, co
 int ldpc_ml_simulate(ldpc_ml_t ml, int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id,
                      uint64_t frame0, int64_t B, int64_t* counters_dev, void* stream);
 
+/* ---- ADMM LP decoding ------------------------------------------------------------------------------------------
+ * Replaces admm.ADMM (src/admm.py:9-77) together with its native projection (src/parity_polytope/projection.cpp:30-275, bound
+ * upstream through ctypes in exact.py:12-53).  Check degrees up to 16. */
+typedef struct ldpc_admm_s* ldpc_admm_t;
+int ldpc_admm_create(ldpc_code_t code, ldpc_admm_t* out);
+int ldpc_admm_destroy(ldpc_admm_t admm);
+/* ADMM_Base.decode(y, gamma) for B frames (src/admm.py:42-69).  gamma_dev [B,n] double: the LLR vectors the channel wrappers
+ * hand over (src/biawgn.py:28, src/bsc.py:25, src/bec.py:38-45).  mu, eps, max_iter: the constructor's kwargs (max_iter <= 0 =
+ * no cap upstream; bounded at 100000 here).  x_dev [B,n] double out: x_hat as it stands at return, BEFORE
+ * math_utils.pseudo_to_cw (src/math_utils.py:28-34); iters_dev [B] int32: iter_count at return (the bin upstream's histogram
+ * increments, src/admm.py:49); converged_dev [B] uint8 or NULL: 1 where the stopping test fired.  fp64 throughout, in the
+ * upstream operation order: results are bit-identical to upstream's for the same gamma. */
+int ldpc_admm_decode(ldpc_admm_t admm, const double* gamma_dev, int64_t B, double mu, double eps, int32_t max_iter, double* x_dev,
+                     int32_t* iters_dev, uint8_t* converged_dev, void* stream);
+
 /* Profiling aid: coalesced 4-byte-per-lane device copy of a known size, used to calibrate the profiler's HBM byte
  * counters for the access width of the streaming kernels. */
 int ldpc_debug_copy4(const void* src_dev, void* dst_dev, int64_t nbytes, void* stream);

@@ -233,3 +233,38 @@ class MlHandle:
         st = torch.cuda.current_stream(counters.device).cuda_stream
         _lib.check(_lib.load().ldpc_ml_simulate(self.h, _lib.CHANNEL[channel], _lib.DTYPE[self.precision], float(param), int(codeword),
                                                 int(seed), int(stream_id), int(frame0), int(B), counters.data_ptr(), st))
+
+
+class AdmmHandle:
+    """ADMM LP decoder workspace on one GPU (``ldpc_admm_*``)."""
+
+    def __init__(self, code, device=None):
+        lib = _lib.load()
+        self.code_handle = code_handle(code, device)
+        self.code = code
+        h = ctypes.c_void_p()
+        _lib.check(lib.ldpc_admm_create(self.code_handle.h, ctypes.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.load().ldpc_admm_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def decode_device(self, gamma, mu, eps, max_iter):
+        """gamma: contiguous CUDA float64 [B,n] -> (x float64 [B,n] before pseudo_to_cw, iters int32 [B], converged uint8 [B])."""
+        import torch
+
+        if not gamma.is_cuda or gamma.dtype != torch.float64 or not gamma.is_contiguous() or gamma.shape[1] != self.code.n:
+            raise ValueError("gamma must be a contiguous CUDA float64 tensor [B,%d]" % self.code.n)
+        B = gamma.shape[0]
+        x = torch.empty_like(gamma)
+        iters = torch.empty(B, dtype=torch.int32, device=gamma.device)
+        conv = torch.empty(B, dtype=torch.uint8, device=gamma.device)
+        st = torch.cuda.current_stream(gamma.device).cuda_stream
+        _lib.check(_lib.load().ldpc_admm_decode(self.h, gamma.data_ptr(), B, float(mu), float(eps), int(max_iter), x.data_ptr(),
+                                                iters.data_ptr(), conv.data_ptr(), st))
+        return x, iters, conv

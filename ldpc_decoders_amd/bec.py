@@ -5,6 +5,7 @@ the stopping-set exit of src/bec.py:120; symbols are {0, 1, 2 = erased}.
 """
 import numpy as np
 
+from . import admm
 from ._device import DecoderHandle, as_code
 
 
@@ -48,6 +49,22 @@ class SPA:
 
 class MSA(SPA):
     pass
+
+
+class ADMM:  # src/bec.py:38-45,58-62: LLR wrapper with +-1e8 for the known symbols, 0 for an erasure
+    id_keys = admm.ADMM.id_keys
+    channel = "bec"
+
+    def __init__(self, p, _code, **kwargs):
+        self.param, self.dec, safe_inf = p, admm.ADMM(_code, **kwargs), 1e8
+        self.llr = np.array([safe_inf, -safe_inf, 0])  # 0 WP1, 1 WP1, 0 OR 1 WP0.5
+        self.stats = self.dec.stats
+
+    def decode(self, y):
+        return self.dec.decode(y, self.llr[np.asarray(y)])
+
+    def decode_batch(self, y):
+        return self.dec.decode_batch(self.llr[np.asarray(y)])
 
 
 from .ml import BecML as ML  # noqa: E402  (src/bec.py: class ML)

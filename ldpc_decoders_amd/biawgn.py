@@ -1,7 +1,7 @@
 """BI-AWGN channel and its LLR decoders -- mirror of the reference's ``src/biawgn.py:10-42``."""
 import numpy as np
 
-from . import bpa
+from . import admm, bpa
 
 noise_var = lambda snr_in_db: 10 ** (-snr_in_db / 10)  # noqa: E731  (src/biawgn.py:10)
 
@@ -45,6 +45,17 @@ class MSA(LLR):
 
     def __init__(self, snr_in_db, _code, **kwargs):
         super().__init__(snr_in_db, bpa.MSA(_code, **kwargs))
+
+
+class ADMM(LLR):  # src/biawgn.py:52-56
+    id_keys = admm.ADMM.id_keys
+
+    def __init__(self, snr_in_db, _code, **kwargs):
+        super().__init__(snr_in_db, admm.ADMM(_code, **kwargs))
+        self.stats = self.dec.stats
+
+    def decode_batch(self, y):
+        return self.dec.decode_batch(self.priors(np.asarray(y)))
 
 
 from .ml import BiawgnML as ML  # noqa: E402  (src/biawgn.py: class ML)

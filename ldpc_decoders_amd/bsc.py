@@ -1,7 +1,7 @@
 """Binary symmetric channel and its LLR decoders -- mirror of the reference's ``src/bsc.py:11-39``."""
 import numpy as np
 
-from . import bpa
+from . import admm, bpa
 
 
 class Channel:
@@ -47,6 +47,17 @@ class MSA(LLR):
 
     def __init__(self, p, _code, **kwargs):
         super().__init__(p, bpa.MSA(_code, **kwargs))
+
+
+class ADMM(LLR):  # src/bsc.py:49-53
+    id_keys = admm.ADMM.id_keys
+
+    def __init__(self, p, _code, **kwargs):
+        super().__init__(p, admm.ADMM(_code, **kwargs))
+        self.stats = self.dec.stats
+
+    def decode_batch(self, y):
+        return self.dec.decode_batch(self.priors(np.asarray(y)))
 
 
 from .ml import BscML as ML  # noqa: E402  (src/bsc.py: class ML)

@@ -1,0 +1,443 @@
+// ADMM LP decoding (Barman, Liu, Draper, Recht: "Decomposition methods for large scale LP decoding") on the GPU -- the
+// batched counterpart of the reference's ADMM class:
+//
+//   iteration, stopping rule, iteration counter ... reference src/admm.py:42-69, 17-23
+//   projection onto the parity polytope ........... reference src/parity_polytope/projection.cpp:30-249 (its only native code)
+//
+// Layout as in the streaming BP backend: tiles of 64 frames, lane == frame, every array [tile][index][64] in HBM, every
+// graph index wave-uniform.  All arithmetic is fp64 in the reference's operation order -- column sums from +0.0 in ascending
+// edge order (scipy COO), divisions kept as divisions, the two stopping sums in numpy's pairwise order (np_sum below), the
+// projection with the same stable decreasing sort and water-filling steps -- so estimates and iteration counts are
+// bit-identical to the reference's (golden vectors, tests/test_gpu_admm.py).  oracle/admm_oracle.c is the CPU statement.
+#include "ldpc_common.hpp"
+
+#include <new>
+#include <vector>
+
+namespace ldpc {
+
+struct AdmmDecoder {
+    Code* code = nullptr;
+    DevBuf z, lam, d1, d2, x, gam, live, flags, part;
+    int32_t* d_leaf_off = nullptr;  // numpy's summation blocks of a length-E vector
+    int32_t* d_leaf_len = nullptr;
+    int32_t* d_prog = nullptr;      // stack program folding the block sums (see k_admm_test)
+    int leaves = 0, prog_len = 0;
+    void* pinned = nullptr;
+    int last_iters = 0;
+};
+
+namespace {
+
+using u64 = unsigned long long;
+constexpr int PP_MAX = 16;  // std::sort is a stable insertion sort up to 16 elements
+
+__device__ __forceinline__ double clamp01(double x) {
+    const double lo = (x < 0.0) ? 0.0 : x;
+    return (1.0 < lo) ? 1.0 : lo;
+}
+
+// Euclidean projection onto the parity polytope; v is overwritten with the result.  Same steps as oracle_pp_project.
+template <int DCM>
+__device__ void pp_project(double (&v)[DCM], int len) {
+    bool none_positive = true, all_above_one = true;
+    for (int i = 0; i < len; ++i) {
+        if (v[i] > 0) none_positive = false;
+        if (v[i] <= 1) all_above_one = false;
+    }
+    if (none_positive) {
+        for (int i = 0; i < len; ++i) v[i] = 0;
+        return;
+    }
+    if (all_above_one && len % 2 == 0) {
+        for (int i = 0; i < len; ++i) v[i] = 1;
+        return;
+    }
+    double s[DCM];
+    int who[DCM];
+    for (int i = 0; i < len; ++i) {  // stable insertion sort, decreasing
+        const double val = v[i];
+        int j = i;
+        while (j > 0 && val > s[j - 1]) {
+            s[j] = s[j - 1];
+            who[j] = who[j - 1];
+            --j;
+        }
+        s[j] = val;
+        who[j] = i;
+    }
+    double c[DCM], mass = 0;
+    for (int i = 0; i < len; ++i) {
+        c[i] = clamp01(s[i]);
+        mass += c[i];
+    }
+    int r = (int)floor(mass);
+    if (r & 1) --r;
+    double facet = 0;
+    for (int i = 0; i < r + 1; ++i) facet += c[i];
+    for (int i = r + 1; i < len; ++i) facet -= c[i];
+    if (facet <= r) {
+        for (int i = 0; i < len; ++i) v[who[i]] = c[i];
+        return;
+    }
+    const double beta_cap = (r + 2 <= len) ? (s[r] - s[r + 1]) / 2 : s[r];
+    double bp[DCM];
+    int bp_who[DCM];
+    {
+        int L = r, R = r + 1, k = 0;
+        while (k < len) {
+            if (L < 0) {
+                for (; k < len; ++k, ++R) { bp_who[k] = R; bp[k] = -s[R]; }
+                break;
+            }
+            if (R >= len) {
+                for (; k < len; ++k, --L) { bp_who[k] = L; bp[k] = s[L] - 1; }
+                break;
+            }
+            const double a = s[L] - 1, b = -s[R];
+            if (a > b) { bp_who[k] = R; bp[k] = b; ++R; } else { bp_who[k] = L; bp[k] = a; --L; }
+            ++k;
+        }
+    }
+    const double tol = 1e-10;
+    int clip = -1, zero = 0, first = 0, last = -1;
+    for (int i = 0; i < len; ++i) {
+        if (s[i] > 1) ++clip;
+        if (s[i] >= 0 - tol) ++zero;
+        if (bp[i] < 0 + tol) ++first;
+        if (bp[i] < beta_cap) ++last;
+    }
+    double active = 0;
+    for (int i = 0; i < len; ++i) {
+        if (i > clip && i <= r) active += s[i];
+        if (i > r && i < zero) active -= s[i];
+    }
+    double total = active + clip + 1;
+    int prev_clip = clip, prev_zero = zero;
+    bool fresh = true;
+    double prev_active = active, beta = 0;
+    for (int i = first; i <= last; ++i) {
+        if (fresh) {
+            prev_clip = clip;
+            prev_zero = zero;
+            prev_active = active;
+        }
+        fresh = false;
+        beta = bp[i];
+        if (bp_who[i] <= r) {
+            --clip;
+            active += s[bp_who[i]];
+        } else {
+            ++zero;
+            active -= s[bp_who[i]];
+        }
+        if (i < len - 1) {
+            if (beta != bp[i + 1]) {
+                total = (clip + 1) + active - beta * (zero - clip - 1);
+                fresh = true;
+                if (total < r) break;
+            }
+        } else if (i == len - 1) {
+            total = (clip + 1) + active - beta * (zero - clip - 1);
+            fresh = true;
+        }
+    }
+    if (total > r)
+        beta = -(r - clip - 1 - active) / (zero - clip - 1);
+    else
+        beta = -(r - prev_clip - 1 - prev_active) / (prev_zero - prev_clip - 1);
+    for (int i = 0; i < len; ++i) v[who[i]] = clamp01(i <= r ? s[i] - beta : s[i] + beta);
+}
+
+// gamma [B,n] -> gam[tile][n][64]; state: z = 0.5, lambda = 0 (src/admm.py:44)
+__global__ __launch_bounds__(256) void k_admm_init(const double* __restrict__ gamma, int64_t B, int n, int64_t E, double* __restrict__ gam,
+                                                   double* __restrict__ z, double* __restrict__ lam, double* __restrict__ x) {
+    const int tile = blockIdx.y, lane = threadIdx.x & 63;
+    const int64_t fr = (int64_t)tile * 64 + lane;
+    for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < E; k += (int64_t)gridDim.x * 4) {
+        z[((int64_t)tile * E + k) * 64 + lane] = 0.5;
+        lam[((int64_t)tile * E + k) * 64 + lane] = 0.0;
+    }
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < n; v += gridDim.x * 4) {
+        gam[((int64_t)tile * n + v) * 64 + lane] = fr < B ? gamma[fr * n + v] : 0.0;
+        x[((int64_t)tile * n + v) * 64 + lane] = 0.0;
+    }
+}
+
+__global__ void k_admm_live(u64* __restrict__ live, int64_t B, int tiles) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    const int64_t rem = B - (int64_t)t * 64;
+    live[t] = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+}
+
+// x update (src/admm.py:54-55): clip((sum_cols(z - lambda/mu) - gamma/mu) / var_deg, 0, 1)
+__global__ __launch_bounds__(256) void k_admm_x(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ col_edge,
+                                                const double* __restrict__ z, const double* __restrict__ lam, const double* __restrict__ gam,
+                                                double* __restrict__ x, const u64* __restrict__ live, int n, int64_t E, int tiles, double mu) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    const u64 lv = live[tile];
+    if (lv == 0 || !((lv >> lane) & 1ull)) return;
+    const double* zt = z + (int64_t)tile * E * 64 + lane;
+    const double* lt = lam + (int64_t)tile * E * 64 + lane;
+    for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < n; v += gridDim.x * 4) {
+        const int p0 = col_ptr[v], p1 = col_ptr[v + 1];
+        double s = 0.0;
+        for (int p = p0; p < p1; ++p) {
+            const int64_t k = col_edge[p];
+            s += zt[k * 64] - lt[k * 64] / mu;
+        }
+        const int64_t o = ((int64_t)tile * n + v) * 64 + lane;
+        x[o] = clamp01((s - gam[o] / mu) / (double)(p1 - p0));
+    }
+}
+
+// z and lambda updates (src/admm.py:58-63) + the two squared-distance vectors of the stopping test (src/admm.py:18-19)
+template <int DCM>
+__global__ __launch_bounds__(256) void k_admm_z(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
+                                                double* __restrict__ z, double* __restrict__ lam, const double* __restrict__ x,
+                                                double* __restrict__ d1, double* __restrict__ d2, const u64* __restrict__ live, int m, int n,
+                                                int64_t E, double mu) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    const u64 lv = live[tile];
+    if (lv == 0 || !((lv >> lane) & 1ull)) return;
+    const int64_t eb = (int64_t)tile * E * 64 + lane;
+    const double* xt = x + (int64_t)tile * n * 64 + lane;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < m; c += gridDim.x * 4) {
+        const int k0 = row_ptr[c], len = row_ptr[c + 1] - k0;
+        double v[DCM], xs[DCM], lm[DCM];
+        for (int j = 0; j < len; ++j) {
+            xs[j] = xt[(int64_t)edge_var[k0 + j] * 64];
+            lm[j] = lam[eb + (int64_t)(k0 + j) * 64];
+            v[j] = xs[j] + lm[j] / mu;
+        }
+        pp_project<DCM>(v, len);
+        for (int j = 0; j < len; ++j) {
+            const int64_t o = eb + (int64_t)(k0 + j) * 64;
+            const double zo = z[o];
+            lam[o] = lm[j] + mu * (xs[j] - v[j]);
+            const double a = xs[j] - v[j], b = zo - v[j];
+            d1[o] = a * a;
+            d2[o] = b * b;
+            z[o] = v[j];
+        }
+    }
+}
+
+// numpy's pairwise sum of the E squared distances (np.add.reduce of a contiguous float64 vector): the vector is split
+// recursively (n2 = n/2 rounded down to a multiple of 8) down to blocks of at most 128 elements, each block is summed with 8
+// strided accumulators, and the block sums are added back up the split tree.  The blocks are independent, so they are summed
+// by one wave each (k_admm_leaves); the tree is then folded by a tiny stack program built on the host (k_admm_test):
+// op >= 0: push the sum of block `op`; op == -1: pop b, pop a, push a + b.
+__device__ double np_block(const double* a, int n) {  // n <= 128, element stride 64 doubles
+    double res;
+    if (n < 8) {
+        res = -0.0;
+        for (int i = 0; i < n; ++i) res += a[(int64_t)i * 64];
+    } else {
+        double r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = a[(int64_t)k * 64];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] += a[(int64_t)(i + k) * 64];
+        }
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[(int64_t)i * 64];
+    }
+    return res;
+}
+
+__global__ __launch_bounds__(256) void k_admm_leaves(const double* __restrict__ d1, const double* __restrict__ d2,
+                                                     const int32_t* __restrict__ leaf_off, const int32_t* __restrict__ leaf_len, int leaves,
+                                                     double* __restrict__ part, const u64* __restrict__ live, int64_t E) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    const u64 lv = live[tile];
+    if (lv == 0 || !((lv >> lane) & 1ull)) return;
+    const int leaf = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (leaf >= leaves) return;
+    const int64_t base = ((int64_t)tile * E + leaf_off[leaf]) * 64 + lane;
+    double* o = part + ((int64_t)tile * leaves + leaf) * 128 + lane;
+    o[0] = np_block(d1 + base, leaf_len[leaf]);
+    o[64] = np_block(d2 + base, leaf_len[leaf]);
+}
+
+// stopping test (src/admm.py:21, 65) and the max_iter exit of the next loop head (src/admm.py:51); one wave per tile
+__global__ __launch_bounds__(64) void k_admm_test(const double* __restrict__ part, const int32_t* __restrict__ prog, int prog_len, int leaves,
+                                                  u64* __restrict__ live, int32_t* __restrict__ iters, uint8_t* __restrict__ converged,
+                                                  int* __restrict__ live_tiles, int64_t B, double thresh, int it, int max_iter) {
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const u64 lv = live[tile];
+    if (lv == 0) return;
+    const bool on = (lv >> lane) & 1ull;
+    bool close = false;
+    if (on) {
+        const double* p = part + (int64_t)tile * leaves * 128 + lane;
+        double s1[40], s2[40];
+        int sp = 0;
+        for (int i = 0; i < prog_len; ++i) {
+            const int op = prog[i];
+            if (op >= 0) {
+                s1[sp] = p[(int64_t)op * 128];
+                s2[sp] = p[(int64_t)op * 128 + 64];
+                ++sp;
+            } else {
+                --sp;
+                s1[sp - 1] = s1[sp - 1] + s1[sp];
+                s2[sp - 1] = s2[sp - 1] + s2[sp];
+            }
+        }
+        const double aa1 = 0.0 + s1[0], aa2 = 0.0 + s2[0];
+        close = aa1 < thresh && aa2 < thresh;
+    }
+    const bool capped = max_iter > 0 && it + 1 >= max_iter;
+    const int64_t fr = (int64_t)tile * 64 + lane;
+    if (on && fr < B) {
+        if (close) {
+            iters[fr] = it;
+            if (converged) converged[fr] = 1;
+        } else if (capped) {
+            iters[fr] = it + 1;
+        }
+    }
+    const u64 leave = capped ? lv : __ballot(on && close);
+    const u64 stay = lv & ~leave;
+    if (lane == 0) {
+        live[tile] = stay;
+        if (stay && live_tiles) atomicAdd(live_tiles, 1);
+    }
+}
+
+__global__ void k_admm_out(const double* __restrict__ x, double* __restrict__ out, int64_t B, int n) {
+    const int tile = blockIdx.y, lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t fr = (int64_t)tile * 64 + lane;
+    if (v < n && fr < B) out[fr * n + v] = x[((int64_t)tile * n + v) * 64 + lane];
+}
+
+}  // namespace
+
+int admm_create(Code* code, AdmmDecoder** out) {
+    if (!code || !out) return LDPC_E_ARG;
+    if (code->max_dc > PP_MAX) {
+        set_error("ADMM: check degree %d above %d (the projection's sort order is only defined up to there)", code->max_dc, PP_MAX);
+        return LDPC_E_UNSUPPORTED;
+    }
+    AdmmDecoder* d = new (std::nothrow) AdmmDecoder();
+    if (!d) return LDPC_E_NOMEM;
+    d->code = code;
+    std::vector<int32_t> off, len, prog;
+    struct Split {
+        static void run(int64_t o, int64_t n, std::vector<int32_t>& off, std::vector<int32_t>& len, std::vector<int32_t>& prog) {
+            if (n <= 128) {
+                prog.push_back((int32_t)off.size());
+                off.push_back((int32_t)o);
+                len.push_back((int32_t)n);
+                return;
+            }
+            int64_t n2 = n / 2;
+            n2 -= n2 % 8;
+            run(o, n2, off, len, prog);
+            run(o + n2, n - n2, off, len, prog);
+            prog.push_back(-1);
+        }
+    };
+    Split::run(0, code->E, off, len, prog);
+    d->leaves = (int)off.size();
+    d->prog_len = (int)prog.size();
+    hipError_t e = hipSetDevice(code->device);
+    if (e == hipSuccess) e = hipHostMalloc(&d->pinned, 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->d_leaf_off, off.size() * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->d_leaf_len, len.size() * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->d_prog, prog.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(d->d_leaf_off, off.data(), off.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d->d_leaf_len, len.data(), len.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d->d_prog, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("admm_create: %s", hipGetErrorString(e));
+        delete d;
+        return LDPC_E_HIP;
+    }
+    *out = d;
+    return LDPC_OK;
+}
+
+void admm_destroy(AdmmDecoder* d) {
+    if (!d) return;
+    for (DevBuf* b : {&d->z, &d->lam, &d->d1, &d->d2, &d->x, &d->gam, &d->live, &d->flags, &d->part}) b->release();
+    for (void* q : {(void*)d->d_leaf_off, (void*)d->d_leaf_len, (void*)d->d_prog})
+        if (q) (void)hipFree(q);
+    if (d->pinned) (void)hipHostFree(d->pinned);
+    delete d;
+}
+
+int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, double eps, int32_t max_iter, double* x_out, int32_t* iters,
+                uint8_t* converged, hipStream_t st) {
+    if (B <= 0) return LDPC_OK;
+    const Code* c = d->code;
+    const int n = c->n, m = c->m;
+    const int64_t E = c->E;
+    if (B > (int64_t)65535 * 64) {
+        set_error("ADMM: at most %d frames per call", 65535 * 64);
+        return LDPC_E_ARG;
+    }
+    if (!(mu > 0.0)) {
+        set_error("ADMM: mu must be positive");
+        return LDPC_E_ARG;
+    }
+    LDPC_HIP_TRY(hipSetDevice(c->device));
+    const int tiles = (int)((B + 63) / 64);
+    const size_t es = (size_t)tiles * E * 64 * sizeof(double), vs = (size_t)tiles * n * 64 * sizeof(double);
+    LDPC_TRY(d->z.reserve(es));
+    LDPC_TRY(d->lam.reserve(es));
+    LDPC_TRY(d->d1.reserve(es));
+    LDPC_TRY(d->d2.reserve(es));
+    LDPC_TRY(d->x.reserve(vs));
+    LDPC_TRY(d->gam.reserve(vs));
+    LDPC_TRY(d->live.reserve((size_t)tiles * 8));
+    LDPC_TRY(d->flags.reserve(64));
+    LDPC_TRY(d->part.reserve((size_t)tiles * d->leaves * 128 * sizeof(double)));
+    double *z = (double*)d->z.p, *lam = (double*)d->lam.p, *d1 = (double*)d->d1.p, *d2 = (double*)d->d2.p, *x = (double*)d->x.p,
+           *gam = (double*)d->gam.p;
+    u64* live = (u64*)d->live.p;
+    int* live_tiles = (int*)d->flags.p;
+    int* h_poll = (int*)d->pinned;
+    LDPC_HIP_TRY(hipMemsetAsync(iters, 0, (size_t)B * sizeof(int32_t), st));
+    if (converged) LDPC_HIP_TRY(hipMemsetAsync(converged, 0, (size_t)B, st));
+    const unsigned gx = 256;
+    hipLaunchKernelGGL(k_admm_init, dim3(gx, tiles), dim3(256), 0, st, gamma, B, n, E, gam, z, lam, x);
+    hipLaunchKernelGGL(k_admm_live, dim3((tiles + 255) / 256), dim3(256), 0, st, live, B, tiles);
+    const double thresh = (eps * eps) * (double)E;  // (eps ** 2) * parity_mtx.sum()   (src/admm.py:14)
+    const int cap = max_iter > 0 ? max_iter : 100000;  // max_iter <= 0: no cap upstream (src/admm.py:51); bounded here
+    const unsigned gv = (unsigned)((n + 3) / 4 < 512 ? (n + 3) / 4 : 512), gc = (unsigned)((m + 3) / 4 < 512 ? (m + 3) / 4 : 512);
+    int done = 0;
+    for (int it = 0; it < cap; ++it) {
+        hipLaunchKernelGGL(k_admm_x, dim3(gv, tiles), dim3(256), 0, st, c->d_col_ptr, c->d_col_edge, z, lam, gam, x, live, n, E, tiles, mu);
+        if (c->max_dc <= 8)
+            hipLaunchKernelGGL((k_admm_z<8>), dim3(gc, tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
+        else
+            hipLaunchKernelGGL((k_admm_z<16>), dim3(gc, tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
+        const bool poll = (it % 8) == 7 || it + 1 == cap;
+        if (poll) LDPC_HIP_TRY(hipMemsetAsync(live_tiles, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_admm_leaves, dim3((d->leaves + 3) / 4, tiles), dim3(256), 0, st, d1, d2, d->d_leaf_off, d->d_leaf_len, d->leaves,
+                           (double*)d->part.p, live, E);
+        hipLaunchKernelGGL(k_admm_test, dim3(tiles), dim3(64), 0, st, (const double*)d->part.p, d->d_prog, d->prog_len, d->leaves, live, iters,
+                           converged, poll ? live_tiles : nullptr, B, thresh, it, it + 1 == cap ? it + 1 : max_iter);
+        done = it + 1;
+        if (poll) {
+            LDPC_HIP_TRY(hipMemcpyAsync(h_poll, live_tiles, sizeof(int), hipMemcpyDeviceToHost, st));
+            LDPC_HIP_TRY(hipStreamSynchronize(st));
+            if (*h_poll == 0) break;
+        }
+    }
+    hipLaunchKernelGGL(k_admm_out, dim3((n + 3) / 4, tiles), dim3(256), 0, st, x, x_out, B, n);
+    LDPC_HIP_TRY(hipGetLastError());
+    d->last_iters = done;
+    return LDPC_OK;
+}
+
+}  // namespace ldpc

@@ -434,4 +434,30 @@ int ldpc_ml_simulate(ldpc_ml_t h, int channel, int dtype, double param, int code
     return ml_simulate((MlDecoder*)h, channel, dtype, param, codeword, seed, stream_id, frame0, B, counters_dev, (hipStream_t)stream);
 }
 
+// ---- ADMM LP decoder (ldpc_admm.hip) ----
+int ldpc_admm_create(ldpc_code_t code, ldpc_admm_t* out) {
+    if (!code || !out) {
+        set_error("ldpc_admm_create: bad arguments");
+        return LDPC_E_ARG;
+    }
+    AdmmDecoder* d = nullptr;
+    LDPC_TRY(admm_create((Code*)code, &d));
+    *out = (ldpc_admm_t)d;
+    return LDPC_OK;
+}
+
+int ldpc_admm_destroy(ldpc_admm_t h) {
+    admm_destroy((AdmmDecoder*)h);
+    return LDPC_OK;
+}
+
+int ldpc_admm_decode(ldpc_admm_t h, const double* gamma_dev, int64_t B, double mu, double eps, int32_t max_iter, double* x_dev,
+                     int32_t* iters_dev, uint8_t* converged_dev, void* stream) {
+    if (!h || !gamma_dev || !x_dev || !iters_dev || B < 0) {
+        set_error("ldpc_admm_decode: bad arguments");
+        return LDPC_E_ARG;
+    }
+    return admm_decode((AdmmDecoder*)h, gamma_dev, B, mu, eps, max_iter, x_dev, iters_dev, converged_dev, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -135,6 +135,13 @@ int ml_decode(MlDecoder* d, int channel, int dtype, const double* coef, const vo
 int ml_simulate(MlDecoder* d, int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id,
                 uint64_t frame0, int64_t B, int64_t* counters, hipStream_t st);
 
+// ---- ADMM LP decoder (ldpc_admm.hip) -------------------------------------------------------------
+struct AdmmDecoder;
+int admm_create(Code* code, AdmmDecoder** out);
+void admm_destroy(AdmmDecoder* d);
+int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, double eps, int32_t max_iter, double* x_out, int32_t* iters,
+                uint8_t* converged, hipStream_t st);
+
 int debug_copy4(const void* src, void* dst, int64_t nbytes, hipStream_t st);
 
 constexpr uint32_t FLAG_NO_EARLY_EXIT = 1u;  // run exactly max_iter sweeps (NOT reference behaviour; benchmarking aid)

@@ -50,6 +50,9 @@ def test(args, comm=None):
             vals = [int(tot), int(wec), float(wer), int(bec), float(ber)]
             if comm.is_root:
                 log.info(", ".join("%s:%s" % (k.upper(), v) for k, v in zip(keys, vals)))
+            if hasattr(decoder, "stats"):  # e.g. the ADMM iteration histogram (src/main.py:34)
+                keys.append("dec"), vals.append(decoder.stats())
+            if comm.is_root:
                 saver.add(param, OrderedDict(zip(keys, vals)))
             return OrderedDict(zip(keys, vals))
 
@@ -58,7 +61,11 @@ def test(args, comm=None):
                 state["t"] = time.time()
                 log_status(dict(tot=tot, wec=wec, bec=bec))
 
-        if exact:
+        inner = decoder if hasattr(decoder, "handle") else getattr(decoder, "dec", None)
+        on_device = hasattr(getattr(inner, "handle", None), "simulate")  # BP and ML: channel + decode + count on the GPU
+        if not exact and not on_device and comm.world > 1:
+            raise SystemExit("decoder %s runs its Monte-Carlo loop on host noise and a single rank" % args.decoder)
+        if exact or not on_device:
             pick = None
             if args.codeword == -1:
                 pick = lambda: code.cb[np.random.choice(code.cb.shape[0], 1)[0]]  # noqa: E731  (src/main.py:38)
@@ -66,8 +73,11 @@ def test(args, comm=None):
             else:
                 x = np.zeros(code_n, dtype=np.int64) + args.codeword
             # one frame per call keeps numpy's stream in the reference's order (send, [ML pick], send, ..)
-            c = run_point_exact(channel, decoder, x, args.min_wec, chunk=1 if (code_n < 64 or args.decoder == "ML") else 32, on_progress=progress,
-                                pick_word=pick)
+            if exact:
+                chunk = 1 if (code_n < 64 or args.decoder in ("ML", "ADMM")) else 32
+            else:  # ADMM without --exact: host noise, frames decoded in batches (counters still stop at the first prefix)
+                chunk = max(1, min(args.batch, 4096))
+            c = run_point_exact(channel, decoder, x, args.min_wec, chunk=chunk, on_progress=progress, pick_word=pick)
         else:
             handle = decoder.handle if hasattr(decoder, "handle") else decoder.dec.handle
             if args.codeword not in (0, 1):

@@ -1,8 +1,8 @@
 """Decoder registry -- mirror of the reference's ``src/models.py:3`` / ``src/utils.py:16``.
 
 ``models[channel]`` is a module exposing ``Channel`` and the decoder classes; ``getattr(models[ch], name)`` selects
-one (src/main.py:11-12).  The BP decoders and the exhaustive ML decoder of the short codes are built for the GPU; the other upstream names
-(LP, ADMM, ADMMA) resolve to a class that raises on construction.
+one (src/main.py:11-12).  The BP decoders, the exhaustive ML decoder of the short codes and the ADMM LP decoder are built for the GPU; the other
+upstream names (LP, ADMMA) resolve to a class that raises on construction.
 """
 from . import bec, biawgn, bsc
 
@@ -15,7 +15,7 @@ def _unavailable(name):
 
         def __init__(self, *a, **k):
             raise NotImplementedError("decoder %s is outside the GPU belief-propagation path (SURVEY.md section 8); "
-                                      "use SPA, MSA or ML" % name)
+                                      "use SPA, MSA, ML or ADMM" % name)
 
     _Unavailable.__name__ = name
     return _Unavailable

@@ -1,0 +1,106 @@
+"""GPU parity tests of the ADMM LP decoder (ldpc_admm_decode through the C ABI): bit-identical estimates and iteration
+counts against vectors captured from the reference's ADMM class, against the C oracle on larger batches, and the
+reference's main.py counters in --exact mode."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import admm_oracle as A
+from helpers import GOLDEN
+from test_oracle_admm import admm_arrays, admm_cases, graph_of
+
+pytestmark = pytest.mark.gpu
+
+
+def _code(name):
+    from ldpc_decoders_amd import codes
+
+    os.environ.setdefault(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
+    return codes.get_code(name)
+
+
+@pytest.mark.parametrize("case", admm_cases(), ids=lambda c: "%s-%s-%s" % (c["channel"], c["code"], c["param"]))
+def test_admm_bit_exact_vs_reference(case, monkeypatch):
+    from ldpc_decoders_amd import admm, codes
+
+    monkeypatch.setenv(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
+    a = admm_arrays(case)
+    dec = admm.ADMM(codes.get_code(case["code"]), mu=case["mu"], eps=case["eps"], max_iter=case["max_iter"],
+                    allow_pseudo=case["allow_pseudo"], log_freq=5.0)  # unknown keywords are ignored, as upstream
+    est, iters = dec.decode_batch(a["gamma"])
+    assert np.array_equal(iters, a["iters"])
+    assert np.array_equal(np.asarray(est, dtype=np.float64), a["xhat"], equal_nan=True)
+    hist = np.bincount(a["iters"], minlength=2000)
+    assert dec.stats()["iter"] == hist.tolist() and dec.stats()["average"] == pytest.approx(a["iters"].mean())
+
+
+@pytest.mark.parametrize("case", [c for c in admm_cases() if c["code"] in ("7_4_hamming", "12_3_4_ldpc", "4_2_test")],
+                         ids=lambda c: "%s-%s-%s" % (c["channel"], c["code"], c["param"]))
+def test_registry_admm_replays_reference_sequence(case):
+    # reference: np.random.seed(s); per frame  Channel.send -> ADMM.decode  through models[channel]
+    from ldpc_decoders_amd import codes
+    from ldpc_decoders_amd.models import models
+
+    a = admm_arrays(case)
+    mod = models[case["channel"]]
+    code = codes.get_code(case["code"])
+    chan = mod.Channel(case["param"])
+    dec = mod.ADMM(case["param"], code, mu=case["mu"], eps=case["eps"], max_iter=case["max_iter"], allow_pseudo=case["allow_pseudo"])
+    assert dec.id_keys == ["mu", "eps", "max_iter", "allow_pseudo"]
+    x = np.zeros(code.get_n(), dtype=np.int64) + case["codeword"]
+    np.random.seed(case["seed"])
+    for f in range(60):
+        y = chan.send(x)
+        assert np.array_equal(np.asarray(y, dtype=np.float64), a["y"][f])
+        assert np.array_equal(np.asarray(dec.decode(y), dtype=np.float64), a["xhat"][f], equal_nan=True)
+
+
+def test_admm_batches_vs_c_oracle():
+    # ragged batch sizes, frames leaving at different iterations, max_iter <= 0 (no cap) on a small code
+    import torch
+    from ldpc_decoders_amd._device import AdmmHandle
+
+    rng = np.random.RandomState(4)
+    for name, B, snr, max_iter in (("1200_3_6_rand_ldpc_1", 130, 2.4, 150), ("512_3_6_rand_ldpc_2", 70, 2.6, 60), ("7_4_hamming", 1000, 2.0, -1),
+                                   ("1200_rho_x5_rand_ldpc_5", 40, 2.0, 120)):
+        code = _code(name)
+        g = graph_of(name)
+        gamma = -2 * (-1 + rng.normal(0, np.sqrt(10 ** (-snr / 10)), (B, code.n))) / 10 ** (-snr / 10)
+        xo, io, co = A.admm_decode(g, gamma, 3.0, 1e-5, max_iter)
+        h = AdmmHandle(code)
+        x, it, cv = h.decode_device(torch.from_numpy(gamma).cuda(), 3.0, 1e-5, max_iter)
+        assert np.array_equal(it.cpu().numpy(), io) and np.array_equal(cv.cpu().numpy(), co)
+        assert np.array_equal(x.cpu().numpy(), xo, equal_nan=True)
+        assert len(np.unique(io)) > 3
+
+
+def _admm_main_cases():
+    with open(os.path.join(GOLDEN, "main_counters_admm.json")) as fp:
+        return json.load(fp)
+
+
+@pytest.mark.parametrize("run", _admm_main_cases(), ids=lambda r: r["argline"].replace(" ", "_")[:60])
+def test_exact_mode_reproduces_reference_admm_counters(run, tmp_path):
+    from ldpc_decoders_amd import main
+
+    argv = run["argline"].split() + ["--data_dir", str(tmp_path), "--console", "--exact", "--np-seed", str(run["seed"])]
+    main.main(argv)
+    with open(os.path.join(str(tmp_path), run["file_name"])) as fp:
+        got = json.load(fp)
+    want = run["result"]
+    assert list(got) == list(want)
+    for key in ("tot", "wec", "bec"):
+        assert got[key] == want[key]
+    for prm in want["dec"]:
+        assert got["dec"][prm]["iter"] == want["dec"][prm]["iter"]  # the decoder's iteration histogram (src/admm.py:38-40)
+
+
+def test_admm_host_noise_batches_cli(tmp_path):
+    from ldpc_decoders_amd import main
+
+    res = main.main("bsc 7_4_hamming ADMM --codeword 0 --min-wec 300 --max-iter 100 --params 0.1 --batch 512".split()
+                    + ["--data_dir", str(tmp_path), "--console", "--np-seed", "3"])
+    # reference golden run (40 word errors): WER 40/136 = 0.29 at p = 0.1
+    assert res[0.1]["wec"] == 300 and 0.2 < res[0.1]["wer"] < 0.4

@@ -1,0 +1,16 @@
+"""One ADMM decode of a resident batch (profiler driver)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from ldpc_decoders_amd import codes
+from ldpc_decoders_amd._device import AdmmHandle
+os.environ.setdefault(codes.file_codes_dir_string, os.path.join(ROOT, "tests", "golden", "codes"))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+code = codes.get_code("1200_3_6_rand_ldpc_1")
+nv = 10 ** (-2.2 / 10)
+gamma = torch.from_numpy(-2 * (-1 + np.random.RandomState(1).normal(0, np.sqrt(nv), (B, code.n))) / nv).cuda()
+h = AdmmHandle(code)
+x, it, cv = h.decode_device(gamma, 3.0, 1e-5, 300)
+torch.cuda.synchronize()
+print("mean iters", it.float().mean().item())
