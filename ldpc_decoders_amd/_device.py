@@ -113,6 +113,8 @@ class DecoderHandle:
             xhat = torch.empty((B, n), dtype=torch.uint8, device=ref.device)
         if iters is None:
             iters = torch.empty((B,), dtype=torch.int32, device=ref.device)
+        if B == 0:
+            return xhat, iters
         st = torch.cuda.current_stream(ref.device).cuda_stream
         _lib.check(lib.ldpc_decode(self.h, None if priors is None else priors.data_ptr(), None if y0 is None else y0.data_ptr(),
                                    B, int(max_iter), flags, xhat.data_ptr(), iters.data_ptr(), st))
@@ -218,6 +220,8 @@ class MlHandle:
                    xhat=torch.empty((B, self.n), dtype=torch.uint8, device=y.device))
         if want_mask:
             out["tie_mask"] = torch.empty((B, self.W), dtype=torch.int32, device=y.device)
+        if B == 0:
+            return out
         c2 = (ctypes.c_double * 2)(float(coef[0]), float(coef[1]))
         st = torch.cuda.current_stream(y.device).cuda_stream
         _lib.check(_lib.load().ldpc_ml_decode(self.h, _lib.CHANNEL[self.channel], _lib.DTYPE[self.precision], c2, y.data_ptr(), B,
@@ -264,6 +268,8 @@ class AdmmHandle:
         x = torch.empty_like(gamma)
         iters = torch.empty(B, dtype=torch.int32, device=gamma.device)
         conv = torch.empty(B, dtype=torch.uint8, device=gamma.device)
+        if B == 0:  # zero-size tensors have no storage to point at
+            return x, iters, conv
         st = torch.cuda.current_stream(gamma.device).cuda_stream
         _lib.check(_lib.load().ldpc_admm_decode(self.h, gamma.data_ptr(), B, float(mu), float(eps), int(max_iter), x.data_ptr(),
                                                 iters.data_ptr(), conv.data_ptr(), st))

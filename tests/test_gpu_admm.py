@@ -104,3 +104,25 @@ def test_admm_host_noise_batches_cli(tmp_path):
                     + ["--data_dir", str(tmp_path), "--console", "--np-seed", "3"])
     # reference golden run (40 word errors): WER 40/136 = 0.29 at p = 0.1
     assert res[0.1]["wec"] == 300 and 0.2 < res[0.1]["wer"] < 0.4
+
+
+def test_admm_edge_cases():
+    # empty batch, one frame, max_iter = 1 (every frame leaves through the cap with the x of the first iteration), bad arguments
+    import torch
+    from ldpc_decoders_amd._device import AdmmHandle
+    from ldpc_decoders_amd._lib import LdpcHipError
+
+    code = _code("7_4_hamming")
+    g = graph_of("7_4_hamming")
+    h = AdmmHandle(code)
+    x, it, cv = h.decode_device(torch.zeros((0, 7), dtype=torch.float64, device="cuda"), 3.0, 1e-5, 10)
+    assert x.shape == (0, 7) and it.numel() == 0
+    gamma = np.random.RandomState(2).normal(0, 3, (65, 7))
+    for mi in (1, 2, 0):
+        xo, io, co = A.admm_decode(g, gamma, 3.0, 1e-5, mi)
+        x, it, cv = h.decode_device(torch.from_numpy(gamma).cuda(), 3.0, 1e-5, mi)
+        assert np.array_equal(x.cpu().numpy(), xo) and np.array_equal(it.cpu().numpy(), io) and np.array_equal(cv.cpu().numpy(), co)
+    with pytest.raises(LdpcHipError):
+        h.decode_device(torch.from_numpy(gamma).cuda(), 0.0, 1e-5, 10)
+    with pytest.raises(ValueError):
+        h.decode_device(torch.from_numpy(gamma[:, :6].copy()).cuda(), 3.0, 1e-5, 10)

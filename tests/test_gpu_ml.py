@@ -163,3 +163,33 @@ def test_ml_device_mode_cli(tmp_path):
     data = json.load(open(os.path.join(str(tmp_path), "biawgn-7_4_hamming-ML-0-2000.json")))
     assert list(data)[:5] == ["channel", "code", "decoder", "codeword", "min_wec"]
     assert 0.07 < data["wer"]["2.0"] < 0.135 and res[2.0]["tot"] % 16384 == 0
+
+
+@pytest.mark.parametrize("channel,param", [("biawgn", 1.0), ("bsc", 0.2), ("bec", 0.5)])
+def test_ml_larger_codebook_vs_oracle(channel, param):
+    # a codebook beyond one 32-bit tie word (k = 7 -> 128 words, n = 20 >= 8: numpy's 8-accumulator summation branch), ragged batch
+    import torch
+
+    from ldpc_decoders_amd._device import MlHandle
+    from ldpc_decoders_amd.models import models
+
+    rng = np.random.RandomState(9)
+    G = rng.randint(0, 2, (7, 20))
+    msgs = ((np.arange(128)[:, None] >> np.arange(7)) & 1)
+    cb = (msgs @ G) % 2
+    h = MlHandle(cb, channel, "f64")
+    assert h.W == 4
+    B = 333
+    np.random.seed(12)
+    chan = models[channel].Channel(param)
+    Y = np.stack([chan.send(cb[rng.randint(128)]) for _ in range(B)])
+    y = torch.from_numpy(np.ascontiguousarray(Y, dtype=np.float64 if channel == "biawgn" else np.uint8)).cuda()
+    coef = M.ml_coefficients(channel, param)
+    out = h.decode_device(y, coef)
+    ties = tie_bits(out["tie_mask"], 128)
+    best = out["best"].cpu().numpy()
+    with np.errstate(all="ignore"):
+        for f in range(B):
+            lp = M.ml_log_prob(channel, cb, Y[f], coef)
+            assert best[f] == lp.max() and np.array_equal(np.flatnonzero(ties[f]), M.ml_tie_set(lp))
+    assert np.array_equal(out["index"].cpu().numpy(), ties.argmax(axis=1)) and np.array_equal(out["ties"].cpu().numpy(), ties.sum(axis=1))
