@@ -91,7 +91,7 @@ void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint6
     identity_layout(c, DC, vr, L);
     L->base_cycles = 2.0 * (CR * DC + vr.total_gathers());
     L->extra_cycles_identity = layout_extra_cycles(c, DC, CR, vr, *L);
-    const int VR = vr.VR, DV = vr.DV, DVM = std::max(vr.DV, vr.dvx);
+    const int VR = vr.VR, DVM = std::max(vr.DV, vr.dvx);
     const int NGC = 2 * CR, NGV = 2 * VR, m = c.m, n = c.n;
     const int64_t E = c.E;
     Rng rng(seed);
