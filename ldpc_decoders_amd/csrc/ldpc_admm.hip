@@ -359,7 +359,7 @@ int admm_create(Code* code, AdmmDecoder** out) {
     if (e == hipSuccess) e = hipMemcpy(d->d_prog, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         set_error("admm_create: %s", hipGetErrorString(e));
-        delete d;
+        admm_destroy(d);  // frees whatever was allocated
         return LDPC_E_HIP;
     }
     *out = d;
