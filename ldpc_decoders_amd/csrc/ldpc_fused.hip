@@ -145,7 +145,7 @@ struct FusedArgs {
 };
 
 template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : (NW == 4 ? 3 : 4)) void k_fused_bp(const FusedArgs A) {
+__global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 3 : 4)) void k_fused_bp(const FusedArgs A) {
     // BIG: a frame takes the whole LDS of a CU (160 KB) and a 16-wave workgroup.  Table entries are dword indices, c2v stores
     // use an address register, and the LAST marginal row is a system row that no sweep writes: dwords [0,16) hand-off
     // channel A (one word per wave), [16,32) channel B, [32] frame hand-out, [33] always zero (target of missing edges).
@@ -1007,7 +1007,9 @@ int fused_plan_create(Decoder* d) {
     LDPC_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     p->num_cu = prop.multiProcessorCount;
     const int by_lds = (int)((size_t)160 * 1024 / p->lds_bytes);
-    int cap = 8;  // resident frames per CU (waves: NW x that)
+    // resident frames per CU (waves: NW x that): 8 for the n = 1200 shapes (LDS-bound anyway); the small one-wave shape
+    // (n <= 512, 8 KB of LDS, built for 128 VGPRs) runs 16 -- measured +13 % on 512_3_6_rand_ldpc_2
+    int cap = (NW == 1 && CRW <= 4) ? 16 : 8;
     if (const char* wenv = std::getenv("LDPC_FUSED_WAVES")) cap = atoi(wenv) > 0 ? atoi(wenv) : cap;  // experiment knob
     p->groups_per_cu = by_lds < cap ? by_lds : cap;
     LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
