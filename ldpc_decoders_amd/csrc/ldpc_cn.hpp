@@ -84,50 +84,54 @@ __device__ __forceinline__ void cn_spa(double (&v)[DCMAX], int deg) {
     }
 }
 
-// ---- sum-product, fp32: leave-one-out in the "distance from certainty" domain -----------------------
-// With t_i = tanh(|v2c_i|/2) the reference computes |c2v_j| = 2 atanh(prod_{i != j} t_i) (src/bpa.py:71-75).  fp32 tanh
-// saturates to exactly 1 at |LLR| ~ 17, so the product is carried as D = 1 - prod instead, built from
-// d_i = 1 - t_i = 2u/(1+u), u = e^-|v2c_i|, with the cancellation-free join  1-(1-x)(1-y) = x + y - xy :
-//     |c2v_j| = ln((2 - D_j) / D_j),   D_j = join over i != j of d_i   (prefix/suffix joins, dc-1 each).
-// Exactly the same quantity as the reference's tanh product (and as the phi-domain statement of the oracle,
-// bp_oracle.spa_phi_check_update); small D (all other edges reliable) keeps full relative precision up to |LLR| ~ 88,
-// D -> 1 (an unreliable edge) gives |c2v| -> 0 with absolute error ~1e-7.  Unlike the reference it has no 0/0 at
-// v2c == 0 (src/bpa.py:74 TODO) and no +-inf / NaN artefacts: above |LLR| ~ 88 the check messages saturate (finite).
-// Agreement with the fp64 reference is a TOLERANCE (tests/test_gpu_parity.py), not bit-exactness.
-// 4 transcendental-unit operations per edge (exp2, rcp, rcp, log2).
-__device__ __forceinline__ float spa_d_of_llr(float a) {  // a = |v2c| >= 0  ->  1 - tanh(a/2)
-    const float u = __builtin_amdgcn_exp2f(a * -1.44269504088896340736f);  // e^-a on the exp2 unit (v_exp_f32, ~1 ulp)
-    return (2.0f * u) * __builtin_amdgcn_rcpf(1.0f + u);                   // v_rcp_f32, ~1 ulp
+// ---- sum-product, fp32: leave-one-out through the even / odd parts of prod (1 + u_i) ---------------------------------
+// With u_i = e^-|v2c_i| the reference's factor is tanh(|v2c_i|/2) = (1 - u_i)/(1 + u_i) (src/bpa.py:71-75).  Write
+// prod_{i != j} (1 + u_i x) = E_j + x O_j (E_j: even-degree, O_j: odd-degree elementary symmetric sums of the other edges'
+// u_i); then prod (1 - u_i) = E_j - O_j, prod (1 + u_i) = E_j + O_j and
+//     |c2v_j| = 2 atanh( (E_j - O_j) / (E_j + O_j) ) = ln(E_j / O_j).
+// (E, O) start at (1, 0); an edge with weight u maps (E, O) -> (E + u O, O + u E); a prefix and a suffix combine as
+// E = Ep Es + Op Os, O = Ep Os + Op Es.  Every term is positive -- no cancellation anywhere: when all other edges are
+// reliable O ~ sum u_i keeps full relative precision (fp32 tanh would have saturated to 1 at |LLR| ~ 17), an unreliable edge
+// (u = 1) makes E == O exactly, i.e. |c2v| = 0.  Exactly the reference's quantity (and the phi-domain statement of the oracle,
+// bp_oracle.spa_phi_check_update); unlike the reference it has no 0/0 at v2c == 0 (src/bpa.py:74 TODO) and no +-inf / NaN
+// artefacts: once O underflows (every other edge beyond |LLR| ~ 87) the message saturates at ~87 instead of becoming +inf,
+// which would turn the next v2c = marginal - c2v into inf - inf.  Agreement with the fp64 reference is a TOLERANCE
+// (tests/test_gpu_parity.py), not bit-exactness.  3 transcendental-unit operations per edge (exp2, log2, log2).
+__device__ __forceinline__ float spa_u_of_llr(float a) {  // a = |v2c| >= 0  ->  e^-a on the exp2 unit (v_exp_f32, ~1 ulp)
+    return __builtin_amdgcn_exp2f(a * -1.44269504088896340736f);
 }
-__device__ __forceinline__ float spa_join(float x, float y) { return fmaf(-x, y, x) + y; }  // 1 - (1-x)(1-y)
-__device__ __forceinline__ float spa_llr_of_d(float D) {  // 2 atanh(1 - D) = ln((2 - D) / D)
-    // D underflows to 0 once every other edge of the check is beyond |LLR| ~ 88: saturate there (|c2v| <= 88.03) instead of
-    // returning +inf, which would turn the next v2c = marginal - c2v into inf - inf = NaN and poison the frame
-    D = fmaxf(D, 1.17549435e-38f);
-    return 0.69314718055994530942f * __builtin_amdgcn_logf((2.0f - D) * __builtin_amdgcn_rcpf(D));  // v_log_f32 is log2
+__device__ __forceinline__ void spa_eo_push(float& e, float& o, float u) {  // append one edge
+    const float e2 = fmaf(u, o, e);
+    o = fmaf(u, e, o);
+    e = e2;
+}
+__device__ __forceinline__ float spa_llr_of_eo(float ep, float op, float es, float os) {  // ln(E/O) of prefix x suffix
+    const float e = fmaf(op, os, ep * es);
+    const float o = fmaxf(fmaf(op, es, ep * os), 1.17549435e-38f);
+    return 0.69314718055994530942f * (__builtin_amdgcn_logf(e) - __builtin_amdgcn_logf(o));  // v_log_f32 is log2
 }
 
 template <int DCMAX>
 __device__ __forceinline__ void cn_spa(float (&v)[DCMAX], int deg) {
-    float d[DCMAX];
-    float pre[DCMAX];
+    float u[DCMAX], pe[DCMAX], po[DCMAX];
     bool parity = false;
-    float run = 0.0f;
+    float re = 1.0f, ro = 0.0f;
 #pragma unroll
     for (int j = 0; j < DCMAX; ++j) {
         if (j < deg) {
-            d[j] = spa_d_of_llr(fabsf(v[j]));
+            u[j] = spa_u_of_llr(fabsf(v[j]));
             parity ^= (v[j] < 0.0f);
-            pre[j] = run;  // join over the edges before j
-            run = spa_join(run, d[j]);
+            pe[j] = re;  // (E, O) of the edges before j
+            po[j] = ro;
+            spa_eo_push(re, ro, u[j]);
         }
     }
-    float suf = 0.0f;  // join over the edges after j
+    float se = 1.0f, so = 0.0f;  // (E, O) of the edges after j
 #pragma unroll
     for (int j = DCMAX - 1; j >= 0; --j) {
         if (j < deg) {
-            const float mag = spa_llr_of_d(spa_join(pre[j], suf));
-            suf = spa_join(suf, d[j]);
+            const float mag = spa_llr_of_eo(pe[j], po[j], se, so);
+            spa_eo_push(se, so, u[j]);
             const bool own_neg = !(v[j] >= 0.0f);
             v[j] = (parity != own_neg) ? -mag : mag;
         }

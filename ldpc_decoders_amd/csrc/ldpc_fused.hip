@@ -583,6 +583,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
                     if constexpr (DC % 2 == 0) synd |= mx; else synd |= ((cn_active[r] >> lane) & 1ull) ? mx : 0u;
                     // leave-one-out reduction of |v|: minimum (min-sum) or join of 1 - tanh(|v|/2) (sum-product, ldpc_cn.hpp)
                     float pre[DC], suf[DC];
+                    float preo[ALG == ALG_MSA ? 1 : DC], sufo[ALG == ALG_MSA ? 1 : DC];  // odd parts (sum-product only)
                     if constexpr (ALG == ALG_MSA && DC == 6) {
                         // 11 minimum instructions for the six leave-one-out minima (v_min3_f32 where three inputs meet)
                         const float s3 = fminf(a[4], a[5]), s2 = fminf(fminf(a[3], a[4]), a[5]), s1 = fminf(a[2], s2);
@@ -601,18 +602,26 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
 #pragma unroll
                         for (int j = DC - 2; j >= 0; --j) suf[j] = fminf(suf[j + 1], a[j + 1]);
                     } else {
+                        // sum-product: (E, O) pairs of prod (1 + u_i), prefix in (pre, preo), suffix in (suf, sufo) -- ldpc_cn.hpp
 #pragma unroll
-                        for (int j = 0; j < DC; ++j) a[j] = spa_d_of_llr(a[j]);
-                        pre[0] = 0.0f;
+                        for (int j = 0; j < DC; ++j) a[j] = spa_u_of_llr(a[j]);
+                        pre[0] = 1.0f; preo[0] = 0.0f;
 #pragma unroll
-                        for (int j = 1; j < DC; ++j) pre[j] = spa_join(pre[j - 1], a[j - 1]);
-                        suf[DC - 1] = 0.0f;
+                        for (int j = 1; j < DC; ++j) {
+                            pre[j] = pre[j - 1]; preo[j] = preo[j - 1];
+                            spa_eo_push(pre[j], preo[j], a[j - 1]);
+                        }
+                        suf[DC - 1] = 1.0f; sufo[DC - 1] = 0.0f;
 #pragma unroll
-                        for (int j = DC - 2; j >= 0; --j) suf[j] = spa_join(suf[j + 1], a[j + 1]);
+                        for (int j = DC - 2; j >= 0; --j) {
+                            suf[j] = suf[j + 1]; sufo[j] = sufo[j + 1];
+                            spa_eo_push(suf[j], sufo[j], a[j + 1]);
+                        }
                     }
                     static_for<0, DC>([&](auto J_) {
                         constexpr int j = decltype(J_)::value;
-                        const float mag = ALG == ALG_MSA ? fminf(pre[j], suf[j]) : spa_llr_of_d(spa_join(pre[j], suf[j]));
+                        float mag;
+                        if constexpr (ALG == ALG_MSA) mag = fminf(pre[j], suf[j]); else mag = spa_llr_of_eo(pre[j], preo[j], suf[j], sufo[j]);
                         const float c = __uint_as_float(__float_as_uint(mag) | ((vx ^ __float_as_uint(v[j])) & 0x80000000u));
                         c2v_old[r][j] = c;
                         if constexpr (!BIG) lds_st_tid<(r * DC + j) * 256>(c);
