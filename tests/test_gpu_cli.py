@@ -44,3 +44,17 @@ def test_device_mode_schema_and_rates(tmp_path, monkeypatch):
     assert 0.012 < data["ber"]["2.0"] < 0.035 and 0.0012 < data["ber"]["2.5"] < 0.0045
     assert data["wec"]["2.0"] >= 200 and data["tot"]["2.0"] % 8192 == 0
     assert res[2.0]["wer"] == data["wer"]["2.0"]
+
+
+def test_curves_overlap_the_published_reference_results(tmp_path):
+    # device Monte-Carlo against the reference's own published result files for the fixture codes (a subset here; the full
+    # table is profiles/curves_vs_reference.md, tools/compare_curves.py): every curve agrees or is a documented deviation
+    import subprocess
+    import sys
+
+    root = os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0]
+    for sel in ("1200_3_6_rand_ldpc_1", "bsc-1200_3_6_ldpc-MSA-40", "7_4_hamming-ML"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "compare_curves.py"), "--only", sel, "--min-wec", "600",
+                            "--out", str(tmp_path / "c.md")], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "agrees" in open(str(tmp_path / "c.md")).read()

@@ -1,0 +1,115 @@
+"""Monte-Carlo curves of this build against the reference's PUBLISHED result files (tests/golden/published_curves.json, collected
+from its data/output/*.json by oracle/make_goldens_curves.py): same channel / code / decoder / max_iter / parameter grid,
+device noise, many more frames.  Writes a markdown table; exit code 1 if a curve outside the known-deviation list disagrees.
+
+    python tools/compare_curves.py [--min-wec 1000] [--max-frames 67108864] [--only SUBSTRING] [--out profiles/curves_vs_reference.md]
+
+Agreement test per point: the two word-error counts are Poisson-like, so z = (WER_a - WER_b) / sqrt(WER_a^2/wec_a + WER_b^2/wec_b);
+a curve agrees when max |z| < 4.5 over its points (the published files hold ~1000 points in all) and the median BER ratio is
+within 15 %.  Points where the reference counted fewer than 20 word errors are reported but not tested."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from ldpc_decoders_amd import codes  # noqa: E402
+from ldpc_decoders_amd.models import models  # noqa: E402
+from ldpc_decoders_amd.montecarlo import DeviceSimulator  # noqa: E402
+
+# Reference behaviour this build documents as NOT reproduced (tests/golden/reference_checks.json): upstream's
+# sum-product is not codeword-symmetric -- 0/0 at v2c == 0 (src/bpa.py:74 TODO), tanh saturation and NaN marginals all decode
+# towards the all-zero word -- so its all-zero-codeword curves are optimistic once those artefacts set in: on the BSC (every LLR
+# has the same magnitude: exact zeros from the first sweeps on), at many iterations on BI-AWGN, and on the irregular rho_x5 codes.
+def known_deviation(cv, max_iter):
+    if cv["decoder"] != "SPA" or int(cv.get("codeword", 0)) != 0:
+        return False
+    return "rho_x5" in cv["code"] or (cv["channel"] == "bsc" and max_iter >= 10) or (cv["channel"] == "biawgn" and max_iter >= 40)
+
+
+# Older-format published files (no `codeword` key) that the CURRENT upstream code does not reproduce either
+# (tests/golden/reference_checks.json, p = 0.0451: max_iter 1: BER 0.010 now / 0.111 in the file; 6: 0.068 / 0.088)
+STALE = ("bsc-1200_3_6_ldpc-MSA-1.json", "bsc-1200_3_6_ldpc-MSA-2.json", "bsc-1200_3_6_ldpc-MSA-3.json", "bsc-1200_3_6_ldpc-MSA-6.json")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--min-wec", type=int, default=1000)
+    ap.add_argument("--max-frames", type=int, default=1 << 26)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "curves_vs_reference.md"))
+    a = ap.parse_args()
+    os.environ.setdefault(codes.file_codes_dir_string, os.path.join(ROOT, "tests", "golden", "codes"))
+    with open(os.path.join(ROOT, "tests", "golden", "published_curves.json")) as fp:
+        curves = json.load(fp)
+    rows, bad = [], []
+    t_all = time.time()
+    for cv in curves:
+        name = cv["file"][:-5]
+        if a.only and a.only not in name:
+            continue
+        if cv["decoder"] == "ADMM":
+            continue  # host-noise loop; covered bit-exactly by tests/test_gpu_admm.py
+        max_iter = int(cv.get("max_iter", 10))
+        if max_iter <= 0:
+            continue  # the published "max_iter 0" files hold ZERO iterations (BER = raw channel); current upstream reads <= 0 as "no cap"
+        code = codes.get_code(cv["code"])
+        codeword = int(cv.get("codeword", 0))
+        mod = models[cv["channel"]]
+        # min-sum on the BSC is tie-dominated (every LLR is +-L): how near-ties break depends on the rounding of sums of L, so
+        # only the fp64 arithmetic of the reference is comparable there; everything else runs in fp32
+        precision = "f64" if (cv["channel"] == "bsc" and cv["decoder"] == "MSA") else "f32"
+        dec = getattr(mod, cv["decoder"])(float(next(iter(cv["points"]))), code, max_iter=max_iter, precision=precision)
+        handle = dec.handle if hasattr(dec, "handle") else dec.dec.handle
+        sim = DeviceSimulator(handle, cv["channel"], max_iter, codeword, seed=0xC0FFEE)
+        zs, ratios, npts, frames = [], [], 0, 0
+        worst = None
+        for pi, (p, ref) in enumerate(sorted(cv["points"].items(), key=lambda kv: float(kv[0]))):
+            if ref["wec"] < 1 or ref["tot"] < 1:
+                continue
+            c = sim.run_point(float(p), stream_id=pi, min_wec=a.min_wec, batch_per_rank=a.batch, max_frames=a.max_frames)
+            frames += c["tot"]
+            if c["wec"] == 0:
+                continue
+            wer, ber = c["wec"] / c["tot"], c["bec"] / (c["tot"] * code.get_n())
+            z = (wer - ref["wer"]) / np.sqrt(wer ** 2 / c["wec"] + ref["wer"] ** 2 / ref["wec"])
+            npts += 1
+            if ref["wec"] >= 20:
+                zs.append(z)
+                if ref["ber"] > 0 and ber > 0:
+                    ratios.append(ber / ref["ber"])
+                if worst is None or abs(z) > abs(worst[1]):
+                    worst = (p, z, wer, ref["wer"], ber, ref["ber"])
+        if not zs:
+            continue
+        maxz, med = float(np.max(np.abs(zs))), float(np.median(ratios)) if ratios else float("nan")
+        ok = maxz < 4.5 and (not ratios or 0.85 < med < 1.15)
+        known = "known deviation (DESIGN 5)" if known_deviation(cv, max_iter) else ("file not reproduced by current upstream" if cv["file"] in STALE else "")
+        rows.append((name, max_iter, npts, frames, maxz, med, worst, ok, known, precision))
+        if not ok and not known:
+            bad.append(name)
+        print("%-50s %s pts %2d frames %.2e max|z| %.2f median BER ratio %.3f %s" % (name, precision, npts, frames, maxz, med,
+                                                                                      "ok" if ok else (known.upper() if known else "DISAGREES")), flush=True)
+    lines = ["# Curves of this build against the reference's published result files\n",
+             "`python tools/compare_curves.py --min-wec %d` on one MI355X (device noise, fp32 message arithmetic), %.0f s for %d curves / %d points; "
+             "reference numbers from its `data/output/*.json` (tests/golden/published_curves.json).  z compares word-error rates "
+             "(see the tool's docstring); points where the reference counted < 20 word errors are not tested.\n" % (
+                 a.min_wec, time.time() - t_all, len(rows), sum(r[2] for r in rows)),
+             "| curve (channel-code-decoder-…) | max_iter | arithmetic | points | frames here | max \\|z\\| | median BER ratio | worst point (param: WER here / ref) | verdict |",
+             "|---|---|---|---|---|---|---|---|---|"]
+    for name, mi, npts, frames, maxz, med, w, ok, known, precision in rows:
+        lines.append("| %s | %d | %s | %d | %.2e | %.2f | %.3f | %s: %.3e / %.3e | %s |" % (
+            name, mi, precision, npts, frames, maxz, med, w[0], w[2], w[3], "agrees" if ok else (known if known else "DISAGREES")))
+    with open(a.out, "w") as fp:
+        fp.write("\n".join(lines) + "\n")
+    print("wrote", a.out, "disagreeing:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
