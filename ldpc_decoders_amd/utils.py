@@ -45,7 +45,7 @@ def setup_parser(code_names, channel_names, decoder_names):
     p.add_argument("--log-freq", help="log frequency in seconds", default=5., type=float)
     # GPU build additions
     p.add_argument("--precision", choices=["f32", "f64"], default=None,
-                   help="message arithmetic (default: f32 with device noise, f64 with --exact)")
+                   help="message arithmetic (default: f32 with device noise; f64 with --exact and for min-sum over the BSC, which is tie-dominated)")
     p.add_argument("--backend", choices=["auto", "stream", "fused"], default="auto", help="kernel family")
     p.add_argument("--batch", type=int, default=65536, help="frames per round and per GPU (device-noise mode)")
     p.add_argument("--seed", type=int, default=0x5EED1200, help="Philox seed of the device noise")
