@@ -11,6 +11,7 @@
 // bit-identical to the reference's (golden vectors, tests/test_gpu_admm.py).  oracle/admm_oracle.c is the CPU statement.
 #include "ldpc_common.hpp"
 
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -37,9 +38,19 @@ __device__ __forceinline__ double clamp01(double x) {
     return (1.0 < lo) ? 1.0 : lo;
 }
 
+// Small per-lane array living in the LDS: element i of this lane at p[i * STRIDE].  The projection indexes its work arrays
+// with data-dependent indices; in registers every such access expands into a select chain over the whole array, in the LDS it
+// is one ds_read / ds_write (lanes sit on distinct banks for any i: i * STRIDE * sizeof(T) is a multiple of 256 bytes).
+template <typename T, int STRIDE>
+struct LdsArr {
+    T* p;
+    __device__ __forceinline__ T& operator[](int i) const { return p[i * STRIDE]; }
+};
+
 // Euclidean projection onto the parity polytope; v is overwritten with the result.  Same steps as oracle_pp_project.
-template <int DCM>
-__device__ void pp_project(double (&v)[DCM], int len) {
+// v, s, c, bp: double arrays, who, bp_who: int arrays -- raw pointers to local arrays or LdsArr accessors.
+template <typename AD, typename AI>
+__device__ void pp_project(AD v, AD s, AD c, AD bp, AI who, AI bp_who, int len) {
     bool none_positive = true, all_above_one = true;
     for (int i = 0; i < len; ++i) {
         if (v[i] > 0) none_positive = false;
@@ -53,8 +64,6 @@ __device__ void pp_project(double (&v)[DCM], int len) {
         for (int i = 0; i < len; ++i) v[i] = 1;
         return;
     }
-    double s[DCM];
-    int who[DCM];
     for (int i = 0; i < len; ++i) {  // stable insertion sort, decreasing
         const double val = v[i];
         int j = i;
@@ -66,7 +75,7 @@ __device__ void pp_project(double (&v)[DCM], int len) {
         s[j] = val;
         who[j] = i;
     }
-    double c[DCM], mass = 0;
+    double mass = 0;
     for (int i = 0; i < len; ++i) {
         c[i] = clamp01(s[i]);
         mass += c[i];
@@ -81,8 +90,6 @@ __device__ void pp_project(double (&v)[DCM], int len) {
         return;
     }
     const double beta_cap = (r + 2 <= len) ? (s[r] - s[r + 1]) / 2 : s[r];
-    double bp[DCM];
-    int bp_who[DCM];
     {
         int L = r, R = r + 1, k = 0;
         while (k < len) {
@@ -194,34 +201,59 @@ __global__ __launch_bounds__(256) void k_admm_x(const int32_t* __restrict__ col_
 }
 
 // z and lambda updates (src/admm.py:58-63) + the two squared-distance vectors of the stopping test (src/admm.py:18-19)
-template <int DCM>
-__global__ __launch_bounds__(256) void k_admm_z(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
-                                                double* __restrict__ z, double* __restrict__ lam, const double* __restrict__ x,
-                                                double* __restrict__ d1, double* __restrict__ d2, const u64* __restrict__ live, int m, int n,
-                                                int64_t E, double mu) {
+template <int DCM, bool LDSARR>
+__global__ __launch_bounds__(LDSARR ? 128 : 256) void k_admm_z(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
+                                                               double* __restrict__ z, double* __restrict__ lam, const double* __restrict__ x,
+                                                               double* __restrict__ d1, double* __restrict__ d2, const u64* __restrict__ live,
+                                                               int m, int n, int64_t E, double mu) {
+    constexpr int TPB = LDSARR ? 128 : 256;
+    __shared__ double sh_d[LDSARR ? 4 : 1][LDSARR ? DCM : 1][LDSARR ? TPB : 1];
+    __shared__ int sh_i[LDSARR ? 2 : 1][LDSARR ? DCM : 1][LDSARR ? TPB : 1];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.y;
     const u64 lv = live[tile];
     if (lv == 0 || !((lv >> lane) & 1ull)) return;
     const int64_t eb = (int64_t)tile * E * 64 + lane;
     const double* xt = x + (int64_t)tile * n * 64 + lane;
-    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < m; c += gridDim.x * 4) {
+    for (int c = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6); c < m; c += gridDim.x * (TPB / 64)) {
         const int k0 = row_ptr[c], len = row_ptr[c + 1] - k0;
-        double v[DCM], xs[DCM], lm[DCM];
-        for (int j = 0; j < len; ++j) {
-            xs[j] = xt[(int64_t)edge_var[k0 + j] * 64];
-            lm[j] = lam[eb + (int64_t)(k0 + j) * 64];
-            v[j] = xs[j] + lm[j] / mu;
-        }
-        pp_project<DCM>(v, len);
-        for (int j = 0; j < len; ++j) {
-            const int64_t o = eb + (int64_t)(k0 + j) * 64;
-            const double zo = z[o];
-            lam[o] = lm[j] + mu * (xs[j] - v[j]);
-            const double a = xs[j] - v[j], b = zo - v[j];
-            d1[o] = a * a;
-            d2[o] = b * b;
-            z[o] = v[j];
+        double xs[DCM], lm[DCM];
+        if constexpr (LDSARR) {
+            const LdsArr<double, TPB> v{&sh_d[0][0][threadIdx.x]}, s{&sh_d[1][0][threadIdx.x]}, cc{&sh_d[2][0][threadIdx.x]}, bp{&sh_d[3][0][threadIdx.x]};
+            const LdsArr<int, TPB> who{&sh_i[0][0][threadIdx.x]}, bp_who{&sh_i[1][0][threadIdx.x]};
+            for (int j = 0; j < len; ++j) {
+                xs[j] = xt[(int64_t)edge_var[k0 + j] * 64];
+                lm[j] = lam[eb + (int64_t)(k0 + j) * 64];
+                v[j] = xs[j] + lm[j] / mu;
+            }
+            pp_project(v, s, cc, bp, who, bp_who, len);
+            for (int j = 0; j < len; ++j) {
+                const int64_t o = eb + (int64_t)(k0 + j) * 64;
+                const double zo = z[o], zn = v[j];
+                lam[o] = lm[j] + mu * (xs[j] - zn);
+                const double a = xs[j] - zn, b = zo - zn;
+                d1[o] = a * a;
+                d2[o] = b * b;
+                z[o] = zn;
+            }
+        } else {
+            double v[DCM], s[DCM], cc[DCM], bp[DCM];
+            int who[DCM], bp_who[DCM];
+            for (int j = 0; j < len; ++j) {
+                xs[j] = xt[(int64_t)edge_var[k0 + j] * 64];
+                lm[j] = lam[eb + (int64_t)(k0 + j) * 64];
+                v[j] = xs[j] + lm[j] / mu;
+            }
+            pp_project((double*)v, (double*)s, (double*)cc, (double*)bp, (int*)who, (int*)bp_who, len);
+            for (int j = 0; j < len; ++j) {
+                const int64_t o = eb + (int64_t)(k0 + j) * 64;
+                const double zo = z[o];
+                lam[o] = lm[j] + mu * (xs[j] - v[j]);
+                const double a = xs[j] - v[j], b = zo - v[j];
+                d1[o] = a * a;
+                d2[o] = b * b;
+                z[o] = v[j];
+            }
         }
     }
 }
@@ -417,10 +449,15 @@ int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, doubl
     int done = 0;
     for (int it = 0; it < cap; ++it) {
         hipLaunchKernelGGL(k_admm_x, dim3(gv, tiles), dim3(256), 0, st, c->d_col_ptr, c->d_col_edge, z, lam, gam, x, live, n, E, tiles, mu);
-        if (c->max_dc <= 8)
-            hipLaunchKernelGGL((k_admm_z<8>), dim3(gc, tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
-        else
-            hipLaunchKernelGGL((k_admm_z<16>), dim3(gc, tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
+        static const bool lds_arrays = !(std::getenv("LDPC_ADMM_REGARR") && std::getenv("LDPC_ADMM_REGARR")[0] == '1');
+        if (c->max_dc <= 8 && lds_arrays) {
+            const unsigned gcl = (unsigned)((m + 1) / 2 < 1024 ? (m + 1) / 2 : 1024);
+            hipLaunchKernelGGL((k_admm_z<8, true>), dim3(gcl, tiles), dim3(128), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
+        } else if (c->max_dc <= 8) {
+            hipLaunchKernelGGL((k_admm_z<8, false>), dim3(gc, tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
+        } else {
+            hipLaunchKernelGGL((k_admm_z<16, false>), dim3(gc, tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
+        }
         const bool poll = (it % 8) == 7 || it + 1 == cap;
         if (poll) LDPC_HIP_TRY(hipMemsetAsync(live_tiles, 0, sizeof(int), st));
         hipLaunchKernelGGL(k_admm_leaves, dim3((d->leaves + 3) / 4, tiles), dim3(256), 0, st, d1, d2, d->d_leaf_off, d->d_leaf_len, d->leaves,
