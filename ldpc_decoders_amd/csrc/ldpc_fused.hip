@@ -150,7 +150,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
     // use an address register, and the LAST marginal row is a system row that no sweep writes: dwords [0,16) hand-off
     // channel A (one word per wave), [16,32) channel B, [32] frame hand-out, [33] always zero (target of missing edges).
     constexpr bool BIG = NW > 4;
-    static_assert(VRX == 0 || NW == 1 || BIG, "wide variable rounds: one wave per frame, or the 16-wave shape");
+    // SYS: the system row (hand-off words + zero word in the last marginal row) is also what lets SEVERAL waves share an
+    // irregular frame of the small shapes (they have no always-zero row and may have no padded slot per wave)
+    constexpr bool SYS = BIG || (NW > 1 && VRX > 0);
     constexpr int VNK = VRX * DVX + (VRW - VRX) * DV;  // gathers of a variable phase: wide rounds first, then narrow ones
     constexpr int VN0 = VRX * DVX;                      // first gather index of the narrow rounds
     constexpr int CR = CRW * NW, VR = VRW * NW;
@@ -195,17 +197,17 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
         if constexpr (VMAP_RESIDENT) return vmap_reg[q]; else return vslot[q * 64 + lane];
     };
     if (A.zero_row && w == 0) reinterpret_cast<float*>(smem)[NPAD + CR * DC * 64 + lane] = 0.0f;  // the always-zero row
-    const bool own_last = !(BIG && w == NW - 1);  // wave NW-1 of the BIG shape never writes its last row (the system row)
+    const bool own_last = !(SYS && w == NW - 1);  // with a system row, wave NW-1 never writes its last marginal row
     auto sysw = [&](int i) { return reinterpret_cast<volatile uint32_t*>(smem + A.sys_off) + i; };
-    if constexpr (BIG) {
+    if constexpr (SYS) {
         if (threadIdx.x == 0) *sysw(33) = 0u;  // published by the barrier at the top of the frame loop
     }
 
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
     const uint32_t m0_c2v = lds_base + (uint32_t)(NPAD + w * CRW * DC * 64) * 4;  // this wave's c2v rows
     const uint32_t m0_marg = lds_base + (uint32_t)(w * VRW * 64) * 4;            // this wave's marginal rows
-    const uint32_t my_sync = (uint32_t)A.sync_off[BIG ? 0 : w];
-    const uint32_t my_msync = (uint32_t)A.msync_off[BIG ? 0 : w];
+    const uint32_t my_sync = (uint32_t)A.sync_off[SYS ? 0 : w];
+    const uint32_t my_msync = (uint32_t)A.msync_off[SYS ? 0 : w];
     const uint32_t c2v_vaddr = m0_c2v + (uint32_t)lane * 4u;  // BIG: address register of the c2v stores
     const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
     // SIM: per-workgroup counters live in wave 0 (scalars + one histogram bin per lane), flushed once at the end
@@ -227,10 +229,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
     auto any_unsat = [&](bool mine) -> bool {
         if constexpr (NW == 1) {
             return mine;
-        } else if constexpr (BIG) {
+        } else if constexpr (SYS) {
             if (lane == 0) *sysw(w) = mine ? 1u : 0u;
             wg_barrier();
-            return __ballot(*sysw(lane & 15) != 0u) != 0;
+            return __ballot(*sysw(lane & (NW - 1)) != 0u) != 0;
         } else {
             if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_sync) = mine ? 1u : 0u;
             wg_barrier();
@@ -247,10 +249,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
     auto exchange_or = [&](uint32_t mine) -> uint32_t {  // OR of the words of all waves (contains one barrier)
         if constexpr (NW == 1) {
             return mine;
-        } else if constexpr (BIG) {
+        } else if constexpr (SYS) {
             if (lane == 0) *sysw(16 + w) = mine;
             wg_barrier();
-            const uint32_t v = *sysw(16 + (lane & 15));
+            const uint32_t v = *sysw(16 + (lane & (NW - 1)));
             return (__ballot((v & 1u) != 0u) != 0 ? 1u : 0u) | (__ballot((v & 2u) != 0u) != 0 ? 2u : 0u);
         } else {
             if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_msync) = mine;
@@ -267,13 +269,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
     auto exchange_add = [&](int mine) -> int {
         if constexpr (NW == 1) {
             return mine;
-        } else if constexpr (BIG) {
+        } else if constexpr (SYS) {
             constexpr int CH = ALG == ALG_BEC ? 0 : 16;  // the channel the sweep loop did not just use
             if (lane == 0) *sysw(CH + w) = (uint32_t)mine;
             wg_barrier();
-            int sum = lane < 16 ? (int)*sysw(CH + (lane & 15)) : 0;
+            int sum = lane < NW ? (int)*sysw(CH + (lane & (NW - 1))) : 0;
 #pragma unroll
-            for (int o = 8; o; o >>= 1) sum += __shfl_xor(sum, o);
+            for (int o = NW / 2; o; o >>= 1) sum += __shfl_xor(sum, o);
             return __builtin_amdgcn_readfirstlane(sum);
         } else {
             const uint32_t mine_off = ALG == ALG_BEC ? my_sync : my_msync;
@@ -316,10 +318,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
             wg_barrier();  // the verdict slots of the previous frame have been read by everybody
             if (w == 0) {
                 const long long f0 = next_frame();
-                if (lane == 0) *(BIG ? sysw(32) : reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0])) = (uint32_t)(int32_t)f0;
+                if (lane == 0) *(SYS ? sysw(32) : reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0])) = (uint32_t)(int32_t)f0;
             }
             wg_barrier();
-            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*(BIG ? sysw(32) : reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0])));
+            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*(SYS ? sysw(32) : reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0])));
         }
         if (fr_s < 0) break;
         const u64 fr = (u64)fr_s;
@@ -760,7 +762,9 @@ const ShapeEntry kShapes[] = {
     shape_entry<ALG_MSA, 6, 3, 4, 8, 1>(),   shape_entry<ALG_SPA, 6, 3, 4, 8, 1>(),   shape_entry<ALG_BEC, 6, 3, 4, 8, 1>(),    // m <= 256, n <= 512
     shape_entry<ALG_MSA, 6, 3, 5, 10, 2>(),  shape_entry<ALG_SPA, 6, 3, 5, 10, 2>(),  shape_entry<ALG_BEC, 6, 3, 5, 10, 2>(),   // m <= 640, n <= 1280, 2 waves/frame
     shape_entry<ALG_MSA, 6, 3, 10, 19, 1>(), shape_entry<ALG_SPA, 6, 3, 10, 19, 1>(), shape_entry<ALG_BEC, 6, 3, 10, 19, 1>(),  // m <= 640, n <= 1216, 1 wave/frame
-    // irregular: check degrees <= 6 (short rows padded by a "certain" variable), variable degrees <= 8 (at most 256 above 3)
+    // irregular: check degrees <= 6 (short rows padded by a "certain" variable), variable degrees <= 8 (at most 256 above 3);
+    // two waves per frame (n <= 1215, system row) preferred, one wave per frame otherwise
+    shape_entry<ALG_MSA, 6, 3, 5, 10, 2, 2, 8>(), shape_entry<ALG_SPA, 6, 3, 5, 10, 2, 2, 8>(), shape_entry<ALG_BEC, 6, 3, 5, 10, 2, 2, 8>(),
     shape_entry<ALG_MSA, 6, 3, 10, 19, 1, 4, 8>(), shape_entry<ALG_SPA, 6, 3, 10, 19, 1, 4, 8>(), shape_entry<ALG_BEC, 6, 3, 10, 19, 1, 4, 8>(),
     // four waves per frame: m <= 1536, n <= 2816 (48 KB of LDS per frame, 3 frames per CU) -- e.g. the (3,6) Margulis code n = 2640
     shape_entry<ALG_MSA, 6, 3, 6, 11, 4>(),  shape_entry<ALG_SPA, 6, 3, 6, 11, 4>(),  shape_entry<ALG_BEC, 6, 3, 6, 11, 4>(),
@@ -827,7 +831,7 @@ int fused_plan_create(Decoder* d) {
     for (int i = 0; i < kNumShapes && si < 0; ++i) {
         const ShapeEntry& s = kShapes[i];
         const int CR = s.CRW * s.NW, VR = s.VRW * s.NW;
-        const bool big = s.NW > 4;  // one system row of variable slots is reserved
+        const bool big = s.NW > 4 || (s.NW > 1 && s.VRX > 0);  // shapes with a system row: one row of variable slots is reserved
         if (s.alg != d->alg || c->max_dc != s.DC || c->m > CR * 64 || c->n + (short_rows ? 1 : 0) > (VR - (big ? 1 : 0)) * 64) continue;
         if (force_nw && s.NW != force_nw) continue;
         if (s.VRX == 0) {
@@ -845,9 +849,10 @@ int fused_plan_create(Decoder* d) {
     const int DC = shape.DC, DV = shape.DV, NW = shape.NW, CRW = shape.CRW, VRW = shape.VRW;
     const int CR = CRW * NW, VR = VRW * NW, NPAD = VR * 64;
     VarRounds vr;
-    const bool BIG = NW > 4;
-    vr.VR = VR; vr.DV = DV; vr.vrx = shape.VRX; vr.dvx = shape.DVX; vr.nw = NW; vr.reserved = BIG ? 1 : 0;
-    p->sys_off = BIG ? (NPAD - 64) * 4 : 0;
+    const bool BIG = NW > 4;                         // dword-index tables, 160 KB frame
+    const bool SYS = BIG || (NW > 1 && shape.VRX > 0);  // system row (see the kernel)
+    vr.VR = VR; vr.DV = DV; vr.vrx = shape.VRX; vr.dvx = shape.DVX; vr.nw = NW; vr.reserved = SYS ? 1 : 0;
+    p->sys_off = SYS ? (NPAD - 64) * 4 : 0;
     p->shape = si; p->DC = DC; p->DV = DV; p->CR = CR; p->VR = VR; p->NW = NW;
     p->zero_row = (NW == 1) ? 1 : 0;
 
@@ -856,7 +861,7 @@ int fused_plan_create(Decoder* d) {
     const char* mode = std::getenv("LDPC_FUSED_LAYOUT");
     if (mode && std::string(mode) == "identity") {
         identity_layout(*c, DC, vr, &L);
-        if (NW > 1 && !BIG) {  // spread the checks / variables evenly over the waves so that every wave keeps padded slots
+        if (NW > 1 && !SYS) {  // spread the checks / variables evenly over the waves so that every wave keeps padded slots
             for (int cc = 0; cc < c->m; ++cc) L.chk_slot[cc] = (int)((int64_t)cc * CR * 64 / c->m);
             for (int v = 0; v < c->n; ++v) L.var_slot[v] = (int)((int64_t)v * NPAD / c->n);
         }
@@ -921,11 +926,11 @@ int fused_plan_create(Decoder* d) {
             if (!((used >> j) & 1u)) cn_addr[(size_t)(R * DC + j) * 64 + lane] = (int64_t)certain_slot * 4;
     }
     // where a missing edge reads its 0: the always-zero row behind the c2v area (one word per lane), or the zero word of the system row
-    auto zero_addr = [&](int lane) -> int64_t { return BIG ? (int64_t)p->sys_off + 33 * 4 : (int64_t)c2v_base + (int64_t)(CR * DC * 64 + lane) * 4; };
+    auto zero_addr = [&](int lane) -> int64_t { return SYS ? (int64_t)p->sys_off + 33 * 4 : (int64_t)c2v_base + (int64_t)(CR * DC * 64 + lane) * 4; };
     for (int v = 0; v < c->n; ++v) {
         const int Q = var_slot[v] / 64, lane = var_slot[v] % 64;
         // a real variable with fewer edges than its round gathers sums zeros for the missing ones
-        if (p->zero_row || BIG)
+        if (p->zero_row || SYS)
             for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = zero_addr(lane);
         for (int pidx = c->col_ptr[v]; pidx < c->col_ptr[v + 1]; ++pidx) {
             const int k = c->col_edge[pidx], cs = chk_slot[c->edge_chk[k]];
@@ -982,7 +987,7 @@ int fused_plan_create(Decoder* d) {
         for (int lane = 0; lane < 64; ++lane) put16(cn_tab, CNW, CRW * DC, K, lane, (uint32_t)(cn_addr[(size_t)K * 64 + lane] >> (BIG ? 2 : 0)));
     for (int K = 0; K < vr.total_gathers(); ++K)
         for (int lane = 0; lane < 64; ++lane) put16(vn_tab, VNW, VNK, K, lane, (uint32_t)(vn_addr[(size_t)K * 64 + lane] >> (BIG ? 2 : 0)));
-    if (NW > 1 && !BIG) {
+    if (NW > 1 && !SYS) {
         // hand-off words: for each wave the c2v slot (position dc-1) of one of its padded check lanes, in its LAST round
         // that has one (so the wave's own garbage write to it precedes the verdict write in program order)
         for (int wv = 0; wv < NW; ++wv) {

@@ -297,6 +297,31 @@ def test_fused_erasure_decoder_variants(nw, monkeypatch):
         assert (c[4:] == np.bincount(np.minimum(io, 50), minlength=51)).all()
 
 
+@pytest.mark.parametrize("nw", ["1", "2"])
+@pytest.mark.parametrize("alg", ["MSA", "BEC"])
+def test_fused_irregular_shapes(nw, alg, monkeypatch):
+    # the irregular n = 1200 code on both of its fused shapes (one wave per frame; two waves with the system row), ragged batches
+    from ldpc_decoders_amd import bec, bpa
+
+    monkeypatch.setenv("LDPC_FUSED_NW", nw)
+    g, code = _code("1200_rho_x5_rand_ldpc_5")
+    rng = np.random.RandomState(31)
+    for B in (3, 257):
+        if alg == "MSA":
+            y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(1.9)), (B, g.n))
+            pri = O.biawgn_priors(y, 1.9).astype(np.float32)
+            dec = bpa.MSA(code, max_iter=40, precision="f32", backend="fused")
+            xhat, iters = dec.decode_batch(None, pri)
+            xo, io = C.bp_decode(g, "MSA", None, pri, 40, dtype=np.float32)
+        else:
+            ye = (rng.random_sample((B, g.n)) < 0.42).astype(np.int64) * 2
+            dec = bec.SPA(0.42, code, max_iter=40, backend="fused")
+            xhat, iters = dec.decode_batch(ye)
+            xo, io = C.bec_decode(g, ye, 40)
+        assert dec.handle.fused_info()["waves_per_frame"] == float(nw)
+        assert (xhat == xo).all() and (iters == io).all()
+
+
 def test_layout_plan_store(monkeypatch, tmp_path):
     # the LDS placement only moves data around: shipped plan (ldpc_decoders_amd/plans), a plan annealed now, a plan saved and
     # read back, and the trivial placement all give the same bits as the oracle
