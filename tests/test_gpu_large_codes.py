@@ -137,3 +137,19 @@ def test_config3_spa_bsc_bec_batch():
     assert 0.003 < ber_e < 0.2  # reference ensemble (max_iter=10): 9.6e-2 at eps=.40 (data/output/bec-1200_3_6_rand_ldpc-SPA.json)
     xo, io = C.bec_decode(g, ye_h[idx], 50)
     assert (xe_h[idx] == xo).all() and (ie.cpu().numpy()[idx] == io).all()
+
+
+def test_config4_fused_deterministic():
+    import torch
+    from ldpc_decoders_amd import codes
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    code = codes.rand_irregular_ldpc(10000, codes.LAMBDA_RHO_X5_HALF_RATE, 6, np.random.RandomState(4))
+    h = DecoderHandle(code, "MSA", "f32", "fused")
+    pri, _ = h.channel_device("biawgn", 1.7, 0, 5, 0, 0, 1500)
+    x0, i0 = h.decode_device(pri, None, 50)
+    x0, i0 = x0.clone(), i0.clone()
+    assert len(torch.unique(i0)) > 3
+    for _ in range(4):
+        x1, i1 = h.decode_device(pri, None, 50)
+        assert torch.equal(x1, x0) and torch.equal(i1, i0)

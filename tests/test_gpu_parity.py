@@ -351,3 +351,27 @@ def test_layout_plan_store(monkeypatch, tmp_path):
     assert run() == fresh
     monkeypatch.setenv("LDPC_FUSED_LAYOUT", "identity")
     assert run() > 400
+
+
+@pytest.mark.parametrize("code_name,alg", [("1200_3_6_rand_ldpc_1", "MSA"), ("1200_rho_x5_rand_ldpc_5", "MSA"), ("margulis", "MSA"),
+                                           ("1200_3_6_rand_ldpc_1", "BEC"), ("margulis", "SPA")])
+def test_fused_multiwave_kernels_are_deterministic(code_name, alg):
+    # the waves of a frame hand verdicts to each other through LDS words: repeated decodes of one resident batch must give
+    # identical outputs (a lost or stale hand-off shows up as a differing iteration count)
+    import torch
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    g, code = _code(code_name)
+    h = DecoderHandle(code, alg, "f32", "fused")
+    assert h.fused_info()["waves_per_frame"] >= 2
+    if alg == "BEC":
+        pri, y = h.channel_device("bec", 0.41, 0, 5, 0, 0, 6000)
+    else:
+        pri, y = h.channel_device("biawgn", 1.8, 0, 5, 0, 0, 6000)
+        y = None
+    x0, i0 = h.decode_device(pri, y, 40)
+    x0, i0 = x0.clone(), i0.clone()
+    assert len(torch.unique(i0)) > 3
+    for _ in range(6):
+        x1, i1 = h.decode_device(pri, y, 40)
+        assert torch.equal(x1, x0) and torch.equal(i1, i0)
