@@ -205,6 +205,22 @@ def main():
                             "frac > 1 means the messages stayed on-chip (fused backend): the kernel is then LDS/VALU-bound, "
                             "see DESIGN.md" % (frac_bytes, kind),
                     "all_kernels_ms": {k: round(v[0], 3) for k, v in prof.items()}}
+        if roof is not None and kind == "fused_decode":
+            # what actually bounds the on-chip kernel: LDS instruction issue.  Per frame-sweep the kernel issues the gathers (2 LDS
+            # cycles each, conflict-free), their planned bank-conflict cycles, and one lane-contiguous store per message / marginal
+            # row (2 cycles each; the 16-wave shape pairs its message rows at 3 cycles per row) -- all known from the plan.
+            fi = handle.fused_info()
+            nw, cr, vr_ = int(fi["waves_per_frame"]), int(fi["check_rounds"]), int(fi["variable_rounds"])
+            store_cycles = (cr * 6 * (3 if nw > 4 else 2)) + vr_ * 2
+            lds_cycles = fi["lds_gather_cycles_min"] + fi["conflict_cycles_planned"] + store_cycles
+            frame_sweeps_per_s = iter_sum_rank0_share / (ms * 1e-3)
+            cus, clk = torch.cuda.get_device_properties(0).multi_processor_count, 2.4e9
+            roof["lds_pipe"] = {"bound": "lds", "unit": "LDS-array cycles/s per CU", "achieved": round(frame_sweeps_per_s * lds_cycles / cus, 1),
+                                "peak": clk, "frac": round(frame_sweeps_per_s * lds_cycles / cus / clk, 4),
+                                "cycles_per_frame_sweep": {"gathers": fi["lds_gather_cycles_min"], "planned_conflicts": fi["conflict_cycles_planned"],
+                                                           "stores": store_cycles},
+                                "note": "instruction-level model of the LDS pipe (MI355X_MICROARCH.md, LDS table) at a nominal 2.4 GHz; "
+                                        "measured SQ_LDS_IDX_ACTIVE per frame-sweep is in profiles/*_summary.md"}
         out = {
             "metric": ("decoded frames/s, n=1200 (3,6) min-sum max_iter=50 (+ achieved HBM GB/s in roofline)"
                        if args.code == "1200_3_6_rand_ldpc_1" and args.max_iter == 50 else
