@@ -100,14 +100,19 @@ __device__ __forceinline__ void cn_spa(double (&v)[DCMAX], int deg) {
 __device__ __forceinline__ float spa_u_of_llr(float a) {  // a = |v2c| >= 0  ->  e^-a on the exp2 unit (v_exp_f32, ~1 ulp)
     return __builtin_amdgcn_exp2f(a * -1.44269504088896340736f);
 }
-__device__ __forceinline__ void spa_eo_push(float& e, float& o, float u) {  // append one edge
-    const float e2 = fmaf(u, o, e);
-    o = fmaf(u, e, o);
-    e = e2;
+typedef float spa_f2 __attribute__((ext_vector_type(2)));
+// Both recurrences are 2-wide: written on float2 so that they map to the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32:
+// one instruction per pair; per component the same IEEE fma / multiply as the scalar form, so results are unchanged).
+__device__ __forceinline__ void spa_eo_push(float& e, float& o, float u) {  // append one edge: (E + uO, O + uE)
+    const spa_f2 r = __builtin_elementwise_fma(spa_f2{u, u}, spa_f2{o, e}, spa_f2{e, o});
+    e = r.x;
+    o = r.y;
 }
 __device__ __forceinline__ float spa_llr_of_eo(float ep, float op, float es, float os) {  // ln(E/O) of prefix x suffix
-    const float e = fmaf(op, os, ep * es);
-    const float o = fmaxf(fmaf(op, es, ep * os), 1.17549435e-38f);
+    const spa_f2 t = spa_f2{ep, ep} * spa_f2{es, os};
+    const spa_f2 r = __builtin_elementwise_fma(spa_f2{op, op}, spa_f2{os, es}, t);  // (EpEs + OpOs, EpOs + OpEs)
+    const float e = r.x;
+    const float o = fmaxf(r.y, 1.17549435e-38f);
     return 0.69314718055994530942f * (__builtin_amdgcn_logf(e) - __builtin_amdgcn_logf(o));  // v_log_f32 is log2
 }
 
