@@ -274,3 +274,45 @@ class AdmmHandle:
         _lib.check(_lib.load().ldpc_admm_decode(self.h, gamma.data_ptr(), B, float(mu), float(eps), int(max_iter), x.data_ptr(),
                                                 iters.data_ptr(), conv.data_ptr(), st))
         return x, iters, conv
+
+    # knobs of the simulate() composition below, set by admm.ADMM
+    mu, eps, allow_pseudo, on_iters = 3.0, 1e-5, False, None
+
+    def simulate(self, channel, param, codeword, seed, stream_id, frame0, B, max_iter, counters, flags=0, hist_bins=0):
+        """Same call shape as DecoderHandle.simulate: device channel kernel -> LLRs -> ADMM -> pseudo_to_cw -> counters, all
+        on the GPU (a composition of ldpc_channel / ldpc_admm_decode / torch element-wise ops; no host noise)."""
+        import torch
+
+        if B <= 0:
+            return
+        lib, n = _lib.load(), self.code.n
+        st = torch.cuda.current_stream(counters.device).cuda_stream
+        step = 1 << 15
+        for b0 in range(0, int(B), step):
+            nb = min(step, int(B) - b0)
+            if channel == "bec":
+                y = torch.empty((nb, n), dtype=torch.uint8, device=counters.device)
+                _lib.check(lib.ldpc_channel(_lib.CHANNEL[channel], 0, float(param), int(codeword), int(seed), int(stream_id), int(frame0) + b0,
+                                            nb, n, None, y.data_ptr(), st))
+                gamma = torch.tensor([1e8, -1e8, 0.0], dtype=torch.float64, device=counters.device)[y.long()]  # src/bec.py:41
+            else:
+                gamma = torch.empty((nb, n), dtype=torch.float64, device=counters.device)
+                y = torch.empty((nb, n), dtype=torch.uint8, device=counters.device) if channel == "bsc" else None
+                _lib.check(lib.ldpc_channel(_lib.CHANNEL[channel], _lib.DTYPE["f64"], float(param), int(codeword), int(seed), int(stream_id),
+                                            int(frame0) + b0, nb, n, gamma.data_ptr(), None if y is None else y.data_ptr(), st))
+            x, iters, _ = self.decode_device(gamma.contiguous(), self.mu, self.eps, max_iter)
+            if self.allow_pseudo:  # src/math_utils.py:28-34, then `x != x_hat` as src/main.py:41
+                x = torch.where(x < 1e-8, torch.zeros_like(x), x)
+                x = torch.where(1 - x < 1e-8, torch.ones_like(x), x)
+                wrong = x != float(codeword)
+            else:
+                wrong = (x > .5) != bool(codeword)
+            err = wrong.sum(dim=1)
+            counters[_lib.CNT_TOT] += nb
+            counters[_lib.CNT_WEC] += (err > 0).sum()
+            counters[_lib.CNT_BEC] += err.sum()
+            counters[_lib.CNT_ITER_SUM] += iters.sum()
+            if hist_bins:
+                counters[_lib.CNT_HIST0:_lib.CNT_HIST0 + hist_bins] += torch.bincount(iters.clamp(max=hist_bins - 1).long(), minlength=hist_bins)
+            if self.on_iters is not None:
+                self.on_iters(iters)

@@ -27,6 +27,8 @@ class ADMM:
         self.mu, self.max_iter, self.eps = kwargs["mu"], kwargs["max_iter"], kwargs["eps"]
         self.code = as_code(parity_mtx)
         self.handle = AdmmHandle(self.code, kwargs.get("device"))
+        self.handle.mu, self.handle.eps, self.handle.allow_pseudo = self.mu, self.eps, bool(self.allow_pseudo)
+        self.handle.on_iters = lambda it: self._count(it.cpu().numpy())  # device Monte-Carlo feeds the same histogram
         self.iter = np.zeros(2000, dtype=int)  # src/admm.py:36
         self.last_iters = None
 

@@ -78,7 +78,7 @@ def test(args, comm=None):
             # one frame per call keeps numpy's stream in the reference's order (send, [ML pick], send, ..)
             if exact:
                 chunk = 1 if (code_n < 64 or args.decoder in ("ML", "ADMM")) else 32
-            else:  # ADMM without --exact: host noise, frames decoded in batches (counters still stop at the first prefix)
+            else:  # a decoder without a device Monte-Carlo path: host noise, frames decoded in batches
                 chunk = max(1, min(args.batch, 4096))
             c = run_point_exact(channel, decoder, x, args.min_wec, chunk=chunk, on_progress=progress, pick_word=pick)
         else:

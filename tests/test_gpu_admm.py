@@ -97,13 +97,17 @@ def test_exact_mode_reproduces_reference_admm_counters(run, tmp_path):
         assert got["dec"][prm]["iter"] == want["dec"][prm]["iter"]  # the decoder's iteration histogram (src/admm.py:38-40)
 
 
-def test_admm_host_noise_batches_cli(tmp_path):
+def test_admm_device_monte_carlo_cli(tmp_path):
+    # device-noise mode (channel kernel -> ADMM -> counters on the GPU) for all three channels; rates against the reference's
+    # own seeded golden runs (tests/golden/main_counters_admm.json: bsc p=.1 WER 40/136, biawgn 2 dB 40/343, bec .3 40/193)
     from ldpc_decoders_amd import main
 
-    res = main.main("bsc 7_4_hamming ADMM --codeword 0 --min-wec 300 --max-iter 100 --params 0.1 --batch 512".split()
-                    + ["--data_dir", str(tmp_path), "--console", "--np-seed", "3"])
-    # reference golden run (40 word errors): WER 40/136 = 0.29 at p = 0.1
-    assert res[0.1]["wec"] == 300 and 0.2 < res[0.1]["wer"] < 0.4
+    for ch, prm, lo, hi, extra in (("bsc", 0.1, 0.2, 0.4, []), ("biawgn", 2.0, 0.08, 0.16, []), ("bec", 0.3, 0.14, 0.28, ["--allow-pseudo"])):
+        res = main.main(("%s 7_4_hamming ADMM --codeword 0 --min-wec 2000 --max-iter 100 --params %g --batch 8192" % (ch, prm)).split()
+                        + extra + ["--data_dir", str(tmp_path), "--console"])
+        r = res[prm]
+        assert r["wec"] >= 2000 and r["tot"] % 8192 == 0 and lo < r["wer"] < hi, (ch, r)
+        assert sum(r["dec"]["iter"]) == r["tot"]  # every decoded frame is in the iteration histogram
 
 
 def test_admm_edge_cases():
