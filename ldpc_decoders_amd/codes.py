@@ -250,3 +250,39 @@ def rand_irregular_ldpc(n, lambda_edge, dc, rng=None):
 
 # lambda(x) of the reference's LP design for rho(x) = x^5, rate 1/2 (from ldpc.solve_dist src/ldpc.py:83-94)
 LAMBDA_RHO_X5_HALF_RATE = {2: 0.4126, 3: 0.1763, 4: 0.1189, 7: 0.1136, 8: 0.1786}
+
+
+def gen_rand_ldpc(args):
+    """CLI of the reference's code generators: ``python src/codes.py <count> <n> <l> <r>`` (src/codes.py:139-174) writes
+    ``<n>_<l>_<r>_rand_ldpc_<i>.txt``; with ``--irregular`` the rate-1/2 rho = x^5 ensemble of ``python src/ldpc.py irg``
+    (src/ldpc.py:149-192) as ``<n>_rho_x5_rand_ldpc_<i>.txt``.  Files land in $FILE_CODES_DIR (default data/codes)."""
+    out = []
+    for i in range(args.count):
+        if args.irregular:
+            code = rand_irregular_ldpc(args.n, LAMBDA_RHO_X5_HALF_RATE, 6)
+            name = "%d_rho_x5_rand_ldpc_%d" % (args.n, i + 1)
+        else:
+            code = rand_reg_ldpc(args.n, args.l, args.r)
+            name = "%d_%d_%d_rand_ldpc_%d" % (args.n, args.l, args.r, i + 1)
+        path = save_parity_mtx(code, name, args.dir)
+        chk = load_parity_mtx(path)  # verify_rand_reg_ldpc (src/codes.py:148-152): reload and report the degrees
+        print(name, (chk.m, chk.n), sorted(set(chk.col_degrees().tolist())), sorted(set(chk.row_degrees().tolist())))
+        out.append(path)
+    return out
+
+
+def setup_parser():
+    import argparse
+
+    p = argparse.ArgumentParser()
+    p.add_argument("count", help="number of random codes to generate", type=int)
+    p.add_argument("n", help="code length", type=int)
+    p.add_argument("l", help="variable degree of the regular ensemble", type=int, nargs="?", default=3)
+    p.add_argument("r", help="check degree of the regular ensemble", type=int, nargs="?", default=6)
+    p.add_argument("--irregular", action="store_true", help="rate-1/2 irregular ensemble (lambda of the reference's LP design, rho = x^5)")
+    p.add_argument("--dir", default=None, help="output directory (default: $FILE_CODES_DIR or data/codes)")
+    return p
+
+
+if __name__ == "__main__":
+    gen_rand_ldpc(setup_parser().parse_args())

@@ -137,3 +137,17 @@ def test_simulation_case_tables_match_reference(case):
     assert simulations.lines(case, extra, all_decoders=True) == want
     bp_only = simulations.lines(case, extra)
     assert bp_only == [ln for ln in want if ln.split()[2] in ("SPA", "MSA")] and len(bp_only) > 0
+
+
+def test_code_generator_cli(tmp_path):
+    # python -m ldpc_decoders_amd.codes <count> <n> <l> <r>  (reference: python src/codes.py ..., src/codes.py:139-174)
+    from ldpc_decoders_amd import codes
+
+    np.random.seed(4)
+    paths = codes.gen_rand_ldpc(codes.setup_parser().parse_args(["2", "96", "3", "6", "--dir", str(tmp_path)]))
+    assert [os.path.basename(p) for p in paths] == ["96_3_6_rand_ldpc_1.txt", "96_3_6_rand_ldpc_2.txt"]
+    c = codes.load_parity_mtx(paths[1])
+    assert (c.m, c.n) == (48, 96) and set(c.col_degrees()) == {3} and set(c.row_degrees()) == {6}
+    paths = codes.gen_rand_ldpc(codes.setup_parser().parse_args(["1", "1200", "--irregular", "--dir", str(tmp_path)]))
+    c = codes.load_parity_mtx(paths[0])
+    assert c.n == 1200 and c.col_degrees().max() == 8 and set(np.unique(c.row_degrees())) <= {2, 4, 6}
