@@ -1,0 +1,60 @@
+"""One artifact for every BASELINE.json configuration that runs on a GPU (configs 2-5), single MI355X, device Monte-Carlo
+(channel + decode + count on the GPU, `ldpc_simulate`).  Writes profiles/<tag>_all_configs.json.
+
+    python tools/measure_configs.py [tag]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from bench import load_code  # noqa: E402
+from ldpc_decoders_amd._device import DecoderHandle  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+CASES = [  # config, code, decoder alg, channel, param, batch, steps, backend
+    ("2: n=1200 (3,6) MSA BI-AWGN", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 1.0, 65536, 6, "auto"),
+    ("2: n=1200 (3,6) MSA BI-AWGN", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 2.0, 65536, 6, "auto"),
+    ("3: n=1200 (3,6) SPA BSC", "1200_3_6_rand_ldpc_1", "SPA", "bsc", 0.07, 65536, 6, "auto"),
+    ("3: n=1200 (3,6) SPA BSC", "1200_3_6_rand_ldpc_1", "SPA", "bsc", 0.05, 65536, 6, "auto"),
+    ("3: n=1200 (3,6) erasure decoder BEC", "1200_3_6_rand_ldpc_1", "BEC", "bec", 0.40, 65536, 6, "auto"),
+    ("3: n=1200 (3,6) erasure decoder BEC", "1200_3_6_rand_ldpc_1", "BEC", "bec", 0.35, 65536, 6, "auto"),
+    ("4: rate-1/2 irregular n=10000 MSA (2^20 frames over 8 GPUs = 131072 per GPU)", "gen:irg:10000", "MSA", "biawgn", 1.2, 131072, 2, "auto"),
+    ("4: rate-1/2 irregular n=10000 MSA (2^20 frames over 8 GPUs = 131072 per GPU)", "gen:irg:10000", "MSA", "biawgn", 1.8, 131072, 2, "auto"),
+    ("4: same, streaming kernels", "gen:irg:10000", "MSA", "biawgn", 1.2, 32768, 1, "stream"),
+    ("5: (3,6) n=64800 MSA, early termination (2^18 frames over 8 GPUs = 32768 per GPU)", "gen:reg:64800:3:6", "MSA", "biawgn", 1.0, 32768, 1, "auto"),
+    ("5: (3,6) n=64800 MSA, early termination (2^18 frames over 8 GPUs = 32768 per GPU)", "gen:reg:64800:3:6", "MSA", "biawgn", 2.0, 32768, 1, "auto"),
+]
+rows = []
+cache = {}
+for cfg, code_name, alg, ch, prm, B, steps, backend in CASES:
+    if code_name not in cache:
+        cache[code_name] = load_code(code_name)
+    g, code = cache[code_name]
+    h = DecoderHandle(code, alg, "f32", backend)
+    cnt = torch.zeros(4 + 51, dtype=torch.int64, device="cuda")
+    h.simulate(ch, prm, 0, 0x5EED1200, 0, 0, B, 50, cnt, hist_bins=51)  # warm-up at full size: workspaces are allocated here
+    torch.cuda.synchronize()
+    cnt.zero_()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        h.simulate(ch, prm, 0, 0x5EED1200, 1, s * B, B, 50, cnt, hist_bins=51)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = cnt.cpu().numpy()
+    frames, sweeps = int(c[0]), int(c[3])
+    bytes_fs = 4 * (4 * g.E + g.n) if alg != "BEC" else (4 * g.E + g.n)
+    rows.append(dict(config=cfg, code=code_name, n=g.n, E=g.E, decoder=alg, channel=ch, param=prm, max_iter=50, frames_per_step=B, steps=steps,
+                     backend=h.last_stats()[0], waves_per_frame=h.fused_info()["waves_per_frame"] if h.last_stats()[0] == "fused" else 0,
+                     frames_per_s=round(frames / dt, 1), ms_per_step=round(1e3 * dt / steps, 3), mean_sweeps=round(sweeps / frames, 3),
+                     wer=round(int(c[1]) / frames, 6), ber=int(c[2]) / (frames * g.n),
+                     algorithmic_GBps=round(sweeps * bytes_fs / dt / 1e9, 1)))
+    print(json.dumps(rows[-1]), flush=True)
+    del h
+with open(os.path.join(ROOT, "profiles", "%s_all_configs.json" % tag), "w") as fp:
+    json.dump(dict(device=torch.cuda.get_device_name(0), note="tools/measure_configs.py: whole hot path (device channel + decode + count), "
+                   "fp32 message arithmetic, max_iter 50; algorithmic_GBps = executed sweeps x s(4E+n) / time (SURVEY 8(d))", rows=rows), fp, indent=1)
