@@ -151,3 +151,24 @@ def test_code_generator_cli(tmp_path):
     paths = codes.gen_rand_ldpc(codes.setup_parser().parse_args(["1", "1200", "--irregular", "--dir", str(tmp_path)]))
     c = codes.load_parity_mtx(paths[0])
     assert c.n == 1200 and c.col_degrees().max() == 8 and set(np.unique(c.row_degrees())) <= {2, 4, 6}
+
+
+def test_product_fails_loudly_without_the_hip_library_or_a_gpu(tmp_path):
+    # no CPU fallback anywhere: a missing libldpc_hip.so raises at load, and on a host without a GPU constructing a decoder
+    # raises from the library (hipMalloc / hipSetDevice fails) instead of computing something on the CPU
+    import subprocess
+    import sys
+
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['LDPC_LIB_PATH'] = %r\n"
+            "from ldpc_decoders_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.LdpcHipError as e:\n    print('RAISED', 'no CPU fallback' in str(e))\n"
+            % (ROOT, str(tmp_path / "missing.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
+    import torch
+
+    if not torch.cuda.is_available():
+        from ldpc_decoders_amd import _lib, bpa, codes
+
+        with pytest.raises(_lib.LdpcHipError):
+            bpa.MSA(codes.get_code("7_4_hamming"), max_iter=5)
