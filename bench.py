@@ -180,7 +180,7 @@ def main():
         dt = time.perf_counter() - t0
         hbm_leg = {"frames_per_s": round(args.steps * args.batch / dt, 1), "ms_per_step": round(1e3 * dt / args.steps, 3),
                    "mean_sweeps": round(float(cnt[3]) / float(cnt[0]), 3),
-                   "note": "priors [B,n] fp32 resident in HBM before the timed region; decode (ldpc_decode) + error counting (ldpc_count_errors)"}
+                   "note": "priors [B,n] %s resident in HBM before the timed region; decode (ldpc_decode) + error counting (ldpc_count_errors)" % args.precision}
         del pri, xh, it
 
     def summarise(snr, r, steps):

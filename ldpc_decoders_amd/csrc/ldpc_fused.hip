@@ -116,7 +116,7 @@ __device__ __forceinline__ void lds_st2_rows(uint32_t vaddr, float a, float b) {
 }
 
 struct FusedArgs {
-    const float* priors;
+    const void* priors;             // [B,n] float (fp32 kernels) or double (fp64 min-sum kernel)
     const uint8_t* y0;
     long long B;
     int n, max_iter;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
                 prior[q] = y == 0 ? -1.0f : (y == 1 ? 1.0f : 0.0f);
             }
         } else {
-            const float* pf = A.priors + fr * n;
+            const float* pf = reinterpret_cast<const float*>(A.priors) + fr * n;
 #pragma unroll
             for (int q = 0; q < VRW; ++q) {
                 const int v = vmap_of(q);
@@ -737,6 +737,202 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp64 min-sum on the LDS: the reference's own arithmetic (src/bpa.py:17-63, 86-102 compute in float64), so hard decisions and
+// iteration counts are bit-identical to the reference on identical priors -- at LDS speed instead of HBM speed.  (3,6)-regular
+// codes; NW waves per frame with the system-row hand-off protocol of the big fp32 shapes (last marginal row reserved: dwords
+// [0,16) verdict channel A, [32] frame hand-out).  Same tables and layout plan as the fp32 kernels with 8-byte elements;
+// gathers are ds_read_b64 (2 LDS cycles, as b32), stores ds_write_b64.  Decode only: the Monte-Carlo driver composes
+// channel kernel -> this kernel -> counting kernel.
+template <int DC, int DV, int CRW, int VRW, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_msa64(const FusedArgs A) {
+    constexpr int VR = VRW * NW, NPAD = VR * 64;
+    constexpr int VNK = VRW * DV, CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    double* const lds = reinterpret_cast<double*>(smem);
+    double* const my_marg = lds + w * VRW * 64 + lane;                  // row q of this wave at my_marg[q * 64]
+    double* const my_c2v = lds + NPAD + w * CRW * DC * 64 + lane;       // message (r, j) of this wave at my_c2v[(r * DC + j) * 64]
+    const int32_t* vslot = A.var_of_slot + w * VRW * 64;
+    const int n = A.n, max_iter = A.max_iter;
+    const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
+    const bool own_last = !(NW > 1 && w == NW - 1);
+    auto sysw = [&](int i) { return reinterpret_cast<volatile uint32_t*>(smem + A.sys_off) + i; };
+    auto gat = [&](uint32_t byte_off) { return *reinterpret_cast<const double*>(smem + byte_off); };
+    if (threadIdx.x == 0) {  // the always-zero double (system-row bytes 136..143) that missing edges gather
+        *sysw(34) = 0u;
+        *sysw(35) = 0u;
+    }
+
+    uint32_t cn_idx[CNW], vn_idx[VNW];
+#pragma unroll
+    for (int i = 0; i < CNW; ++i) cn_idx[i] = A.cn_tab[(w * CNW + i) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < VNW; ++i) vn_idx[i] = A.vn_tab[(w * VNW + i) * 64 + lane];
+    int vmap[VRW];
+#pragma unroll
+    for (int q = 0; q < VRW; ++q) vmap[q] = vslot[q * 64 + lane];
+
+    auto any_unsat = [&](bool mine) -> bool {  // contains the barrier that separates the phases
+        if constexpr (NW == 1) {
+            __builtin_amdgcn_wave_barrier();
+            return mine;
+        } else {
+            if (lane == 0) *sysw(w) = mine ? 1u : 0u;
+            __syncthreads();
+            return __ballot(*sysw(lane & (NW - 1)) != 0u) != 0;
+        }
+    };
+    auto phase_barrier = [&]() {
+        if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    };
+
+    constexpr int NSHARD = 8;
+    const long long shard_len = (A.B + NSHARD - 1) / NSHARD;
+    int shard = (int)(blockIdx.x % NSHARD), shards_left = NSHARD;
+    auto next_frame = [&]() -> long long {
+        long long got = -1;
+        while (shards_left > 0) {
+            const long long base = shard * shard_len;
+            const long long len = (base + shard_len <= A.B ? shard_len : A.B - base);
+            u64 t = 0;
+            if (lane == 0) t = atomicAdd(A.next_frame + shard * 8, 1ull);
+            const long long k = (long long)(((u64)__builtin_amdgcn_readfirstlane((unsigned)(t >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)t));
+            if (k < len) { got = base + k; break; }
+            shard = (shard + 1) % NSHARD;
+            --shards_left;
+        }
+        return got;
+    };
+    const double* priors = reinterpret_cast<const double*>(A.priors);
+    for (;;) {
+        long long fr_s;
+        if constexpr (NW == 1) {
+            fr_s = next_frame();
+        } else {
+            __syncthreads();
+            if (w == 0) {
+                const long long f0 = next_frame();
+                if (lane == 0) *sysw(32) = (uint32_t)(int32_t)f0;
+            }
+            __syncthreads();
+            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*sysw(32));
+        }
+        if (fr_s < 0) break;
+        const u64 fr = (u64)fr_s;
+        double prior[VRW], c2v_old[CRW][DC];
+        unsigned xb = 0;
+        const double* pf = priors + fr * n;
+#pragma unroll
+        for (int q = 0; q < VRW; ++q) prior[q] = vmap[q] >= 0 ? pf[vmap[q]] : 0.0;
+#pragma unroll
+        for (int r = 0; r < CRW; ++r)
+#pragma unroll
+            for (int j = 0; j < DC; ++j) c2v_old[r][j] = 0.0;
+        int it = 0;
+        bool left_at_0 = false;
+        if (A.y0 != nullptr) {  // iteration-0 test of the received hard word (src/bpa.py:20,29)
+            const uint8_t* yf = A.y0 + fr * n;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                const bool one = vmap[q] >= 0 && yf[vmap[q]] != 0;
+                if (q < VRW - 1 || own_last) my_marg[q * 64] = one ? -1.0 : 1.0;
+                xb |= one ? (1u << q) : 0u;
+            }
+            phase_barrier();
+            u64 unsat = 0;
+#pragma unroll
+            for (int r = 0; r < CRW; ++r) {
+                u64 par = 0;
+#pragma unroll
+                for (int j = 0; j < DC; ++j) par ^= __ballot(gat(half_of<CRW * DC>(cn_idx, r * DC + j)) < 0.0);
+                unsat |= par;  // even dc: a padded check lane reads one marginal dc times -> even parity
+            }
+            left_at_0 = early && !any_unsat(unsat != 0);
+            phase_barrier();
+        }
+        if (!left_at_0) {
+#pragma unroll
+            for (int q = 0; q < VRW; ++q)
+                if (q < VRW - 1 || own_last) my_marg[q * 64] = prior[q];
+            phase_barrier();
+            for (;;) {
+                if (max_iter > 0 && it >= max_iter) break;
+                // ---- check phase (+ syndrome of the previous decisions: sign of the gathered marginals)
+                uint32_t synd = 0;
+                double mg[2][DC];
+#pragma unroll
+                for (int j = 0; j < DC; ++j) mg[0][j] = gat(half_of<CRW * DC>(cn_idx, j));
+                static_for<0, CRW>([&](auto R_) {
+                    constexpr int r = decltype(R_)::value;
+                    if constexpr (r + 1 < CRW) {
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = gat(half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double v[DC], a[DC];
+                    uint32_t vx = 0, mx = 0;  // XOR of the sign words (high dwords); v is never -0.0 (marginals start from +0.0 sums)
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) {
+                        v[j] = mg[r & 1][j] - c2v_old[r][j];
+                        a[j] = __builtin_fabs(v[j]);
+                        vx ^= (uint32_t)__double2hiint(v[j]);
+                        mx ^= (uint32_t)__double2hiint(mg[r & 1][j]);
+                    }
+                    synd |= mx;
+                    static_assert(DC == 6, "leave-one-out network written for dc = 6");
+                    const double s3 = fmin(a[4], a[5]), s2 = fmin(fmin(a[3], a[4]), a[5]), s1 = fmin(a[2], s2);
+                    const double p2 = fmin(a[0], a[1]), p3 = fmin(fmin(a[0], a[1]), a[2]);
+                    double mag[DC];
+                    mag[0] = fmin(fmin(a[1], a[2]), s2);
+                    mag[1] = fmin(a[0], s1);
+                    mag[2] = fmin(p2, s2);
+                    mag[3] = fmin(p3, s3);
+                    mag[4] = fmin(fmin(p3, a[3]), a[5]);
+                    mag[5] = fmin(fmin(p3, a[3]), a[4]);
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) {
+                        const uint32_t sgn = (vx ^ (uint32_t)__double2hiint(v[j])) & 0x80000000u;
+                        const double c = __hiloint2double((int)((uint32_t)__double2hiint(mag[j]) | sgn), __double2loint(mag[j]));
+                        c2v_old[r][j] = c;
+                        my_c2v[(r * DC + j) * 64] = c;
+                    }
+                });
+                const bool unsat = any_unsat(__ballot((synd & 0x80000000u) != 0u) != 0);
+                if (early && it > 0 && !unsat) break;
+                // ---- variable phase: ordered sum from +0.0 (scipy COO), prior last, decision bit
+                xb = 0;
+                double cv[2][DV];
+#pragma unroll
+                for (int j = 0; j < DV; ++j) cv[0][j] = gat(half_of<VNK>(vn_idx, j));
+                static_for<0, VRW>([&](auto Q_) {
+                    constexpr int q = decltype(Q_)::value;
+                    if constexpr (q + 1 < VRW) {
+#pragma unroll
+                        for (int j = 0; j < DV; ++j) cv[(q + 1) & 1][j] = gat(half_of<VNK>(vn_idx, (q + 1) * DV + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double sn = 0.0 + cv[q & 1][0];
+#pragma unroll
+                    for (int j = 1; j < DV; ++j) sn += cv[q & 1][j];
+                    const double m1 = prior[q] + sn;
+                    if (q < VRW - 1 || own_last) my_marg[q * 64] = m1;
+                    xb |= (m1 < 0.0) ? (1u << q) : 0u;
+                });
+                phase_barrier();
+                ++it;
+            }
+        }
+        if (w == 0 && lane == 0) A.iters[fr] = it;
+        uint8_t* xf = A.xhat + fr * n;
+#pragma unroll
+        for (int q = 0; q < VRW; ++q)
+            if (vmap[q] >= 0) xf[vmap[q]] = (uint8_t)((xb >> q) & 1u);
+    }
+}
+
 template <typename T>
 int upload_vec(const std::vector<T>& h, T** d) {
     LDPC_HIP_TRY(hipMalloc((void**)d, (h.size() + 1) * sizeof(T)));
@@ -747,8 +943,14 @@ int upload_vec(const std::vector<T>& h, T** d) {
 struct ShapeEntry {
     int alg, DC, DV, CRW, VRW, NW, VRX, DVX;  // VRX wide variable rounds of DVX gathers (irregular codes), 0 for regular
     const void* kernel;      // decode: priors in, decisions out
-    const void* kernel_sim;  // simulate: noise in the kernel, counters out
+    const void* kernel_sim;  // simulate: noise in the kernel, counters out (null: decode only)
+    int esz = 4;             // bytes per LDS element: 4 (fp32 kernels), 8 (fp64 min-sum)
 };
+
+template <int DC, int DV, int CRW, int VRW, int NW>
+constexpr ShapeEntry shape_entry64() {
+    return ShapeEntry{ALG_MSA, DC, DV, CRW, VRW, NW, 0, DV, (const void*)k_fused_msa64<DC, DV, CRW, VRW, NW>, nullptr, 8};
+}
 
 template <int ALG, int DC, int DV, int CRW, int VRW, int NW, int VRX = 0, int DVX = DV>
 constexpr ShapeEntry shape_entry() {
@@ -771,6 +973,10 @@ const ShapeEntry kShapes[] = {
     // sixteen waves per frame, the whole LDS of a CU (160 KB) for one frame: m <= 5120, n <= 10 175, check degrees <= 6,
     // variable degrees <= 8 (at most 3072 above 3) -- the rate-1/2 irregular n = 10 000 ensemble
     shape_entry<ALG_MSA, 6, 3, 5, 10, 16, 3, 8>(), shape_entry<ALG_SPA, 6, 3, 5, 10, 16, 3, 8>(), shape_entry<ALG_BEC, 6, 3, 5, 10, 16, 3, 8>(),
+    // fp64 min-sum (the reference's arithmetic): (3,6)-regular, n <= 1216 (one marginal row reserved).  Two waves per frame
+    // (40 KB of LDS per frame, 4 frames per CU) measured 3 % faster than four (46 KB, 3 frames): 6.66 vs 6.87 ms per 65 536 frames
+    shape_entry64<6, 3, 5, 10, 2>(),
+    shape_entry64<6, 3, 3, 5, 4>(),
 };
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
@@ -821,7 +1027,9 @@ int fused_plan_create(Decoder* d) {
     const Code* c = d->code;
     d->fused = new FusedPlan();
     FusedPlan* p = d->fused;
-    if (d->alg != ALG_BEC && d->dtype != DT_F32) return LDPC_OK;  // fp64 message arithmetic stays on the streaming backend
+    // fp64 message arithmetic: min-sum has an LDS kernel of its own, sum-product stays on the streaming backend
+    if (d->alg != ALG_BEC && d->dtype != DT_F32 && !(d->alg == ALG_MSA && d->dtype == DT_F64)) return LDPC_OK;
+    const int want_esz = (d->alg == ALG_MSA && d->dtype == DT_F64) ? 8 : 4;
     const bool full_dv = c->min_dv == c->max_dv;  // every variable has all its DV edges: no zero row needed
     const bool short_rows = c->min_dc != c->max_dc;
     if (c->min_dc < 1) return LDPC_OK;
@@ -831,7 +1039,8 @@ int fused_plan_create(Decoder* d) {
     for (int i = 0; i < kNumShapes && si < 0; ++i) {
         const ShapeEntry& s = kShapes[i];
         const int CR = s.CRW * s.NW, VR = s.VRW * s.NW;
-        const bool big = s.NW > 4 || (s.NW > 1 && s.VRX > 0);  // shapes with a system row: one row of variable slots is reserved
+        const bool big = s.NW > 4 || (s.NW > 1 && s.VRX > 0) || s.esz == 8;  // shapes with a system row: one row of variable slots is reserved
+        if (s.esz != want_esz) continue;
         if (s.alg != d->alg || c->max_dc != s.DC || c->m > CR * 64 || c->n + (short_rows ? 1 : 0) > (VR - (big ? 1 : 0)) * 64) continue;
         if (force_nw && s.NW != force_nw) continue;
         if (s.VRX == 0) {
@@ -850,9 +1059,10 @@ int fused_plan_create(Decoder* d) {
     const int CR = CRW * NW, VR = VRW * NW, NPAD = VR * 64;
     VarRounds vr;
     const bool BIG = NW > 4;                         // dword-index tables, 160 KB frame
-    const bool SYS = BIG || (NW > 1 && shape.VRX > 0);  // system row (see the kernel)
+    const int esz = shape.esz;
+    const bool SYS = BIG || (NW > 1 && shape.VRX > 0) || esz == 8;  // system row (see the kernels)
     vr.VR = VR; vr.DV = DV; vr.vrx = shape.VRX; vr.dvx = shape.DVX; vr.nw = NW; vr.reserved = SYS ? 1 : 0;
-    p->sys_off = SYS ? (NPAD - 64) * 4 : 0;
+    p->sys_off = SYS ? (NPAD - 64) * esz : 0;
     p->shape = si; p->DC = DC; p->DV = DV; p->CR = CR; p->VR = VR; p->NW = NW;
     p->zero_row = (NW == 1) ? 1 : 0;
 
@@ -903,7 +1113,7 @@ int fused_plan_create(Decoder* d) {
         uint32_t& w = tab[((size_t)wv * words_per_wave + (k >> 1)) * 64 + lane];
         w = (k & 1) ? ((w & 0x0000ffffu) | (val << 16)) : ((w & 0xffff0000u) | val);
     };
-    const uint32_t c2v_base = (uint32_t)NPAD * 4;
+    const uint32_t c2v_base = (uint32_t)NPAD * esz;
     std::vector<int64_t> cn_addr((size_t)CR * DC * 64, -1), vn_addr((size_t)vr.total_gathers() * 64, -1);  // byte offsets, -1 = padded lane
     for (int v = 0; v < c->n; ++v) var_of_slot[var_slot[v]] = v;
     // short check rows are padded with reads of one "certain" variable slot (marked -2): +-inf marginal, see the kernel
@@ -919,14 +1129,14 @@ int fused_plan_create(Decoder* d) {
         cn_active[R] |= 1ull << lane;
         unsigned used = 0;
         for (int k = c->row_ptr[cc]; k < c->row_ptr[cc + 1]; ++k) {
-            cn_addr[(size_t)(R * DC + edge_pos[k]) * 64 + lane] = (int64_t)var_slot[c->edge_var[k]] * 4;
+            cn_addr[(size_t)(R * DC + edge_pos[k]) * 64 + lane] = (int64_t)var_slot[c->edge_var[k]] * esz;
             used |= 1u << edge_pos[k];
         }
         for (int j = 0; j < DC; ++j)
-            if (!((used >> j) & 1u)) cn_addr[(size_t)(R * DC + j) * 64 + lane] = (int64_t)certain_slot * 4;
+            if (!((used >> j) & 1u)) cn_addr[(size_t)(R * DC + j) * 64 + lane] = (int64_t)certain_slot * esz;
     }
     // where a missing edge reads its 0: the always-zero row behind the c2v area (one word per lane), or the zero word of the system row
-    auto zero_addr = [&](int lane) -> int64_t { return SYS ? (int64_t)p->sys_off + 33 * 4 : (int64_t)c2v_base + (int64_t)(CR * DC * 64 + lane) * 4; };
+    auto zero_addr = [&](int lane) -> int64_t { return SYS ? (int64_t)p->sys_off + (esz == 8 ? 136 : 132) : (int64_t)c2v_base + (int64_t)(CR * DC * 64 + lane) * esz; };
     for (int v = 0; v < c->n; ++v) {
         const int Q = var_slot[v] / 64, lane = var_slot[v] % 64;
         // a real variable with fewer edges than its round gathers sums zeros for the missing ones
@@ -934,7 +1144,7 @@ int fused_plan_create(Decoder* d) {
             for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = zero_addr(lane);
         for (int pidx = c->col_ptr[v]; pidx < c->col_ptr[v + 1]; ++pidx) {
             const int k = c->col_edge[pidx], cs = chk_slot[c->edge_chk[k]];
-            vn_addr[(size_t)(vr.first_gather(Q) + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(((cs / 64) * DC + edge_pos[k]) * 64 + cs % 64) * 4;
+            vn_addr[(size_t)(vr.first_gather(Q) + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(((cs / 64) * DC + edge_pos[k]) * 64 + cs % 64) * esz;
         }
     }
     if (certain_slot >= 0) {  // the certain slot sums nothing: every gather reads the zero row
@@ -967,8 +1177,8 @@ int fused_plan_create(Decoder* d) {
                         for (int l = 0; l < 32; ++l) {
                             const int64_t a = cn_addr[(size_t)(R * DC + j) * 64 + h * 32 + l];
                             if (a < 0) continue;
-                            if (a == (int64_t)slot * 4) same = true;
-                            else if (((a / 4) & 31) == (slot & 31)) clash = true;
+                            if (a == (int64_t)slot * esz) same = true;
+                            else if (((a / esz) & 31) == (slot & 31)) clash = true;
                         }
                         cost += (clash && !same) ? 1 : 0;
                     }
@@ -977,7 +1187,7 @@ int fused_plan_create(Decoder* d) {
                 for (int j = 0; j < DC; ++j)
                     for (int l = 0; l < 32; ++l) {
                         int64_t& a = cn_addr[(size_t)(R * DC + j) * 64 + h * 32 + l];
-                        if (a < 0) a = (int64_t)best_slot * 4;
+                        if (a < 0) a = (int64_t)best_slot * esz;
                     }
             }
     }
@@ -994,17 +1204,17 @@ int fused_plan_create(Decoder* d) {
             int found = -1;
             for (int R = (wv + 1) * CRW - 1; R >= wv * CRW && found < 0; --R)
                 for (int lane = 0; lane < 64 && found < 0; ++lane)
-                    if (!((cn_active[R] >> lane) & 1ull)) found = (int)c2v_base + ((R * DC + DC - 1) * 64 + lane) * 4;
+                    if (!((cn_active[R] >> lane) & 1ull)) found = (int)c2v_base + ((R * DC + DC - 1) * 64 + lane) * esz;
             if (found < 0) return LDPC_OK;  // (plan stays !ok -> streaming backend; practically unreachable)
             p->sync_off[wv] = found;
             int mfound = -1;
             for (int s = wv * VRW * 64; s < (wv + 1) * VRW * 64 && mfound < 0; ++s)
-                if (var_of_slot[s] < 0) mfound = s * 4;
+                if (var_of_slot[s] < 0) mfound = s * esz;
             if (mfound < 0) return LDPC_OK;
             p->msync_off[wv] = mfound;
         }
     }
-    p->lds_bytes = (size_t)(NPAD + (CR * DC + p->zero_row) * 64) * 4;
+    p->lds_bytes = (size_t)(NPAD + (CR * DC + p->zero_row) * 64) * esz;
     if (p->lds_bytes > (BIG ? (size_t)160 * 1024 : (size_t)65535)) return LDPC_OK;  // 16-bit byte offsets (dword indices for the 16-wave shape)
     LDPC_HIP_TRY(hipSetDevice(c->device));
     LDPC_TRY(upload_vec(cn_tab, &p->d_cn_tab));
@@ -1027,7 +1237,7 @@ int fused_plan_create(Decoder* d) {
     if (const char* wenv = std::getenv("LDPC_FUSED_WAVES")) cap = atoi(wenv) > 0 ? atoi(wenv) : cap;  // experiment knob
     p->groups_per_cu = by_lds < cap ? by_lds : cap;
     LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
-    LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel_sim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    if (shape.kernel_sim) LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel_sim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
     p->ok = p->groups_per_cu >= 1;
     return LDPC_OK;
 }
@@ -1099,7 +1309,7 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
         return LDPC_E_ARG;
     }
     FusedArgs a{};
-    a.priors = (const float*)priors;
+    a.priors = priors;
     a.y0 = y0;
     a.xhat = xhat;
     a.iters = iters;
@@ -1109,6 +1319,7 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
 // channel -> LLR -> decode -> count in ONE kernel (BI-AWGN, all-`codeword` word): priors never touch HBM.
 bool fused_simulate_supported(const Decoder* d, int channel, double param, int hist_bins) {
     if (!fused_supported(d) || hist_bins < 1 || hist_bins > 64) return false;
+    if (!kShapes[d->fused->shape].kernel_sim) return false;  // decode-only shape (fp64 min-sum): channel / decode / count kernels
     if (d->alg == ALG_BEC) return channel == CH_BEC;
     return channel == CH_BIAWGN || (channel == CH_BSC && param > 0.0 && param < 0.5);  // BSC: needs llr > 0
 }

@@ -375,3 +375,32 @@ def test_fused_multiwave_kernels_are_deterministic(code_name, alg):
     for _ in range(6):
         x1, i1 = h.decode_device(pri, y, 40)
         assert torch.equal(x1, x0) and torch.equal(i1, i0)
+
+
+def test_fp64_min_sum_on_the_lds_kernel():
+    # the fp64 LDS kernel (the reference's own arithmetic) against the fp64 C oracle: ragged batches, BSC iteration-0 exits,
+    # max_iter cuts, no-early-exit flag; and it is the kernel "auto" picks for regular codes in fp64
+    import torch
+    from ldpc_decoders_amd import bpa, bsc
+
+    for name in ("1200_3_6_rand_ldpc_1", "512_3_6_rand_ldpc_2"):
+        g, code = _code(name)
+        rng = np.random.RandomState(17)
+        for B, mi in ((1, 50), (67, 50), (400, 7)):
+            y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(2.1)), (B, g.n))
+            pri = O.biawgn_priors(y, 2.1)
+            dec = bpa.MSA(code, max_iter=mi, precision="f64")
+            xhat, iters = dec.decode_batch(None, pri)
+            assert dec.handle.last_stats()[0] == "fused" and dec.handle.fused_info()["lds_bytes_per_frame"] > 40000
+            xo, io = C.bp_decode(g, "MSA", None, pri, mi, dtype=np.float64)
+            assert (xhat == xo).all() and (iters == io).all()
+    g, code = _code("1200_3_6_rand_ldpc_1")
+    yb = (np.random.RandomState(3).random_sample((200, g.n)) < 0.035).astype(np.int64)
+    yb[:4] = 0
+    dec = bsc.MSA(0.035, code, max_iter=30, precision="f64")
+    xhat, iters = dec.decode_batch(yb)
+    xo, io = C.bp_decode(g, "MSA", yb.astype(np.float64), O.bsc_priors(yb, 0.035), 30, dtype=np.float64)
+    assert dec.dec.handle.last_stats()[0] == "fused" and (xhat == xo).all() and (iters == io).all() and (iters[:4] == 0).all()
+    h = bpa.MSA(code, max_iter=3, precision="f64", backend="fused").handle
+    x3, i3 = h.decode_device(torch.from_numpy(O.bsc_priors(yb, 0.035)).cuda(), None, 3, flags=1)
+    assert (i3.cpu().numpy() == 3).all()

@@ -22,7 +22,7 @@ from bench import load_code
 t0 = time.time()
 code = load_code(%(code)r)[1] if %(code)r.startswith("gen:") else codes.get_code(%(code)r)  # gen:reg:<n>:<l>:<r> / gen:irg:<n> as in bench.py
 try:
-    h = DecoderHandle(code, "MSA", "f32", "fused")
+    h = DecoderHandle(code, "MSA", os.environ.get("LDPC_PLAN_PRECISION", "f32"), "fused")
 except Exception as e:  # no fused shape for this (code, LDPC_FUSED_NW): nothing to plan
     print(%(code)r, "nw", os.environ.get("LDPC_FUSED_NW", "auto"), "skipped:", e, flush=True)
     sys.exit(0)
@@ -36,13 +36,15 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "plans"))
     ap.add_argument("--codes", nargs="*", default=CODES)
     ap.add_argument("--codes-dir", default=os.path.join(ROOT, "tests", "golden", "codes"))
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="f64: the shapes of the fp64 min-sum kernel")
+    ap.add_argument("--nw", nargs="*", default=["", "1"], help="LDPC_FUSED_NW values to plan for ('' = the default shape)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     procs = []
     for code in a.codes:
-        for nw in ("", "1"):  # the default shape and the one-wave-per-frame shape (LDPC_FUSED_NW=1)
+        for nw in a.nw:  # by default: the default shape and the one-wave-per-frame shape (LDPC_FUSED_NW=1)
             env = dict(os.environ, LDPC_FUSED_PLAN_MOVES=str(a.moves), LDPC_FUSED_PLAN_SAVE=a.out, LDPC_FUSED_LAYOUT="replan",
-                       FILE_CODES_DIR=a.codes_dir)
+                       FILE_CODES_DIR=a.codes_dir, LDPC_PLAN_PRECISION=a.precision)
             if nw:
                 env["LDPC_FUSED_NW"] = nw
             procs.append(subprocess.Popen([sys.executable, "-c", CHILD % dict(root=ROOT, code=code)], env=env))
