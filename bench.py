@@ -5,7 +5,9 @@ A "step" is one pass of the hot path over one batch of synthetic input, entirely
     BI-AWGN channel + LLR kernel (Philox noise, all-zero word) -> flooding min-sum decode (syndrome early exit as in the
     reference) -> bit/word error counters.
 Workload = BASELINE.json configs[1]: code 1200_3_6_rand_ldpc_1 (the reference's own H, tests/golden fixture), batch
-65 536 frames per GPU, fp32 messages.  Default operating point 1.0 dB: every frame fails there, so every frame
+65 536 frames per GPU.  Message arithmetic: fp64 by default -- the reference's own, hard decisions and iteration counts
+bit-identical to it (LDS-resident fp64 min-sum kernel) --; `--precision f32` is the throughput mode, reported beside it under
+"fp32_mode".  Default operating point 1.0 dB: every frame fails there, so every frame
 executes exactly 50 sweeps -- the honest "50-iteration" number (no early-exit benefit).  `--snr` selects others;
 `--points` adds 2.0/3.0 dB lines to the same JSON under "points".
 
@@ -51,28 +53,29 @@ def load_code(name):
     return g, Code.from_edges(g.m, g.n, g.chk, g.var)
 
 
-def cpu_baseline(g, snr, max_iter, budget_s=12.0):
+def cpu_baseline(g, snr, max_iter, precision="f64", budget_s=12.0):
     """The CPU oracle (oracle/bp_oracle.c, a plain-C port of the reference algorithm, OpenMP over frames) timed on this
     host on a bounded sample of the same workload."""
     import bp_oracle as O
     import c_oracle as C
 
     cores = os.cpu_count() or 1
+    dt_np = np.float64 if precision == "f64" else np.float32
     rng = np.random.RandomState(2024)
     var = O.biawgn_noise_var(snr)
 
     def sample(nf):
         y = -1 + rng.normal(0, np.sqrt(var), (nf, g.n))
-        return O.biawgn_priors(y, snr).astype(np.float32)
+        return O.biawgn_priors(y, snr).astype(dt_np)
 
     pri = sample(64 * cores)
     t0 = time.time()
-    C.bp_decode(g, "MSA", None, pri, max_iter, dtype=np.float32, nthreads=cores)
+    C.bp_decode(g, "MSA", None, pri, max_iter, dtype=dt_np, nthreads=cores)
     rate = len(pri) / max(time.time() - t0, 1e-6)
     nf = int(max(64 * cores, min(rate * budget_s, 400000)))
     pri = sample(nf)
     t0 = time.time()
-    _, it = C.bp_decode(g, "MSA", None, pri, max_iter, dtype=np.float32, nthreads=cores)
+    _, it = C.bp_decode(g, "MSA", None, pri, max_iter, dtype=dt_np, nthreads=cores)
     dt = time.time() - t0
     ref = {}
     try:
@@ -85,8 +88,9 @@ def cpu_baseline(g, snr, max_iter, budget_s=12.0):
     except Exception:
         pass
     out = {"value": round(nf / dt, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": "%d frames, same H / SNR %.1f dB / max_iter %d, fp32 C port of the reference algorithm (oracle/bp_oracle.c), "
-                     "%d OpenMP threads, %.1f s, mean %.1f sweeps/frame" % (nf, snr, max_iter, cores, dt, float(it.mean()))}
+           "sample": "%d frames, same H / SNR %.1f dB / max_iter %d, %s C port of the reference algorithm (oracle/bp_oracle.c), "
+                     "%d OpenMP threads, %.1f s, mean %.1f sweeps/frame" % (nf, snr, max_iter, "fp64" if precision == "f64" else "fp32", cores, dt,
+                                                                             float(it.mean()))}
     out.update(ref)
     return out
 
@@ -121,7 +125,8 @@ def main():
     ap.add_argument("--snr", type=float, default=1.0)
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--code", default="1200_3_6_rand_ldpc_1")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--precision", default="f64", choices=["f32", "f64"],
+                    help="message arithmetic; f64 is the reference's own (hard decisions bit-identical to it), f32 the throughput mode")
     ap.add_argument("--backend", default="auto", choices=["auto", "stream", "fused"])
     ap.add_argument("--points", type=float, nargs="*", default=[2.0, 3.0], help="extra SNR points reported under 'points'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,6 +188,15 @@ def main():
                    "note": "priors [B,n] %s resident in HBM before the timed region; decode (ldpc_decode) + error counting (ldpc_count_errors)" % args.precision}
         del pri, xh, it
 
+    # the fp32 throughput mode of the same workload (statistically identical curves, not bit-identical frame by frame), N = 1
+    f32_res = None
+    if args.precision == "f64" and comm.world == 1 and not args.no_profile:
+        h3 = DecoderHandle(code, "MSA", "f32", args.backend)
+        sim3 = DeviceSimulator(h3, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=args.max_iter + 1)
+        f32_res = run_point(sim3, h3, comm, args.snr, args.steps, 1, args.batch, 0, torch)
+        f32_res["backend"] = h3.last_stats()[0]
+        del sim3, h3
+
     def summarise(snr, r, steps):
         c = r["counters"]
         frames, iter_sum = int(c[0]), int(c[3])
@@ -209,7 +223,9 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fp:
                 tj = json.load(fp)
-            key = {"stream_check_pass": "stream:k_cn", "stream_variable_pass": "stream:k_vn", "fused_decode": "sim:k_fused_bp"}[kind]
+            # keys of profiles/hbm_traffic.json: "<pass>:<precision>:<kernel>" (tools/summarize_profile.py)
+            key = {"stream_check_pass": "stream:%s:k_cn" % args.precision, "stream_variable_pass": "stream:%s:k_vn" % args.precision,
+                   "fused_decode": "sim:%s:%s" % (args.precision, "k_fused_msa64" if args.precision == "f64" else "k_fused_bp")}[kind]
             for k, v in tj.items():
                 if k.startswith(key) and args.batch == 65536 and args.code == "1200_3_6_rand_ldpc_1" and abs(args.snr - 1.0) < 1e-9:
                     traffic = int(v)
@@ -233,7 +249,8 @@ def main():
             # row (2 cycles each; the 16-wave shape pairs its message rows at 3 cycles per row) -- all known from the plan.
             fi = handle.fused_info()
             nw, cr, vr_ = int(fi["waves_per_frame"]), int(fi["check_rounds"]), int(fi["variable_rounds"])
-            store_cycles = (cr * 6 * (3 if nw > 4 else 2)) + vr_ * 2
+            row_cycles = 6 if args.precision == "f64" else 2  # ds_write_b64 rows vs ds_write_addtid_b32 rows
+            store_cycles = (cr * 6 * (3 if nw > 4 else row_cycles)) + vr_ * row_cycles
             lds_cycles = fi["lds_gather_cycles_min"] + fi["conflict_cycles_planned"] + store_cycles
             frame_sweeps_per_s = iter_sum_rank0_share / (ms * 1e-3)
             cus, clk = torch.cuda.get_device_properties(0).multi_processor_count, 2.4e9
@@ -259,6 +276,8 @@ def main():
             "algorithmic_GBps": head["algorithmic_GBps"], "bytes_per_frame_sweep": bytes_per_frame_iter,
             "roofline": roof,
             "decode_from_hbm": hbm_leg,
+            "fp32_mode": None if f32_res is None else dict(summarise(args.snr, f32_res, args.steps), backend=f32_res["backend"],
+                                                           note="same workload with fp32 message arithmetic (bench.py --precision f32)"),
             "points": [summarise(snr, r, max(2, args.steps // 2)) for snr, r in extra],
         }
         if stream_res is not None:
@@ -277,7 +296,7 @@ def main():
                 "note": "same workload with --backend stream (messages resident in HBM): the HBM-bound path used for codes that do "
                         "not fit the LDS; PMC traffic per launch in profiles/hbm_traffic.json equals the algorithmic bytes"}
         if comm.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(g, args.snr, args.max_iter)
+            out["cpu_baseline"] = cpu_baseline(g, args.snr, args.max_iter, args.precision)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
