@@ -772,8 +772,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_msa64(const 
 #pragma unroll
     for (int i = 0; i < VNW; ++i) vn_idx[i] = A.vn_tab[(w * VNW + i) * 64 + lane];
     int vmap[VRW];
+    unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
 #pragma unroll
-    for (int q = 0; q < VRW; ++q) vmap[q] = vslot[q * 64 + lane];
+    for (int q = 0; q < VRW; ++q) {
+        vmap[q] = vslot[q * 64 + lane];
+        valid |= vmap[q] >= 0 ? (1u << q) : 0u;
+    }
+    // counting mode (A.counters != null): the Monte-Carlo counters of main.test (src/main.py:41-45) are accumulated here instead of
+    // writing decisions and iteration counts out -- per-workgroup sums in wave 0, one histogram bin per lane, flushed once
+    u64 acc_tot = 0, acc_wec = 0, acc_bec = 0, acc_it = 0;
+    unsigned hist_lane = 0;
 
     auto any_unsat = [&](bool mine) -> bool {  // contains the barrier that separates the phases
         if constexpr (NW == 1) {
@@ -878,8 +886,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_msa64(const 
                     for (int j = 0; j < DC; ++j) {
                         v[j] = mg[r & 1][j] - c2v_old[r][j];
                         a[j] = __builtin_fabs(v[j]);
-                        vx ^= (uint32_t)__double2hiint(v[j]);
-                        mx ^= (uint32_t)__double2hiint(mg[r & 1][j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j + 2 < DC; j += 3) {  // three inputs per instruction (v_bitop3_b32, truth table 0x96)
+                        vx ^= xor3((uint32_t)__double2hiint(v[j]), (uint32_t)__double2hiint(v[j + 1]), (uint32_t)__double2hiint(v[j + 2]));
+                        mx ^= xor3((uint32_t)__double2hiint(mg[r & 1][j]), (uint32_t)__double2hiint(mg[r & 1][j + 1]), (uint32_t)__double2hiint(mg[r & 1][j + 2]));
                     }
                     synd |= mx;
                     static_assert(DC == 6, "leave-one-out network written for dc = 6");
@@ -919,17 +930,48 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_msa64(const 
                     for (int j = 1; j < DV; ++j) sn += cv[q & 1][j];
                     const double m1 = prior[q] + sn;
                     if (q < VRW - 1 || own_last) my_marg[q * 64] = m1;
-                    xb |= (m1 < 0.0) ? (1u << q) : 0u;
+                    xb |= ((uint32_t)__double2hiint(m1) >> 31) << q;  // (m1 < 0): m1 is never -0.0 (sums start from +0.0) nor NaN for finite priors
                 });
                 phase_barrier();
                 ++it;
             }
         }
-        if (w == 0 && lane == 0) A.iters[fr] = it;
-        uint8_t* xf = A.xhat + fr * n;
+        if (A.counters != nullptr) {
+            const unsigned wrong = (A.codeword ? ~xb : xb) & valid;
+            int err = 0;
 #pragma unroll
-        for (int q = 0; q < VRW; ++q)
-            if (vmap[q] >= 0) xf[vmap[q]] = (uint8_t)((xb >> q) & 1u);
+            for (int q = 0; q < VRW; ++q) err += __popcll(__ballot((wrong >> q) & 1u));
+            if constexpr (NW > 1) {  // channel B of the system row (the sweep loop's last exchange used channel A)
+                if (lane == 0) *sysw(16 + w) = (uint32_t)err;
+                __syncthreads();
+                int sum = lane < NW ? (int)*sysw(16 + (lane & (NW - 1))) : 0;
+#pragma unroll
+                for (int o = NW / 2; o; o >>= 1) sum += __shfl_xor(sum, o);
+                err = sum;
+            }
+            err = __builtin_amdgcn_readfirstlane(err);
+            acc_tot += 1;
+            acc_wec += err > 0;
+            acc_bec += (u64)err;
+            acc_it += (u64)it;
+            const int bin = it < A.hist_bins ? it : A.hist_bins - 1;
+            hist_lane += (lane == bin) ? 1u : 0u;
+        } else {
+            if (w == 0 && lane == 0) A.iters[fr] = it;
+            uint8_t* xf = A.xhat + fr * n;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q)
+                if (vmap[q] >= 0) xf[vmap[q]] = (uint8_t)((xb >> q) & 1u);
+        }
+    }
+    if (A.counters != nullptr && w == 0) {
+        if (lane == 0) {
+            atomicAdd(&A.counters[0], acc_tot);
+            atomicAdd(&A.counters[1], acc_wec);
+            atomicAdd(&A.counters[2], acc_bec);
+            atomicAdd(&A.counters[3], acc_it);
+        }
+        if (lane < A.hist_bins && hist_lane) atomicAdd(&A.counters[4 + lane], (u64)hist_lane);
     }
 }
 
@@ -1319,7 +1361,8 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
 // channel -> LLR -> decode -> count in ONE kernel (BI-AWGN, all-`codeword` word): priors never touch HBM.
 bool fused_simulate_supported(const Decoder* d, int channel, double param, int hist_bins) {
     if (!fused_supported(d) || hist_bins < 1 || hist_bins > 64) return false;
-    if (!kShapes[d->fused->shape].kernel_sim) return false;  // decode-only shape (fp64 min-sum): channel / decode / count kernels
+    if (!kShapes[d->fused->shape].kernel_sim)  // fp64 min-sum: channel kernel -> decode kernel in counting mode
+        return d->alg == ALG_MSA && (channel == CH_BIAWGN || channel == CH_BSC);
     if (d->alg == ALG_BEC) return channel == CH_BEC;
     return channel == CH_BIAWGN || (channel == CH_BSC && param > 0.0 && param < 0.5);  // BSC: needs llr > 0
 }
@@ -1327,6 +1370,30 @@ bool fused_simulate_supported(const Decoder* d, int channel, double param, int h
 int fused_simulate(Decoder* d, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
                    int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st) {
     if (B <= 0) return LDPC_OK;
+    if (!kShapes[d->fused->shape].kernel_sim) {
+        // fp64 min-sum: priors (and the BSC's received word) of a chunk are generated into HBM by the channel kernel, the decode
+        // kernel then counts the errors itself (no decisions written, no counting kernel)
+        const int64_t step = (int64_t)1 << 17;
+        const size_t n = (size_t)d->code->n;
+        for (int64_t b0 = 0; b0 < B; b0 += step) {
+            const int64_t nb = (B - b0) < step ? (B - b0) : step;
+            LDPC_TRY(d->h_in.reserve((size_t)nb * n * sizeof(double)));
+            uint8_t* y = nullptr;
+            if (channel == CH_BSC) {
+                LDPC_TRY(d->h_y0.reserve((size_t)nb * n));
+                y = (uint8_t*)d->h_y0.p;
+            }
+            LDPC_TRY(channel_generate(channel, DT_F64, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, (int32_t)n, d->h_in.p, y, st));
+            FusedArgs a{};
+            a.priors = d->h_in.p;
+            a.y0 = y;
+            a.codeword = codeword;
+            a.hist_bins = hist_bins;
+            a.counters = (unsigned long long*)counters;
+            LDPC_TRY(fused_launch(d, a, false, nb, max_iter, flags, st));
+        }
+        return LDPC_OK;
+    }
     const double var = pow(10.0, -param / 10.0);  // src/biawgn.py:10 -- same host arithmetic as channel_generate()
     const double sigma = sqrt(var), k = 2.0 / var;
     FusedArgs a{};

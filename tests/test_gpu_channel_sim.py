@@ -125,3 +125,26 @@ def test_full_size_properties():
     idx = np.r_[0:64, B - 64:B]
     xo, io = C.bp_decode(g, "MSA", None, pri[idx].cpu().numpy(), 50, dtype=np.float32)
     assert (xh[idx] == xo).all() and (it[idx] == io).all()
+
+
+@pytest.mark.parametrize("channel,param", [("biawgn", 1.9), ("bsc", 0.045)])
+def test_fp64_simulate_on_the_lds_kernel_equals_streaming(channel, param):
+    # fp64 Monte-Carlo: channel kernel -> fp64 LDS kernel in counting mode  ==  channel kernel -> streaming decode -> counting kernel
+    # (identical priors, bit-identical arithmetic => identical counters and iteration histograms, any batch split)
+    import torch
+    from helpers import golden_edges
+    from ldpc_decoders_amd._device import DecoderHandle
+    from ldpc_decoders_amd.codes import Code
+
+    g = golden_edges("1200_3_6_rand_ldpc_1")
+    code = Code.from_edges(g.m, g.n, g.chk, g.var)
+    res = {}
+    for be in ("fused", "stream"):
+        h = DecoderHandle(code, "MSA", "f64", be)
+        cnt = torch.zeros(4 + 41, dtype=torch.int64, device="cuda")
+        for a, b in ((0, 1), (1, 700), (700, 3000)):
+            h.simulate(channel, param, 1, 99, 3, 5000 + a, b - a, 40, cnt, hist_bins=41)
+        assert h.last_stats()[0] == be
+        res[be] = cnt.cpu().numpy()
+    assert (res["fused"] == res["stream"]).all() and res["fused"][0] == 3000 and 0 < res["fused"][1] < 3000
+    assert res["fused"][4:].sum() == 3000
