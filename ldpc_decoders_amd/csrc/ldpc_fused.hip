@@ -745,10 +745,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
 // [0,16) verdict channel A, [32] frame hand-out).  Same tables and layout plan as the fp32 kernels with 8-byte elements;
 // gathers are ds_read_b64 (2 LDS cycles, as b32), stores ds_write_b64.  Decode only: the Monte-Carlo driver composes
 // channel kernel -> this kernel -> counting kernel.
-template <int DC, int DV, int CRW, int VRW, int NW>
+template <int DC, int DV, int CRW, int VRW, int NW, int VRX, int DVX>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_msa64(const FusedArgs A) {
     constexpr int VR = VRW * NW, NPAD = VR * 64;
-    constexpr int VNK = VRW * DV, CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
+    constexpr int VNK = VRX * DVX + (VRW - VRX) * DV;  // gathers of a wave's variable phase: VRX wide rounds (irregular codes) first
+    constexpr int VN0 = VRX * DVX, VRN = VRW - VRX;
+    constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int w = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
@@ -773,10 +775,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_msa64(const 
     for (int i = 0; i < VNW; ++i) vn_idx[i] = A.vn_tab[(w * VNW + i) * 64 + lane];
     int vmap[VRW];
     unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
+    unsigned dummy = 0;  // bit q: the "certain" slot that pads short check rows (var_of_slot == -2): prior +inf
 #pragma unroll
     for (int q = 0; q < VRW; ++q) {
         vmap[q] = vslot[q * 64 + lane];
         valid |= vmap[q] >= 0 ? (1u << q) : 0u;
+        dummy |= vmap[q] == -2 ? (1u << q) : 0u;
     }
     // counting mode (A.counters != null): the Monte-Carlo counters of main.test (src/main.py:41-45) are accumulated here instead of
     // writing decisions and iteration counts out -- per-workgroup sums in wave 0, one histogram bin per lane, flushed once
@@ -834,7 +838,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_msa64(const 
         unsigned xb = 0;
         const double* pf = priors + fr * n;
 #pragma unroll
-        for (int q = 0; q < VRW; ++q) prior[q] = vmap[q] >= 0 ? pf[vmap[q]] : 0.0;
+        for (int q = 0; q < VRW; ++q) prior[q] = vmap[q] >= 0 ? pf[vmap[q]] : (((dummy >> q) & 1u) ? __builtin_huge_val() : 0.0);
 #pragma unroll
         for (int r = 0; r < CRW; ++r)
 #pragma unroll
@@ -915,22 +919,43 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_msa64(const 
                 if (early && it > 0 && !unsat) break;
                 // ---- variable phase: ordered sum from +0.0 (scipy COO), prior last, decision bit
                 xb = 0;
+                auto finish_var = [&](auto Q_, double sn) {
+                    constexpr int q = decltype(Q_)::value;
+                    const double m1 = prior[q] + sn;
+                    if (q < VRW - 1 || own_last) my_marg[q * 64] = m1;
+                    xb |= ((uint32_t)__double2hiint(m1) >> 31) << q;  // (m1 < 0): m1 is never -0.0 (sums start from +0.0) nor NaN for finite priors
+                };
+                if constexpr (VRX > 0) {  // wide rounds: DVX gathers per variable (missing edges read the zero double)
+                    double cw[2][DVX];
+#pragma unroll
+                    for (int j = 0; j < DVX; ++j) cw[0][j] = gat(half_of<VNK>(vn_idx, j));
+                    static_for<0, VRX>([&](auto Q_) {
+                        constexpr int q = decltype(Q_)::value;
+                        if constexpr (q + 1 < VRX) {
+#pragma unroll
+                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = gat(half_of<VNK>(vn_idx, (q + 1) * DVX + j));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        double sw = 0.0 + cw[q & 1][0];
+#pragma unroll
+                        for (int j = 1; j < DVX; ++j) sw += cw[q & 1][j];
+                        finish_var(Q_, sw);
+                    });
+                }
                 double cv[2][DV];
 #pragma unroll
-                for (int j = 0; j < DV; ++j) cv[0][j] = gat(half_of<VNK>(vn_idx, j));
-                static_for<0, VRW>([&](auto Q_) {
+                for (int j = 0; j < DV; ++j) cv[0][j] = gat(half_of<VNK>(vn_idx, VN0 + j));
+                static_for<0, VRN>([&](auto Q_) {
                     constexpr int q = decltype(Q_)::value;
-                    if constexpr (q + 1 < VRW) {
+                    if constexpr (q + 1 < VRN) {
 #pragma unroll
-                        for (int j = 0; j < DV; ++j) cv[(q + 1) & 1][j] = gat(half_of<VNK>(vn_idx, (q + 1) * DV + j));
+                        for (int j = 0; j < DV; ++j) cv[(q + 1) & 1][j] = gat(half_of<VNK>(vn_idx, VN0 + (q + 1) * DV + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     double sn = 0.0 + cv[q & 1][0];
 #pragma unroll
                     for (int j = 1; j < DV; ++j) sn += cv[q & 1][j];
-                    const double m1 = prior[q] + sn;
-                    if (q < VRW - 1 || own_last) my_marg[q * 64] = m1;
-                    xb |= ((uint32_t)__double2hiint(m1) >> 31) << q;  // (m1 < 0): m1 is never -0.0 (sums start from +0.0) nor NaN for finite priors
+                    finish_var(std::integral_constant<int, VRX + q>{}, sn);
                 });
                 phase_barrier();
                 ++it;
@@ -989,9 +1014,9 @@ struct ShapeEntry {
     int esz = 4;             // bytes per LDS element: 4 (fp32 kernels), 8 (fp64 min-sum)
 };
 
-template <int DC, int DV, int CRW, int VRW, int NW>
+template <int DC, int DV, int CRW, int VRW, int NW, int VRX = 0, int DVX = DV>
 constexpr ShapeEntry shape_entry64() {
-    return ShapeEntry{ALG_MSA, DC, DV, CRW, VRW, NW, 0, DV, (const void*)k_fused_msa64<DC, DV, CRW, VRW, NW>, nullptr, 8};
+    return ShapeEntry{ALG_MSA, DC, DV, CRW, VRW, NW, VRX, DVX, (const void*)k_fused_msa64<DC, DV, CRW, VRW, NW, VRX, DVX>, nullptr, 8};
 }
 
 template <int ALG, int DC, int DV, int CRW, int VRW, int NW, int VRX = 0, int DVX = DV>
@@ -1019,6 +1044,7 @@ const ShapeEntry kShapes[] = {
     // (40 KB of LDS per frame, 4 frames per CU) measured 3 % faster than four (46 KB, 3 frames): 6.66 vs 6.87 ms per 65 536 frames
     shape_entry64<6, 3, 5, 10, 2>(),
     shape_entry64<6, 3, 3, 5, 4>(),
+    shape_entry64<6, 3, 5, 10, 2, 2, 8>(),  // irregular n <= 1215: two wide variable rounds per wave, short check rows padded
 };
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
