@@ -53,7 +53,7 @@ def test_curves_overlap_the_published_reference_results(tmp_path):
     import sys
 
     root = os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0]
-    for sel in ("1200_3_6_rand_ldpc_1", "bsc-1200_3_6_ldpc-MSA-40", "7_4_hamming-ML"):
+    for sel in ("1200_3_6_rand_ldpc_1", "bsc-1200_3_6_ldpc-MSA-40", "7_4_hamming-ML", "bsc-1200_3_6_ldpc-SPA-40"):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "compare_curves.py"), "--only", sel, "--min-wec", "600",
                             "--out", str(tmp_path / "c.md")], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
