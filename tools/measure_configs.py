@@ -16,9 +16,11 @@ from bench import load_code  # noqa: E402
 from ldpc_decoders_amd._device import DecoderHandle  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-CASES = [  # config, code, decoder alg, channel, param, batch, steps, backend
-    ("2: n=1200 (3,6) MSA BI-AWGN", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 1.0, 65536, 6, "auto"),
-    ("2: n=1200 (3,6) MSA BI-AWGN", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 2.0, 65536, 6, "auto"),
+CASES = [  # config, code, decoder alg, channel, param, batch, steps, backend[, precision]
+    ("2: n=1200 (3,6) MSA BI-AWGN, fp64 (the reference's arithmetic, bit-identical decisions)", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 1.0, 65536, 6, "auto", "f64"),
+    ("2: n=1200 (3,6) MSA BI-AWGN, fp64 (the reference's arithmetic, bit-identical decisions)", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 2.0, 65536, 6, "auto", "f64"),
+    ("2: n=1200 (3,6) MSA BI-AWGN, fp32 mode", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 1.0, 65536, 6, "auto"),
+    ("2: n=1200 (3,6) MSA BI-AWGN, fp32 mode", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 2.0, 65536, 6, "auto"),
     ("3: n=1200 (3,6) SPA BSC", "1200_3_6_rand_ldpc_1", "SPA", "bsc", 0.07, 65536, 6, "auto"),
     ("3: n=1200 (3,6) SPA BSC", "1200_3_6_rand_ldpc_1", "SPA", "bsc", 0.05, 65536, 6, "auto"),
     ("3: n=1200 (3,6) erasure decoder BEC", "1200_3_6_rand_ldpc_1", "BEC", "bec", 0.40, 65536, 6, "auto"),
@@ -31,11 +33,13 @@ CASES = [  # config, code, decoder alg, channel, param, batch, steps, backend
 ]
 rows = []
 cache = {}
-for cfg, code_name, alg, ch, prm, B, steps, backend in CASES:
+for case in CASES:
+    cfg, code_name, alg, ch, prm, B, steps, backend = case[:8]
+    prec = case[8] if len(case) > 8 else "f32"
     if code_name not in cache:
         cache[code_name] = load_code(code_name)
     g, code = cache[code_name]
-    h = DecoderHandle(code, alg, "f32", backend)
+    h = DecoderHandle(code, alg, prec, backend)
     cnt = torch.zeros(4 + 51, dtype=torch.int64, device="cuda")
     h.simulate(ch, prm, 0, 0x5EED1200, 0, 0, B, 50, cnt, hist_bins=51)  # warm-up at full size: workspaces are allocated here
     torch.cuda.synchronize()
@@ -47,8 +51,8 @@ for cfg, code_name, alg, ch, prm, B, steps, backend in CASES:
     dt = time.perf_counter() - t0
     c = cnt.cpu().numpy()
     frames, sweeps = int(c[0]), int(c[3])
-    bytes_fs = 4 * (4 * g.E + g.n) if alg != "BEC" else (4 * g.E + g.n)
-    rows.append(dict(config=cfg, code=code_name, n=g.n, E=g.E, decoder=alg, channel=ch, param=prm, max_iter=50, frames_per_step=B, steps=steps,
+    bytes_fs = (8 if prec == "f64" else 4) * (4 * g.E + g.n) if alg != "BEC" else (4 * g.E + g.n)
+    rows.append(dict(config=cfg, code=code_name, n=g.n, E=g.E, decoder=alg, precision=prec, channel=ch, param=prm, max_iter=50, frames_per_step=B, steps=steps,
                      backend=h.last_stats()[0], waves_per_frame=h.fused_info()["waves_per_frame"] if h.last_stats()[0] == "fused" else 0,
                      frames_per_s=round(frames / dt, 1), ms_per_step=round(1e3 * dt / steps, 3), mean_sweeps=round(sweeps / frames, 3),
                      wer=round(int(c[1]) / frames, 6), ber=int(c[2]) / (frames * g.n),
@@ -57,4 +61,4 @@ for cfg, code_name, alg, ch, prm, B, steps, backend in CASES:
     del h
 with open(os.path.join(ROOT, "profiles", "%s_all_configs.json" % tag), "w") as fp:
     json.dump(dict(device=torch.cuda.get_device_name(0), note="tools/measure_configs.py: whole hot path (device channel + decode + count), "
-                   "fp32 message arithmetic, max_iter 50; algorithmic_GBps = executed sweeps x s(4E+n) / time (SURVEY 8(d))", rows=rows), fp, indent=1)
+                   "max_iter 50; algorithmic_GBps = executed sweeps x s(4E+n) / time (SURVEY 8(d))", rows=rows), fp, indent=1)
