@@ -762,7 +762,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_msa64(const 
     const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
     const bool own_last = !(NW > 1 && w == NW - 1);
     auto sysw = [&](int i) { return reinterpret_cast<volatile uint32_t*>(smem + A.sys_off) + i; };
-    auto gat = [&](uint32_t byte_off) { return *reinterpret_cast<const double*>(smem + byte_off); };
+    // table entries: 16-bit byte offsets, or -- frames beyond 64 KB of LDS (WIDE) -- 16-bit indices of 8-byte elements
+    constexpr bool WIDE = (size_t)(VR * 64 + CRW * NW * DC * 64) * 8 > 65536;
+    auto gat = [&](uint32_t entry) { return *reinterpret_cast<const double*>(smem + (WIDE ? (entry << 3) : entry)); };
     if (threadIdx.x == 0) {  // the always-zero double (system-row bytes 136..143) that missing edges gather
         *sysw(34) = 0u;
         *sysw(35) = 0u;
@@ -1045,6 +1047,7 @@ const ShapeEntry kShapes[] = {
     shape_entry64<6, 3, 5, 10, 2>(),
     shape_entry64<6, 3, 3, 5, 4>(),
     shape_entry64<6, 3, 5, 10, 2, 2, 8>(),  // irregular n <= 1215: two wide variable rounds per wave, short check rows padded
+    shape_entry64<6, 3, 3, 6, 8>(),         // (3,6)-regular n <= 3008 (Margulis n = 2640): 96 KB per frame, one frame = 8 waves per CU
 };
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
@@ -1182,6 +1185,10 @@ int fused_plan_create(Decoder* d) {
         w = (k & 1) ? ((w & 0x0000ffffu) | (val << 16)) : ((w & 0xffff0000u) | val);
     };
     const uint32_t c2v_base = (uint32_t)NPAD * esz;
+    // gather tables hold 16 bits per entry: byte offsets while the frame fits 64 KB, element indices beyond (fp32: the 16-wave shape;
+    // fp64: exactly the kernel's own WIDE rule)
+    const size_t frame_bytes = (size_t)(NPAD + CR * DC * 64) * esz;
+    const int tab_shift = esz == 8 ? (frame_bytes > 65536 ? 3 : 0) : (BIG ? 2 : 0);
     std::vector<int64_t> cn_addr((size_t)CR * DC * 64, -1), vn_addr((size_t)vr.total_gathers() * 64, -1);  // byte offsets, -1 = padded lane
     for (int v = 0; v < c->n; ++v) var_of_slot[var_slot[v]] = v;
     // short check rows are padded with reads of one "certain" variable slot (marked -2): +-inf marginal, see the kernel
@@ -1262,9 +1269,9 @@ int fused_plan_create(Decoder* d) {
     fill_padding(cn_addr, 0);
     fill_padding(vn_addr, c2v_base);
     for (int K = 0; K < CR * DC; ++K)
-        for (int lane = 0; lane < 64; ++lane) put16(cn_tab, CNW, CRW * DC, K, lane, (uint32_t)(cn_addr[(size_t)K * 64 + lane] >> (BIG ? 2 : 0)));
+        for (int lane = 0; lane < 64; ++lane) put16(cn_tab, CNW, CRW * DC, K, lane, (uint32_t)(cn_addr[(size_t)K * 64 + lane] >> tab_shift));
     for (int K = 0; K < vr.total_gathers(); ++K)
-        for (int lane = 0; lane < 64; ++lane) put16(vn_tab, VNW, VNK, K, lane, (uint32_t)(vn_addr[(size_t)K * 64 + lane] >> (BIG ? 2 : 0)));
+        for (int lane = 0; lane < 64; ++lane) put16(vn_tab, VNW, VNK, K, lane, (uint32_t)(vn_addr[(size_t)K * 64 + lane] >> tab_shift));
     if (NW > 1 && !SYS) {
         // hand-off words: for each wave the c2v slot (position dc-1) of one of its padded check lanes, in its LAST round
         // that has one (so the wave's own garbage write to it precedes the verdict write in program order)
@@ -1283,7 +1290,7 @@ int fused_plan_create(Decoder* d) {
         }
     }
     p->lds_bytes = (size_t)(NPAD + (CR * DC + p->zero_row) * 64) * esz;
-    if (p->lds_bytes > (BIG ? (size_t)160 * 1024 : (size_t)65535)) return LDPC_OK;  // 16-bit byte offsets (dword indices for the 16-wave shape)
+    if (p->lds_bytes > ((BIG || tab_shift) ? (size_t)160 * 1024 : (size_t)65535)) return LDPC_OK;  // 16-bit byte offsets / element indices
     LDPC_HIP_TRY(hipSetDevice(c->device));
     LDPC_TRY(upload_vec(cn_tab, &p->d_cn_tab));
     LDPC_TRY(upload_vec(vn_tab, &p->d_vn_tab));

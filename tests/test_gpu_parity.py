@@ -383,7 +383,7 @@ def test_fp64_min_sum_on_the_lds_kernel():
     import torch
     from ldpc_decoders_amd import bpa, bsc
 
-    for name in ("1200_3_6_rand_ldpc_1", "512_3_6_rand_ldpc_2", "1200_rho_x5_rand_ldpc_5"):  # regular, small, irregular (wide rounds)
+    for name in ("1200_3_6_rand_ldpc_1", "512_3_6_rand_ldpc_2", "1200_rho_x5_rand_ldpc_5", "margulis"):  # regular, small, irregular, 96 KB frame
         g, code = _code(name)
         rng = np.random.RandomState(17)
         for B, mi in ((1, 50), (67, 50), (400, 7)):
