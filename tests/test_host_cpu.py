@@ -172,3 +172,23 @@ def test_product_fails_loudly_without_the_hip_library_or_a_gpu(tmp_path):
 
         with pytest.raises(_lib.LdpcHipError):
             bpa.MSA(codes.get_code("7_4_hamming"), max_iter=5)
+
+
+def test_committed_bench_line_keeps_the_contract():
+    # the last bench line committed under profiles/ carries every field of the bench contract (+ roofline and cpu_baseline)
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
+    assert files
+    with open(files[-1]) as fp:
+        d = json.load(fp)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["dtype"] == "f64" and d["value"] > 1e7  # the reference's arithmetic, >= 1e7 frames/s at 50 sweeps on one MI355X
