@@ -404,3 +404,21 @@ def test_fp64_min_sum_on_the_lds_kernel():
     h = bpa.MSA(code, max_iter=3, precision="f64", backend="fused").handle
     x3, i3 = h.decode_device(torch.from_numpy(O.bsc_priors(yb, 0.035)).cuda(), None, 3, flags=1)
     assert (i3.cpu().numpy() == 3).all()
+
+
+@pytest.mark.parametrize("code_name", ["1200_3_6_rand_ldpc_1", "1200_rho_x5_rand_ldpc_5", "margulis"])
+def test_fp64_lds_kernel_is_deterministic(code_name):
+    # repeated decodes of one resident batch on the multi-wave fp64 kernels (2 and 8 waves per frame): identical outputs
+    import torch
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    g, code = _code(code_name)
+    h = DecoderHandle(code, "MSA", "f64", "fused")
+    assert h.fused_info()["waves_per_frame"] >= 2
+    pri, _ = h.channel_device("biawgn", 1.9, 0, 5, 0, 0, 5000)
+    x0, i0 = h.decode_device(pri, None, 40)
+    x0, i0 = x0.clone(), i0.clone()
+    assert len(torch.unique(i0)) > 3
+    for _ in range(5):
+        x1, i1 = h.decode_device(pri, None, 40)
+        assert torch.equal(x1, x0) and torch.equal(i1, i0)
