@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < c.E; ++k) c.col_edge[fill[c.edge_var[k]]++] = k;
     const int CR = atoi(argv[2]), VR = atoi(argv[3]);
     VarRounds vr; vr.VR = VR; vr.DV = 3; vr.vrx = atoi(argv[4]); vr.dvx = vr.vrx ? 8 : 3;
+    if (argc > 8) { vr.nw = atoi(argv[8]); vr.reserved = atoi(argv[9]); }  // per-wave wide rounds / reserved system row
     FusedLayout L; plan_fused_layout(c, 6, CR, vr, 0x1200, 1200000, &L);
     {   // plan store: round trip, and a damaged file is refused
         const uint64_t key = layout_key(c, 6, CR, vr, 1);
@@ -40,7 +41,7 @@ int main(int argc, char** argv) {
         FusedLayout D = L; std::swap(D.var_slot[0], D.var_slot[1]); D.var_slot[2] = D.var_slot[3];  // duplicate slot
         if (layout_valid(c, 6, CR, vr, D) || !layout_save(path, key, c, D) || layout_load(path, key, c, 6, CR, vr, &M)) return 9;
     }
-    if (argc > 6) {  // a shipped plan for this code / shape: must load and beat the short run
+    if (argc > 6 && argv[6][0]) {  // a shipped plan for this code / shape: must load and beat the short run
         char name[64]; snprintf(name, sizeof(name), "/%016llx.plan", (unsigned long long)layout_key(c, 6, CR, vr, atoi(argv[7])));
         FusedLayout S;
         if (!layout_load(std::string(argv[6]) + name, layout_key(c, 6, CR, vr, atoi(argv[7])), c, 6, CR, vr, &S)) return 10;
@@ -48,7 +49,7 @@ int main(int argc, char** argv) {
         printf("stored %.0f\n", S.extra_cycles_planned);
     }
     for (int v = 0; v < c.n; ++v)  // placement constraint: more than 3 edges only in the wide rounds
-        if (c.col_ptr[v + 1] - c.col_ptr[v] > 3 && L.var_slot[v] / 64 >= vr.vrx) return 5;
+        if (c.col_ptr[v + 1] - c.col_ptr[v] > vr.width(L.var_slot[v] / 64) || !vr.usable(L.var_slot[v] / 64)) return 5;
     // the plan must be a permutation of slots and of the positions inside every check
     std::vector<int> seen(CR * 64, 0); for (int s : L.chk_slot) { if (s < 0 || s >= CR * 64 || seen[s]++) return 2; }
     std::vector<int> seenv(VR * 64, 0); for (int s : L.var_slot) { if (s < 0 || s >= VR * 64 || seenv[s]++) return 3; }
@@ -92,3 +93,32 @@ def test_layout_planner_under_asan(tmp_path, code_name, cr, vr, vrx, nw):
     stored = float(lines[0].split()[1])  # conflict cycles of the shipped plan (ldpc_decoders_amd/plans), recomputed on load
     base, ident, planned = (float(v) for v in lines[1].split())
     assert base == 2.0 * (cr * 6 + vrx * 8 + (vr - vrx) * 3) and planned < 0.6 * ident and stored < planned
+
+
+@pytest.mark.timeout(900)
+def test_layout_planner_under_asan_16_wave_shape(tmp_path):
+    # the one-frame-per-CU shape: 80 check rounds, 160 variable rounds over 16 waves (3 wide rounds each), last row reserved,
+    # on a generated rate-1/2 irregular n = 10 000 code
+    import numpy as np
+
+    from ldpc_decoders_amd import codes
+
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler")
+    code = codes.rand_irregular_ldpc(10000, codes.LAMBDA_RHO_X5_HALF_RATE, 6, np.random.RandomState(4))
+    code_file = codes.save_parity_mtx(code, "irg10000", str(tmp_path))
+    src = tmp_path / "harness.cpp"
+    src.write_text(HARNESS.replace("plan_fused_layout(c, 6, CR, vr, 0x1200, 1200000, &L)", "plan_fused_layout(c, 6, CR, vr, 0x1200, 300000, &L)"))
+    exe = str(tmp_path / "harness")
+    cmd = ["/opt/rocm/bin/hipcc", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", CSRC, "-x", "hip",
+           "--offload-arch=gfx950", "--cuda-host-only", str(src), os.path.join(CSRC, "ldpc_layout.hip"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        if "error:" in r.stderr and "ldpc_" in r.stderr:
+            pytest.fail("planner harness does not compile: " + r.stderr[-1500:])
+        pytest.skip("sanitized host build unavailable here: " + r.stderr[-300:])
+    out = subprocess.run([exe, code_file, "80", "160", "3", str(tmp_path), "", "16", "16", "1"], capture_output=True, text=True,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"), timeout=800)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-2000:]
+    base, ident, planned = (float(v) for v in out.stdout.strip().splitlines()[-1].split())
+    assert base == 2.0 * (80 * 6 + 16 * (3 * 8 + 7 * 3)) and planned < ident
