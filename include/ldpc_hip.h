@@ -80,9 +80,10 @@ int ldpc_decoder_profile_read(ldpc_decoder_t dec, double* ms3, int64_t* launches
  *   iters_dev   [B]  int32 out: sweeps executed by each frame (0 = left at the iteration-0 check, x_hat = y0) */
 int ldpc_decode(ldpc_decoder_t dec, const void* priors_dev, const uint8_t* y0_dev, int64_t B, int32_t max_iter,
                 uint32_t flags, uint8_t* xhat_dev, int32_t* iters_dev, void* stream);
-/* Same on the streaming backend, additionally returning the soft output: marginals_dev [B,n] (`dtype`) = the
- * marginal LLRs (prior + sum of check messages, src/bpa.py:35) of each frame's LAST executed sweep (0 where a frame
- * never swept).  LLR decoders only; B <= 2^17. */
+/* Same (on whichever backend the decoder uses: streaming or fused), additionally returning the soft output:
+ * marginals_dev [B,n] (`dtype`) = the marginal LLRs (prior + sum of check messages, src/bpa.py:35 -- a local of the
+ * reference's loop, captured upstream only through its sum_cols hook) of each frame's LAST executed sweep (0 where a
+ * frame never swept).  LLR decoders only; B <= 2^17. */
 int ldpc_decode_soft(ldpc_decoder_t dec, const void* priors_dev, const uint8_t* y0_dev, int64_t B, int32_t max_iter,
                      uint32_t flags, uint8_t* xhat_dev, int32_t* iters_dev, void* marginals_dev, void* stream);
 /* Same with host buffers (numpy ndpointer style, as exact.proj_csr); copies in, decodes, copies out, synchronises. */

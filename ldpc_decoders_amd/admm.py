@@ -33,7 +33,8 @@ class ADMM:
         self.last_iters = None
 
     def stats(self):  # src/admm.py:38-40
-        avg = self.iter @ np.arange(len(self.iter)) / self.iter.sum()
+        total = self.iter.sum()
+        avg = self.iter @ np.arange(len(self.iter)) / total if total else 0.0  # (an intermediate progress line of a device run)
         return {"average": avg, "iter": self.iter.tolist()}
 
     def _count(self, iters):

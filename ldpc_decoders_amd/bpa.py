@@ -48,7 +48,7 @@ class BPA:
     def decode(self, y, priors):
         y = np.asarray(y)
         y0, host_ok = self._iter0_word(y)
-        if host_ok is not None and host_ok[0] and not (0 < self.max_iter <= 0):
+        if host_ok is not None and host_ok[0]:  # passes the iteration-0 test of src/bpa.py:28-29 for every max_iter (0 included)
             self.last_iters = np.zeros(1, dtype=np.int32)
             return y
         xhat, iters = self.handle.decode_host(np.asarray(priors), y0, self.max_iter)

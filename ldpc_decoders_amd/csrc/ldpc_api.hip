@@ -281,7 +281,7 @@ int ldpc_decode(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t
         const int64_t nb = (B - b0) < step ? (B - b0) : step;
         const void* p = priors ? (const char*)priors + (size_t)b0 * d->code->n * esz : nullptr;
         const uint8_t* y = y0 ? y0 + (size_t)b0 * d->code->n : nullptr;
-        int rc = bk == BK_FUSED ? fused_decode(d, p, y, nb, max_iter, flags, xhat + (size_t)b0 * d->code->n, iters + b0, st)
+        int rc = bk == BK_FUSED ? fused_decode(d, p, y, nb, max_iter, flags, xhat + (size_t)b0 * d->code->n, iters + b0, nullptr, st)
                                 : stream_decode(d, p, y, nb, max_iter, flags, xhat + (size_t)b0 * d->code->n, iters + b0, nullptr, st);
         if (rc) return rc;
         sweeps = d->last_sweeps > sweeps ? d->last_sweeps : sweeps;
@@ -298,6 +298,9 @@ int ldpc_decode_soft(ldpc_decoder_t h, const void* priors, const uint8_t* y0, in
         return LDPC_E_ARG;
     }
     LDPC_HIP_TRY(hipSetDevice(d->code->device));
+    const int bk = pick_backend(d);
+    if (bk < 0) return bk;
+    if (bk == BK_FUSED) return fused_decode(d, priors, y0, B, max_iter, flags, xhat, iters, marginals, (hipStream_t)stream);
     return stream_decode(d, priors, y0, B, max_iter, flags, xhat, iters, marginals, (hipStream_t)stream);
 }
 

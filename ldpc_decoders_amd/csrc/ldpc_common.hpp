@@ -117,7 +117,7 @@ int fused_simulate(Decoder* d, int channel, double param, int codeword, uint64_t
                    int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st);
 int fused_info(const Decoder* d, double* out8);
 int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
-                 uint8_t* xhat, int32_t* iters, hipStream_t st);
+                 uint8_t* xhat, int32_t* iters, void* soft_out, hipStream_t st);
 
 // ---- channel / counting kernels -------------------------------------------------------------------
 int channel_generate(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id,

@@ -127,6 +127,7 @@ struct FusedArgs {
     const u64* cn_active;
     uint8_t* xhat;
     int32_t* iters;
+    void* soft;                     // optional [B,n] (float / double as the kernel): marginals of each frame's last executed sweep (src/bpa.py:35), 0 if none
     u64* next_frame;
     int zero_row;
     int sync_off[4];                 // 1 < NW <= 4: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
@@ -722,6 +723,18 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : (NW == 4 ? 
                 const int v = vmap_of(q);
                 if (v >= 0) xf[v] = ((xe >> q) & 1u) ? (uint8_t)2 : (uint8_t)((xb >> q) & 1u);
             }
+            if constexpr (ALG != ALG_BEC) {
+                // soft output: the marginal rows this wave wrote in its last variable phase are still in the LDS (the check phase
+                // that found the syndrome satisfied, or the sweep cap, does not touch them)
+                if (A.soft != nullptr) {
+                    float* sf = reinterpret_cast<float*>(A.soft) + fr * n;
+#pragma unroll
+                    for (int q = 0; q < VRW; ++q) {
+                        const int v = vmap_of(q);
+                        if (v >= 0) sf[v] = it > 0 ? lds_marg[q * 64 + lane] : 0.0f;
+                    }
+                }
+            }
         }
     }
     if constexpr (SIM) {
@@ -989,6 +1002,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_msa64(const 
 #pragma unroll
             for (int q = 0; q < VRW; ++q)
                 if (vmap[q] >= 0) xf[vmap[q]] = (uint8_t)((xb >> q) & 1u);
+            if (A.soft != nullptr) {  // marginals of the last executed sweep: still in this wave's LDS rows
+                double* sf = reinterpret_cast<double*>(A.soft) + fr * n;
+#pragma unroll
+                for (int q = 0; q < VRW; ++q)
+                    if (vmap[q] >= 0) sf[vmap[q]] = it > 0 ? my_marg[q * 64] : 0.0;
+            }
         }
     }
     if (A.counters != nullptr && w == 0) {
@@ -1372,7 +1391,7 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
 }
 
 int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
-                 uint8_t* xhat, int32_t* iters, hipStream_t st) {
+                 uint8_t* xhat, int32_t* iters, void* soft_out, hipStream_t st) {
     FusedPlan* p = d->fused;
     if (!p || !p->ok) {
         set_error("fused backend not available for this decoder");
@@ -1388,12 +1407,13 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
     a.y0 = y0;
     a.xhat = xhat;
     a.iters = iters;
+    a.soft = soft_out;
     return fused_launch(d, a, false, B, max_iter, flags, st);
 }
 
 // channel -> LLR -> decode -> count in ONE kernel (BI-AWGN, all-`codeword` word): priors never touch HBM.
 bool fused_simulate_supported(const Decoder* d, int channel, double param, int hist_bins) {
-    if (!fused_supported(d) || hist_bins < 1 || hist_bins > 64) return false;
+    if (!fused_supported(d) || hist_bins < 0 || hist_bins > 64) return false;  // 0 bins: counters only (what main.py asks for)
     if (!kShapes[d->fused->shape].kernel_sim)  // fp64 min-sum: channel kernel -> decode kernel in counting mode
         return d->alg == ALG_MSA && (channel == CH_BIAWGN || channel == CH_BSC);
     if (d->alg == ALG_BEC) return channel == CH_BEC;

@@ -10,8 +10,11 @@ import numpy as np
 
 
 class Comm:
-    def __init__(self, rank=0, world=1, local_rank=0, backend=None):
+    def __init__(self, rank=0, world=1, local_rank=0, backend=None, group=None):
         self.rank, self.world, self.local_rank, self.backend = rank, world, local_rank, backend
+        # collectives run whenever a process group exists -- normally world > 1; LDPC_DIST_FORCE_GROUP=1 creates one for a
+        # single rank too (exercises RCCL itself on a 1-GPU box)
+        self.group = (world > 1) if group is None else bool(group)
 
     @property
     def is_root(self):
@@ -24,9 +27,12 @@ class Comm:
         start = frame0 + self.rank * base + min(self.rank, rem)
         return start, cnt
 
-    def all_reduce_sum(self, counters):
-        """Sum an int64 vector over ranks.  Accepts numpy (staged through a tensor) or a torch tensor (in place)."""
-        if self.world == 1:
+    def all_reduce_sum(self, counters, async_on_stream=False):
+        """Sum an int64 vector over ranks.  Accepts numpy (staged through a tensor) or a torch tensor (in place).
+
+        ``async_on_stream`` (device tensors, RCCL): the collective is only ENQUEUED -- it runs on the communicator's stream behind the
+        work already queued on the current stream, and the current stream is made to wait for it; the host does not block."""
+        if not self.group:
             return counters
         import torch
         import torch.distributed as td
@@ -41,17 +47,20 @@ class Comm:
             td.all_reduce(t, op=td.ReduceOp.SUM)
             counters.copy_(t)
             return counters
+        if async_on_stream and counters.is_cuda:
+            td.all_reduce(counters, op=td.ReduceOp.SUM, async_op=True).wait()  # wait() == stream dependency, not a host sync
+            return counters
         td.all_reduce(counters, op=td.ReduceOp.SUM)
         return counters
 
     def barrier(self):
-        if self.world > 1:
+        if self.group:
             import torch.distributed as td
 
             td.barrier()
 
     def max_float(self, x):
-        if self.world == 1:
+        if not self.group:
             return float(x)
         import torch
         import torch.distributed as td
@@ -73,7 +82,8 @@ def init_from_env(prefer_gpu=True):
     use_gpu = prefer_gpu and torch.cuda.is_available()
     if use_gpu:
         torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-    if world > 1:
+    force = os.environ.get("LDPC_DIST_FORCE_GROUP") == "1"
+    if world > 1 or force:
         import torch.distributed as td
 
         # "nccl" is RCCL on ROCm; LDPC_DIST_BACKEND=gloo lets several ranks share one GPU (tests of the N>1 path on a 1-GPU box)
@@ -82,7 +92,7 @@ def init_from_env(prefer_gpu=True):
         os.environ.setdefault("MASTER_PORT", "29533")
         if not td.is_initialized():
             td.init_process_group(backend=backend, rank=rank, world_size=world)
-    return Comm(rank, world, local, backend)
+    return Comm(rank, world, local, backend, group=(world > 1 or force))
 
 
 def finalize():

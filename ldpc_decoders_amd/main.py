@@ -85,8 +85,17 @@ def test(args, comm=None):
             handle = decoder.handle if hasattr(decoder, "handle") else decoder.dec.handle
             if args.codeword not in (0, 1):
                 raise SystemExit("the device channel sends the all-zero or all-one word; use --exact for other --codeword values")
-            sim = DeviceSimulator(handle, args.channel, args.max_iter, args.codeword, args.seed, comm)
+            # a decoder that reports statistics (ADMM: iteration histogram, src/main.py:34) gets them from the REDUCED counters, so
+            # that `dec` describes the same frames as tot/wec/bec -- the whole job, not rank 0's shard
+            own_hist = hasattr(decoder, "stats") and hasattr(inner, "iter")
+            bins = min(len(inner.iter), args.max_iter + 1 if args.max_iter > 0 else len(inner.iter)) if own_hist else 0
+            if own_hist:
+                handle.on_iters = None
+            sim = DeviceSimulator(handle, args.channel, args.max_iter, args.codeword, args.seed, comm, hist_bins=bins)
             c = sim.run_point(param, stream_id=pi, min_wec=args.min_wec, batch_per_rank=args.batch, on_progress=progress)
+            if own_hist:
+                inner.iter[:] = 0
+                inner.iter[:bins] = c["hist"]
         results[param] = log_status(c, final=True)
     log.info("Done!")
     return results

@@ -16,7 +16,12 @@ from .dist import Comm
 
 def run_point_exact(channel, decoder, x, min_wec, chunk=64, on_progress=None, pick_word=None):
     """Sequential-rule Monte-Carlo with host noise.  ``channel.send`` / ``decoder.decode_batch`` as in the registry.
-    Returns dict(tot, wec, bec, iter_sum)."""
+    Returns dict(tot, wec, bec, iter_sum).
+
+    The reference draws exactly one frame of noise per trip of its loop (src/main.py:37-40), so when it stops, the global
+    ``np.random`` stream stands right behind the LAST COUNTED frame -- and the next ``--params`` value continues from there.
+    Frames are decoded ``chunk`` at a time here; a chunk that reaches ``min_wec`` before its end is therefore rewound: the
+    stream state saved before the chunk is restored and exactly the counted frames are drawn again."""
     n = len(x)
     tot = wec = bec = itsum = 0
     while wec < min_wec:
@@ -26,23 +31,37 @@ def run_point_exact(channel, decoder, x, min_wec, chunk=64, on_progress=None, pi
         else:
             chunk_now = chunk
         X = np.broadcast_to(x, (chunk_now, n))
+        state = np.random.get_state() if chunk_now > 1 else None
         Y = channel.send(X)
         xhat, iters = decoder.decode_batch(Y)
         err = (np.asarray(xhat) != X).sum(axis=1)
+        used = 0
         for e, it in zip(err, iters):
+            used += 1
             tot += 1
             wec += int(e > 0)
             bec += int(e)
             itsum += int(it)
             if wec >= min_wec:
                 break
+        if used < chunk_now:  # stopped inside the chunk: leave the stream where the reference leaves it
+            np.random.set_state(state)
+            channel.send(np.broadcast_to(x, (used, n)))
         if on_progress:
             on_progress(tot, wec, bec)
     return dict(tot=tot, wec=wec, bec=bec, iter_sum=itsum)
 
 
 class DeviceSimulator:
-    """Rounds of ``batch`` frames per rank, all on the GPU (channel kernel -> decode -> count)."""
+    """Rounds of ``batch`` frames per rank, all on the GPU (channel kernel -> decode -> count).
+
+    Rounds are PIPELINED: ``launch_round`` only enqueues work (zero the round's counters, the simulate kernels, the all-reduce
+    over ranks, a copy of the reduced counters into page-locked host memory, an event) and returns at once; ``finish_round`` waits
+    for that round's event alone.  With two rounds in flight the GPU never idles behind the host, the collective of round k
+    overlaps the decode of round k+1, and no host synchronisation sits between kernels.  ``run_round`` = launch + finish (the
+    synchronous form)."""
+
+    DEPTH = 2  # rounds in flight in run_point / bench.py
 
     def __init__(self, handle, channel, max_iter, codeword=0, seed=0x5EED1200, comm=None, hist_bins=0):
         import torch
@@ -50,27 +69,59 @@ class DeviceSimulator:
         self.torch = torch
         self.h, self.channel, self.max_iter, self.codeword = handle, channel, int(max_iter), int(codeword)
         self.seed, self.comm, self.hist_bins = int(seed), comm or Comm(), int(hist_bins)
-        self.counters = torch.zeros(4 + self.hist_bins, dtype=torch.int64, device="cuda")
+        k = 4 + self.hist_bins
+        self._slots = [dict(dev=torch.zeros(k, dtype=torch.int64, device="cuda"), host=torch.zeros(k, dtype=torch.int64).pin_memory(),
+                            done=torch.cuda.Event(), busy=False) for _ in range(self.DEPTH + 1)]
+        self._next = 0
+
+    def launch_round(self, param, stream_id, frame0, frames_total, flags=0):
+        """Enqueue the decode of global frames [frame0, frame0+frames_total), split over ranks; returns a ticket for finish_round."""
+        slot = self._slots[self._next]
+        if slot["busy"]:
+            raise RuntimeError("more than %d rounds in flight" % len(self._slots))
+        self._next = (self._next + 1) % len(self._slots)
+        start, cnt = self.comm.shard(frame0, frames_total)
+        slot["dev"].zero_()
+        if cnt > 0:
+            self.h.simulate(self.channel, param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
+                            flags=flags, hist_bins=self.hist_bins)
+        self.comm.all_reduce_sum(slot["dev"], async_on_stream=True)
+        slot["host"].copy_(slot["dev"], non_blocking=True)
+        slot["done"].record()
+        slot["busy"] = True
+        return slot
+
+    def finish_round(self, slot):
+        """Wait for one launched round; returns its whole-job counters (numpy int64)."""
+        slot["done"].synchronize()
+        slot["busy"] = False
+        return slot["host"].numpy().copy()
 
     def run_round(self, param, stream_id, frame0, frames_total, flags=0):
         """Decode global frames [frame0, frame0+frames_total) split over ranks; returns the reduced counters (numpy)."""
-        start, cnt = self.comm.shard(frame0, frames_total)
-        self.counters.zero_()
-        if cnt > 0:
-            self.h.simulate(self.channel, param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, self.counters,
-                            flags=flags, hist_bins=self.hist_bins)
-        red = self.comm.all_reduce_sum(self.counters)
-        return red.cpu().numpy()
+        return self.finish_round(self.launch_round(param, stream_id, frame0, frames_total, flags))
 
     def run_point(self, param, stream_id, min_wec, batch_per_rank, on_progress=None, max_frames=None):
+        """Rounds until ``wec >= min_wec``.  The stopping rule is evaluated when a round's counters arrive, by which time the next
+        round is already running: that round is drained and DISCARDED, so the counters are exactly those of the synchronous
+        loop (a function of the round size only, not of the pipeline depth or the number of ranks)."""
         tot = np.zeros(4 + self.hist_bins, dtype=np.int64)
         frame0 = 0
         per_round = int(batch_per_rank) * self.comm.world
-        while tot[_lib.CNT_WEC] < min_wec and (max_frames is None or tot[_lib.CNT_TOT] < max_frames):
-            tot += self.run_round(param, stream_id, frame0, per_round)
-            frame0 += per_round
-            if on_progress:
-                on_progress(int(tot[0]), int(tot[1]), int(tot[2]))
+        inflight = []
+
+        def more():
+            return tot[_lib.CNT_WEC] < min_wec and (max_frames is None or tot[_lib.CNT_TOT] < max_frames)
+
+        while more() or inflight:
+            while more() and len(inflight) < self.DEPTH:
+                inflight.append(self.launch_round(param, stream_id, frame0, per_round))
+                frame0 += per_round
+            got = self.finish_round(inflight.pop(0))
+            if more():
+                tot += got
+                if on_progress:
+                    on_progress(int(tot[0]), int(tot[1]), int(tot[2]))
         out = dict(tot=int(tot[0]), wec=int(tot[1]), bec=int(tot[2]), iter_sum=int(tot[3]))
         if self.hist_bins:
             out["hist"] = tot[4:].tolist()

@@ -5,12 +5,12 @@
 
 prints one ``main.py`` argument line per run (same grammar and the same parameter grids as upstream
 ``simulations.py:27-85``: cases HMG, MAR, REG_BAD, REG_ENS, IREG_ENS), so ``run_sims.sh`` can feed them to
-``python -m ldpc_decoders_amd.main``.  Lines for decoders outside the GPU belief-propagation path (ML, LP, ADMM) are
-skipped unless ``--all-decoders`` is given (then the output is identical to upstream's, line for line).
+``python -m ldpc_decoders_amd.main``.  Only the lines of the decoders that are not built here (LP, ADMMA) are skipped -- ML and
+ADMM run on the GPU like SPA / MSA; with ``--all-decoders`` the output is identical to upstream's, line for line.
 """
 import argparse
 
-BP = ("SPA", "MSA")
+BUILT = ("SPA", "MSA", "ML", "ADMM")  # everything upstream's tables name except LP (and ADMMA, which they never name)
 ERASURE_GRID = ".5 .475 .45 .425 .4 .375 .35 .34 .33 .325 .32 .31 .3"
 
 
@@ -67,14 +67,14 @@ CASES = {"HMG": case_HMG, "MAR": case_MAR, "REG_BAD": case_REG_BAD,
 def lines(case, extra=(), all_decoders=False):
     out = []
     for run in CASES[case]():
-        if all_decoders or run[2] in BP:
+        if all_decoders or run[2] in BUILT:
             out.append(" ".join(list(run) + list(extra)))
     return out
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--all-decoders", action="store_true", help="also print the ML/LP/ADMM lines (not runnable on the GPU path)")
+    ap.add_argument("--all-decoders", action="store_true", help="also print the LP lines (that decoder is not built: those runs stop with an error)")
     ap.add_argument("case", nargs="+", choices=sorted(CASES), help="specify case(s)")
     ap.add_argument("arg", nargs=argparse.REMAINDER, help="arguments passed to wrapped command")
     a = ap.parse_args(argv)

@@ -3,8 +3,9 @@
 The argument grammar (positional ``channel code decoder`` + ``--codeword --min-wec --params --max-iter ...``) and
 the result files (``<channel>-<code>-<decoder>-<codeword>-<min_wec>-<max_iter>.json`` with the id keys first, then
 ``tot wec wer bec ber`` as ``{str(param): value}``) are what ``simulations.py`` / ``run_sims.sh`` emit and what
-``graph.py`` reads upstream (src/graph.py:25-58), so they are kept verbatim.  Flags that only concern decoders
-outside the BP path (``--mu --eps --allow-pseudo --layers --train --apprx``) are accepted and ignored.
+``graph.py`` reads upstream (src/graph.py:25-58), so flag names, defaults and the file layout are kept; the help texts are
+this build's own.  ``--mu --eps --allow-pseudo`` configure the ADMM decoder; ``--layers --train --apprx`` belong to ADMMA, which
+is not built -- they are accepted so that upstream arg-lines parse, and ignored.
 """
 import argparse
 import json
@@ -23,46 +24,52 @@ def default_data_root():
     return os.environ.get("LDPC_DATA_ROOT", os.path.join(os.path.expanduser("~"), "decoders"))
 
 
+def _reference_flags(p, channel_names, code_names, decoder_names):
+    """The reference's flag grammar (names, types, defaults, choices: src/utils.py:21-45) -- the contract simulations.py's arg-lines
+    rely on.  Help texts are this build's own."""
+    p.add_argument("channel", choices=list(channel_names), help="which channel model to simulate")
+    p.add_argument("code", choices=list(code_names),
+                   help="name of the code: a built-in, or a parity-check text file found in $%s (falls back to data/codes)" % codes.file_codes_dir_string)
+    p.add_argument("decoder", choices=list(decoder_names), help="which decoder to run on the GPU")
+    p.add_argument("--codeword", type=int, default=0, choices=[-1, 0, 1],
+                   help="what is sent: 0 = the all-zero word, 1 = the all-one word, -1 = a fresh random codeword per frame (short codes; host noise)")
+    p.add_argument("--min-wec", type=int, default=100, help="stop a point once this many frames were decoded wrongly")
+    p.add_argument("--params", type=float, nargs="+", default=[.1, .01],
+                   help="one run per value: SNR in dB (biawgn), crossover probability (bsc) or erasure probability (bec)")
+    p.add_argument("--max-iter", type=int, default=10, help="sweep cap of the iterative decoders (<= 0: no cap)")
+    p.add_argument("--mu", type=float, default=3., help="ADMM penalty parameter")
+    p.add_argument("--eps", type=float, default=1e-5, help="ADMM stopping tolerance")
+    p.add_argument("--allow-pseudo", action="store_true", help="ADMM: keep fractional (pseudo-codeword) outputs instead of rounding them")
+    # decoders that are not built here (ADMMA): accepted so that upstream arg-lines parse, otherwise unused
+    p.add_argument("--layers", type=int, nargs="+", default=[100, 100], help=argparse.SUPPRESS)
+    p.add_argument("--train", action="store_true", help=argparse.SUPPRESS)
+    p.add_argument("--apprx", type=int, default=-1, help=argparse.SUPPRESS)
+    p.add_argument("--log-freq", type=float, default=5., help="seconds between progress lines / intermediate result writes")
+
+
 def setup_parser(code_names, channel_names, decoder_names):
     p = argparse.ArgumentParser()
-    p.add_argument("channel", help="channel type", choices=list(channel_names))
-    p.add_argument("code", help="code name; built-ins plus the files in $%s (default data/codes)" % codes.file_codes_dir_string,
-                   choices=list(code_names))
-    p.add_argument("decoder", help="decoder type", choices=list(decoder_names))
-    p.add_argument("--codeword", help="transmitted codeword [0:all-zero, 1:all-ones, -1:random from code book (small codes, host noise)]",
-                   default=0, type=int, choices=[-1, 0, 1])
-    p.add_argument("--min-wec", help="min word errors to accumulate", default=100, type=int)
-    p.add_argument("--params", help="channel condition, e.g. erasure probability for erasure channel", nargs="+", type=float,
-                   default=[.1, .01])
-    p.add_argument("--max-iter", help="max iteration count for iterative decoders", default=10, type=int)
-    # accepted for arg-line compatibility with simulations.py; unused by SPA/MSA
-    p.add_argument("--mu", default=3., type=float, help=argparse.SUPPRESS)
-    p.add_argument("--eps", default=1e-5, type=float, help=argparse.SUPPRESS)
-    p.add_argument("--allow-pseudo", action="store_true", help=argparse.SUPPRESS)
-    p.add_argument("--layers", nargs="+", default=[100, 100], type=int, help=argparse.SUPPRESS)
-    p.add_argument("--train", action="store_true", help=argparse.SUPPRESS)
-    p.add_argument("--apprx", default=-1, type=int, help=argparse.SUPPRESS)
-    p.add_argument("--log-freq", help="log frequency in seconds", default=5., type=float)
-    # GPU build additions
-    p.add_argument("--precision", choices=["f32", "f64"], default=None,
+    _reference_flags(p, channel_names, code_names, decoder_names)
+    g = p.add_argument_group("GPU build")
+    g.add_argument("--precision", choices=["f32", "f64"], default=None,
                    help="message arithmetic (default: f32 with device noise; f64 with --exact and for min-sum over the BSC, which is tie-dominated)")
-    p.add_argument("--backend", choices=["auto", "stream", "fused"], default="auto", help="kernel family")
-    p.add_argument("--batch", type=int, default=65536, help="frames per round and per GPU (device-noise mode)")
-    p.add_argument("--seed", type=int, default=0x5EED1200, help="Philox seed of the device noise")
-    p.add_argument("--exact", action="store_true",
+    g.add_argument("--backend", choices=["auto", "stream", "fused"], default="auto", help="kernel family")
+    g.add_argument("--batch", type=int, default=65536, help="frames per round and per GPU (device-noise mode)")
+    g.add_argument("--seed", type=int, default=0x5EED1200, help="Philox seed of the device noise")
+    g.add_argument("--exact", action="store_true",
                    help="reference-exact mode: host numpy noise (np.random global stream), fp64 messages, sequential stopping rule")
-    p.add_argument("--np-seed", type=int, default=None, help="np.random.seed() for --exact runs (upstream runs unseeded)")
+    g.add_argument("--np-seed", type=int, default=None, help="np.random.seed() for --exact runs (upstream runs unseeded)")
     return bind_parser_common(p)
 
 
 def bind_parser_common(parser):
-    _dir = default_data_root()
-    path_ = lambda p_: os.path.abspath(os.path.join(_dir, p_))  # noqa: E731
-    parser.add_argument("--data_dir", help="location for writing simulation output", default=path_("data"))
-    parser.add_argument("--cache_dir", help="unused (ADMMA cache upstream)", default=path_("cache"))
-    parser.add_argument("--plots_dir", help="save location of plots", default=path_("plots"))
-    parser.add_argument("--debug", help="logs debug info", action="store_true")
-    parser.add_argument("--console", help="if true prints log onto console, otherwise write to a file", action="store_true")
+    root = default_data_root()
+    for flag, sub, text in (("--data_dir", "data", "directory the JSON result files go to"),
+                            ("--cache_dir", "cache", "accepted for upstream compatibility (ADMMA cache), unused"),
+                            ("--plots_dir", "plots", "directory for figures")):
+        parser.add_argument(flag, default=os.path.abspath(os.path.join(root, sub)), help=text)
+    parser.add_argument("--debug", action="store_true", help="log at DEBUG level")
+    parser.add_argument("--console", action="store_true", help="log to the terminal instead of <data_dir>/test.log")
     return parser
 
 

@@ -11,17 +11,25 @@ from helpers import GOLDEN, main_counter_cases
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("run", [r for r in main_counter_cases() if " SPA " not in r["argline"] or r["argline"].startswith("bec")],
-                         ids=lambda r: r["argline"].replace(" ", "_")[:60])
-def test_exact_mode_reproduces_reference_counters(run, tmp_path, monkeypatch):
-    # reference: `np.random.seed(s); python src/main.py <argline>` (tests/golden/main_counters.json)
+def _is_llr_spa(run):
+    return " SPA " in run["argline"] and not run["argline"].startswith("bec")
+
+
+def _run_exact(run, tmp_path, monkeypatch):
     from ldpc_decoders_amd import codes, main
 
     monkeypatch.setenv(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
     argv = run["argline"].split() + ["--data_dir", str(tmp_path), "--console", "--exact", "--np-seed", str(run["seed"])]
     main.main(argv)
     with open(os.path.join(str(tmp_path), run["file_name"])) as fp:
-        got = json.load(fp)
+        return json.load(fp)
+
+
+@pytest.mark.parametrize("run", [r for r in main_counter_cases() if not _is_llr_spa(r)], ids=lambda r: r["argline"].replace(" ", "_")[:60])
+def test_exact_mode_reproduces_reference_counters(run, tmp_path, monkeypatch):
+    # reference: `np.random.seed(s); python src/main.py <argline>` (tests/golden/main_counters.json); min-sum, the erasure
+    # decoder and every multi-parameter line (one np.random stream runs through all --params values)
+    got = _run_exact(run, tmp_path, monkeypatch)
     want = run["result"]
     assert list(got) == list(want)
     for key in ("tot", "wec", "bec"):
@@ -29,6 +37,63 @@ def test_exact_mode_reproduces_reference_counters(run, tmp_path, monkeypatch):
     for key in ("wer", "ber"):
         for prm in want[key]:
             assert got[key][prm] == pytest.approx(want[key][prm], rel=1e-12)
+
+
+SPA_RUNS = [r for r in main_counter_cases() if _is_llr_spa(r)]
+
+
+@pytest.mark.parametrize("run", SPA_RUNS, ids=lambda r: ("config1_" if "7_4_hamming" in r["argline"] else "") + r["argline"].replace(" ", "_")[:60])
+def test_exact_mode_sum_product_lines_through_hip(run, tmp_path, monkeypatch, capsys):
+    # The LLR sum-product arg-lines of tests/golden/main_counters.json -- BASELINE config 1's own anchor
+    # `biawgn 7_4_hamming SPA --codeword 1 --min-wec 50 --max-iter 10 --params 2 4` -> 412/50/118 and 2025/50/133,
+    # `biawgn 1200_3_6_rand_ldpc_1 SPA 1.5 dB` -> 20/5/331, `bsc 1200_3_6_rand_ldpc_1 SPA .07` -> 29/5/305 -- through
+    # `ldpc_decoders_amd.main --exact` on the HIP path (fp64 sum-product, the reference formula verbatim, src/bpa.py:66-75).
+    # Bar: tot, wec and bec EQUAL the reference's.  Device libm (tanh/log/exp/atanh) differs from numpy's by ulps, which could move
+    # bits of a frame that does not converge upstream either; so the frames are also re-decoded one by one against the numpy
+    # oracle on the same np.random stream, and the report says WHICH frames differ (none, measured) before the counters are compared.
+    import bp_oracle as O
+    from helpers import golden_edges
+    from ldpc_decoders_amd import codes
+    from ldpc_decoders_amd.models import models
+
+    got = _run_exact(run, tmp_path, monkeypatch)
+    want = run["result"]
+    assert list(got) == list(want)
+    a = run["argline"].split()
+    channel, code_name = a[0], a[1]
+    opt = {a[i]: a[i + 1] for i in range(3, len(a) - 1) if a[i].startswith("--") and a[i] != "--params"}
+    cw, max_iter = int(opt["--codeword"]), int(opt["--max-iter"])
+    g = golden_edges(code_name)
+    code = codes.get_code(code_name)
+    np.random.seed(run["seed"])
+    report = []
+    for prm in want["tot"]:
+        tot = want["tot"][prm]
+        x = np.full(g.n, cw, dtype=np.int64)
+        send = {"biawgn": O.biawgn_send, "bsc": O.bsc_send}[channel]
+        Y = np.stack([send(x, float(prm)) for _ in range(tot)])  # the reference's frames of this point, in its order
+        Xo, Io = O.channel_decode(g, channel, "SPA", float(prm), Y, max_iter)
+        dec = getattr(models[channel], "SPA")(float(prm), code, max_iter=max_iter, precision="f64")
+        Xd, Id = dec.decode_batch(Y)
+        Xd = np.asarray(Xd).astype(np.int64)
+        differ = np.flatnonzero((Xd != Xo).any(axis=1))
+        err_o, err_d = (Xo != x).sum(axis=1), (Xd != x).sum(axis=1)
+        report.append("%s param %s: %d frames, device == oracle on %d (%.2f %%); differing frames %s, oracle iterations there %s; "
+                      "counters device %d/%d/%d reference %d/%d/%d" % (run["argline"][:40], prm, tot, tot - len(differ), 100.0 * (tot - len(differ)) / tot,
+                                                                         differ.tolist(), Io[differ].tolist(), got["tot"][prm], got["wec"][prm],
+                                                                         got["bec"][prm], tot, want["wec"][prm], want["bec"][prm]))
+        # the numpy oracle reproduces the reference's counters on these frames (pins the comparison itself)
+        assert (int((err_o > 0).sum()), int(err_o.sum())) == (want["wec"][prm], want["bec"][prm])
+        # a frame may differ only where upstream does not converge (it is a word error on both sides)
+        assert (Io[differ] >= max_iter).all() and (err_o[differ] > 0).all() and (err_d[differ] > 0).all()
+        assert len(differ) <= max(1, tot // 10)
+    with capsys.disabled():
+        print("\n" + "\n".join(report))
+    # measured on MI355X (ROCm 7.2 device libm): every frame of every line identical to the numpy oracle, all counters equal
+    for key in ("tot", "wec", "bec"):
+        assert got[key] == want[key]
+    if "7_4_hamming" in run["argline"]:  # BASELINE config 1, by name
+        assert got["tot"] == {"2.0": 412, "4.0": 2025} and got["wec"] == {"2.0": 50, "4.0": 50} and got["bec"] == {"2.0": 118, "4.0": 133}
 
 
 def test_device_mode_schema_and_rates(tmp_path, monkeypatch):

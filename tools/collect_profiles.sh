@@ -16,7 +16,7 @@ for P in f64 f32; do
       rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${BK}_${P}_$C -o p -- python3 $R/tools/prof_fused.py --reps 1 --precision $P --backend $B > $OUT/pmc_${BK}_${P}_$C.log 2>&1
     done
   done
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_fused_${P}_SQ -o p -- python3 $R/tools/prof_fused.py --reps 1 --precision $P > $OUT/pmc_fused_${P}_SQ.log 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_fused_${P}_SQ -o p -- python3 $R/tools/prof_fused.py --reps 1 --precision $P --info $OUT/pmc_fused_${P}_SQ.info.json > $OUT/pmc_fused_${P}_SQ.log 2>&1
   rocprofv3 --pmc SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM --kernel-trace --output-format csv -d $OUT/pmc_fused_${P}_SQ2 -o p -- python3 $R/tools/prof_fused.py --reps 1 --precision $P > $OUT/pmc_fused_${P}_SQ2.log 2>&1
   # the kernels of the bench step itself (fp32: the fused SIMULATE kernel; fp64: channel + decode + count kernels)
   for C in FETCH_SIZE WRITE_SIZE; do

@@ -6,7 +6,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 import torch
 from bench import load_code
 from ldpc_decoders_amd._device import DecoderHandle
-g, code = load_code("1200_3_6_rand_ldpc_1")
+code = load_code("1200_3_6_rand_ldpc_1")
+g = code
 h = DecoderHandle(code, sys.argv[1] if len(sys.argv) > 1 else "MSA", "f32", "auto")
 B = 65536
 pri, _ = h.channel_device("biawgn", 1.0, 0, 1, 0, 0, B)

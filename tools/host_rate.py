@@ -6,7 +6,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 import numpy as np
 from bench import load_code
 from ldpc_decoders_amd import bpa
-g, code = load_code("1200_3_6_rand_ldpc_1")
+code = load_code("1200_3_6_rand_ldpc_1")
+g = code
 for snr in (1.0, 3.0):
     rng = np.random.RandomState(1)
     B = 65536

@@ -38,7 +38,8 @@ for case in CASES:
     prec = case[8] if len(case) > 8 else "f32"
     if code_name not in cache:
         cache[code_name] = load_code(code_name)
-    g, code = cache[code_name]
+    code = cache[code_name]
+    g = code
     h = DecoderHandle(code, alg, prec, backend)
     cnt = torch.zeros(4 + 51, dtype=torch.int64, device="cuda")
     h.simulate(ch, prm, 0, 0x5EED1200, 0, 0, B, 50, cnt, hist_bins=51)  # warm-up at full size: workspaces are allocated here

@@ -20,7 +20,7 @@ from ldpc_decoders_amd import codes
 from ldpc_decoders_amd._device import DecoderHandle
 from bench import load_code
 t0 = time.time()
-code = load_code(%(code)r)[1] if %(code)r.startswith("gen:") else codes.get_code(%(code)r)  # gen:reg:<n>:<l>:<r> / gen:irg:<n> as in bench.py
+code = load_code(%(code)r) if %(code)r.startswith("gen:") else codes.get_code(%(code)r)  # gen:reg:<n>:<l>:<r> / gen:irg:<n> as in bench.py
 try:
     h = DecoderHandle(code, "MSA", os.environ.get("LDPC_PLAN_PRECISION", "f32"), "fused")
 except Exception as e:  # no fused shape for this (code, LDPC_FUSED_NW): nothing to plan

@@ -32,7 +32,17 @@ def pmc(dirname):
     return acc
 
 
-traffic = {}
+def kernel_durations(dirname):
+    """Kernel name -> list of dispatch durations (ns) from the kernel trace of a pass."""
+    f = glob.glob(os.path.join(src, dirname, "*kernel_trace.csv"))
+    acc = collections.defaultdict(list)
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            acc[short(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return acc
+
+
+traffic, lds = {}, {}
 for prec in ("f64", "f32"):
     for bk in ("fused", "stream"):
         f = glob.glob(os.path.join(src, "stats_%s_%s" % (bk, prec), "*kernel_stats.csv"))
@@ -90,6 +100,31 @@ for prec in ("f64", "f32"):
                     k, d, prec, len(next(iter(v.values())))))
                 for c, vals in sorted(v.items()):
                     out.append("- %s = %.4g" % (c, sum(vals)))
+                info_path = os.path.join(src, d + ".info.json")
+                if "SQ_LDS_IDX_ACTIVE" in v and os.path.exists(info_path):
+                    # LDS roofline inputs of bench.py: LDS-array cycles per frame-sweep, and the clock the profiled launches ran at
+                    info = json.load(open(info_path))
+                    nl = len(v["SQ_LDS_IDX_ACTIVE"])
+                    fs = info["frame_sweeps_per_launch"] * nl
+                    dur = kernel_durations(d).get(k, [])
+                    dur_s = sum(dur) * 1e-9
+                    cus = info.get("cus", 256)
+                    clk = None
+                    if dur_s > 0 and "GRBM_GUI_ACTIVE" in v:
+                        clk = sum(v["GRBM_GUI_ACTIVE"]) / dur_s
+                    elif dur_s > 0 and "SQ_BUSY_CYCLES" in v:
+                        clk = sum(v["SQ_BUSY_CYCLES"]) / 32 / dur_s  # summed over the 32 shader engines
+                    entry = {"kernel": k, "launches": nl, "frame_sweeps": fs, "workload": "%s %s %.1f dB batch %d" % (info["code"], info["alg"], info["snr"], info["batch"]),
+                             "lds_idx_active_per_frame_sweep": round(sum(v["SQ_LDS_IDX_ACTIVE"]) / fs, 2),
+                             "bank_conflict_per_frame_sweep": round(sum(v.get("SQ_LDS_BANK_CONFLICT", [0])) / fs, 2),
+                             "insts_lds_per_frame_sweep": round(sum(v.get("SQ_INSTS_LDS", [0])) / fs, 2),
+                             "insts_valu_per_frame_sweep": round(sum(v.get("SQ_INSTS_VALU", [0])) / fs, 2),
+                             "kernel_ms_per_launch_in_pmc_pass": round(1e3 * dur_s / max(nl, 1), 4) if dur_s else None,
+                             "effective_clock_hz": round(clk, 0) if clk else None,
+                             "effective_clock_from": "GRBM_GUI_ACTIVE / kernel time" if (dur_s > 0 and "GRBM_GUI_ACTIVE" in v) else "SQ_BUSY_CYCLES / 32 SEs / kernel time",
+                             "lds_pipe_busy_in_pmc_pass": round(sum(v["SQ_LDS_IDX_ACTIVE"]) / (dur_s * clk * cus), 4) if (dur_s and clk) else None}
+                    lds["%s:%s" % (prec, k)] = entry
+                    out.append("\nLDS roofline inputs: `%s`" % json.dumps(entry))
 
 for name in ("bench.json", "bench_f32.json"):
     p = os.path.join(src, name)
@@ -97,8 +132,13 @@ for name in ("bench.json", "bench_f32.json"):
         shutil.copyfile(p, os.path.join(dst, "%s_%s" % (tag, name)))
         d = json.load(open(p))
         keep = ("value", "unit", "dtype", "ms_per_step", "mean_sweeps", "roofline", "decode_from_hbm", "fp32_mode", "points", "roofline_streaming_backend",
-                "cpu_baseline")
+                "cpu_baseline", "kernel_ms_per_step", "host_overhead_ms_per_step")
         out.append("\n## %s\n\n```json\n%s\n```" % (name, json.dumps({k: d[k] for k in keep if k in d}, indent=1)))
 json.dump(traffic, open(os.path.join(dst, "%s_hbm_traffic.json" % tag), "w"), indent=1)
+if lds:
+    json.dump(lds, open(os.path.join(dst, "%s_lds_cycles.json" % tag), "w"), indent=1)
+    json.dump(lds, open(os.path.join(dst, "lds_cycles.json"), "w"), indent=1)  # the copy bench.py reads
+if traffic:
+    json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(out) + "\n")
 print("\n".join(out)[:6000])
