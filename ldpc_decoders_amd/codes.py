@@ -208,6 +208,27 @@ def rand_reg_ldpc(n, l, r, rng=None):
     return code
 
 
+def irregular_degree_counts(n, lambda_edge, dc):
+    """Variables per degree of the irregular ensemble -> ({degree: count}, extra degrees).
+
+    ``floor(L_i n)`` variables of degree i with L_i ~ lambda_i / i (node perspective, ``get_node_dist`` / ``gen_L_R`` of
+    src/ldpc.py:138-143,158-159 -- pinned to the reference's counts by tests/golden/irregular_ensembles.json), then the few
+    variables still missing.  Upstream hard-codes those (``extra``, src/ldpc.py:154,167 -- which is why it asserts out for
+    n != 1200); here they are solved for: the smallest combination of ensemble degrees that makes the socket count a multiple of dc."""
+    degs = sorted(lambda_edge)
+    node = np.array([lambda_edge[d] / d for d in degs], dtype=np.float64)
+    node /= node.sum()
+    counts = {d: int(f * n) for d, f in zip(degs, node)}
+    left = n - sum(counts.values())
+    sockets = sum(d * c for d, c in counts.items())
+    for combo in itertools.combinations_with_replacement(degs, left):
+        if (sockets + sum(combo)) % dc == 0:
+            for d in combo:
+                counts[d] += 1
+            return counts, list(combo)
+    raise ValueError("cannot complete the degree sequence for n=%d, dc=%d" % (n, dc))
+
+
 def rand_irregular_ldpc(n, lambda_edge, dc, rng=None):
     """Random irregular code from an edge-perspective variable degree distribution and check degree ``dc``.
 
@@ -219,24 +240,8 @@ def rand_irregular_ldpc(n, lambda_edge, dc, rng=None):
     Sparse, O(E).  Degree-0/odd-multiplicity effects mean a few checks end up with degree < dc, as upstream.
     """
     rng = rng or np.random
-    degs = sorted(lambda_edge)
-    node = np.array([lambda_edge[d] / d for d in degs], dtype=np.float64)
-    node /= node.sum()
-    counts = {d: int(f * n) for d, f in zip(degs, node)}
-    left = n - sum(counts.values())
-    sockets = sum(d * c for d, c in counts.items())
-    # choose degrees for the `left` remaining variables so that sockets % dc == 0 (search small combinations)
-    best = None
-    import itertools
-
-    for combo in itertools.combinations_with_replacement(degs, left):
-        if (sockets + sum(combo)) % dc == 0:
-            best = combo
-            break
-    if best is None:
-        raise ValueError("cannot complete the degree sequence for n=%d, dc=%d" % (n, dc))
-    for d in best:
-        counts[d] += 1
+    counts, _ = irregular_degree_counts(n, lambda_edge, dc)
+    degs = sorted(counts)
     var_sockets = np.concatenate([np.repeat(np.arange(start, start + counts[d]), d)
                                   for d, start in zip(degs, np.cumsum([0] + [counts[d] for d in degs[:-1]]))])
     m = len(var_sockets) // dc
@@ -250,17 +255,24 @@ def rand_irregular_ldpc(n, lambda_edge, dc, rng=None):
 
 # lambda(x) of the reference's LP design for rho(x) = x^5, rate 1/2 (from ldpc.solve_dist src/ldpc.py:83-94)
 LAMBDA_RHO_X5_HALF_RATE = {2: 0.4126, 3: 0.1763, 4: 0.1189, 7: 0.1136, 8: 0.1786}
+# the same design for the other check degrees `python src/ldpc.py irg --rho R --rate .5` accepts (probed from ldpc.solve_dist; the
+# full values are in tests/golden/irregular_ensembles.json): {rho exponent: {variable degree: edge fraction}}, check degree = rho + 1
+LAMBDA_HALF_RATE = {
+    4: {2: 0.55215011, 3: 0.14354961, 4: 0.30430028},
+    5: LAMBDA_RHO_X5_HALF_RATE,
+    6: {2: 0.33871274, 3: 0.14130372, 4: 0.10088889, 6: 0.09617581, 7: 0.09710031, 15: 0.00480352, 16: 0.22101500},
+}
 
 
 def gen_rand_ldpc(args):
     """CLI of the reference's code generators: ``python src/codes.py <count> <n> <l> <r>`` (src/codes.py:139-174) writes
-    ``<n>_<l>_<r>_rand_ldpc_<i>.txt``; with ``--irregular`` the rate-1/2 rho = x^5 ensemble of ``python src/ldpc.py irg``
-    (src/ldpc.py:149-192) as ``<n>_rho_x5_rand_ldpc_<i>.txt``.  Files land in $FILE_CODES_DIR (default data/codes)."""
+    ``<n>_<l>_<r>_rand_ldpc_<i>.txt``; with ``--irregular [--rho R]`` the rate-1/2 rho = x^R ensemble of ``python src/ldpc.py irg
+    --rho R --rate .5`` (src/ldpc.py:149-192) as ``<n>_rho_x<R>_rand_ldpc_<i>.txt``.  Files land in $FILE_CODES_DIR (default data/codes)."""
     out = []
     for i in range(args.count):
         if args.irregular:
-            code = rand_irregular_ldpc(args.n, LAMBDA_RHO_X5_HALF_RATE, 6)
-            name = "%d_rho_x5_rand_ldpc_%d" % (args.n, i + 1)
+            code = rand_irregular_ldpc(args.n, LAMBDA_HALF_RATE[args.rho], args.rho + 1)
+            name = "%d_rho_x%d_rand_ldpc_%d" % (args.n, args.rho, i + 1)
         else:
             code = rand_reg_ldpc(args.n, args.l, args.r)
             name = "%d_%d_%d_rand_ldpc_%d" % (args.n, args.l, args.r, i + 1)
@@ -279,7 +291,8 @@ def setup_parser():
     p.add_argument("n", help="code length", type=int)
     p.add_argument("l", help="variable degree of the regular ensemble", type=int, nargs="?", default=3)
     p.add_argument("r", help="check degree of the regular ensemble", type=int, nargs="?", default=6)
-    p.add_argument("--irregular", action="store_true", help="rate-1/2 irregular ensemble (lambda of the reference's LP design, rho = x^5)")
+    p.add_argument("--irregular", action="store_true", help="rate-1/2 irregular ensemble (lambda of the reference's LP design for rho = x^RHO)")
+    p.add_argument("--rho", type=int, default=5, choices=sorted(LAMBDA_HALF_RATE), help="exponent of rho(x) = x^RHO, i.e. check degree RHO + 1 (with --irregular)")
     p.add_argument("--dir", default=None, help="output directory (default: $FILE_CODES_DIR or data/codes)")
     return p
 

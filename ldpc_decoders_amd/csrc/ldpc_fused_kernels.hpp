@@ -1,0 +1,1124 @@
+// Fused on-chip backend -- device code (kernels + shape descriptors), included by the ldpc_fused_shapes_*.hip translation units.
+//
+// Fused on-chip backend: one workgroup of NW wavefronts owns one frame for ALL of its sweeps; messages never leave the CU.
+//
+// Regime: (dv,dc)-regular codes whose per-frame state fits the LDS (n = 1200 (3,6): 20 KB -> 8 frames per CU).
+// The HBM traffic of a frame shrinks from sizeof(T)(4E+n) PER SWEEP (streaming backend) to its priors in and its
+// decisions out, once; the kernel is bound by LDS gathers and VALU instead.
+//
+// Mapping (all tables are built once on the host, FusedPlan):
+//   * wave w, lane L owns check slots (w*CRW + r, L), r < CRW, and variable slots (w*VRW + q, L), q < VRW.
+//   * registers: the check->variable messages of the owned checks (c2v_old[CRW][DC]), the priors of the owned
+//     variables, and every gather address (packed 16-bit LDS byte offsets) -- loaded once per launch.
+//   * LDS (per frame): marg[VR*64]  marginal of variable slot s at dword s            (VR = NW*VRW)
+//                      c2v [CR*DC*64 (+64)]  message of (check slot (R,L), edge position j) at dword (R*DC+j)*64+L;
+//                                            an optional last row stays 0 (target of the gathers of missing edges)
+//   * check phase : v2c_j = marg[var] - c2v_old_j  (dc LDS gathers), leave-one-out min / join + sign parity, write c2v
+//                   (lane-contiguous, conflict-free); the syndrome of the previous decisions falls out of the same
+//                   gathers (sign of marg) -- that is the reference's early-exit test (src/bpa.py:29).
+//   * variable phase: marginal = prior + ((0 + c_a) + c_b) + c_c in ascending edge order (dv LDS gathers), write marg.
+//   NW = 1: LDS is private to the wave and DS operations of one wave execute in order, so the phases need no barrier.
+//   NW = 2: twice the resident waves per CU (the kernel is latency-bound at 2 waves per SIMD); one s_barrier after each
+//           phase, the syndrome verdicts of the waves are exchanged through padded c2v slots each wave owns.
+//   NW = 4: codes up to m = 1536 / n = 2816 (48 KB of LDS per frame, 3 frames per CU), same hand-off scheme.
+//           (NW = 4 with 3 check rounds per wave was measured for n = 1200: slower than NW = 2, 4.15 vs 3.74 ms.)
+//
+// Arithmetic identical to the streaming backend / reference (src/bpa.py:17-63, 86-102): the leave-one-out minimum
+// equals "second minimum at the first arg-min, first minimum elsewhere"; min/compare/negate/add/sub only.
+#pragma once
+#include <type_traits>
+
+#include "ldpc_cn.hpp"
+#include "ldpc_common.hpp"
+#include "ldpc_rng.hpp"
+
+namespace ldpc {
+
+// One instantiated kernel shape: what the host-side plan builder (ldpc_fused.hip) chooses from.
+struct ShapeEntry {
+    int alg, DC, DV, CRW, VRW, NW, VRX, DVX;  // VRX wide variable rounds of DVX gathers (irregular codes), 0 for regular
+    const void* kernel;      // decode: priors in, decisions out
+    const void* kernel_sim;  // simulate: noise in the kernel, counters out (null: decode only)
+    int esz = 4;             // bytes per LDS element: 4 (fp32 kernels), 8 (fp64 kernels)
+};
+// shape tables, one per translation unit (built in parallel); preference order = table order
+const ShapeEntry* fused_shapes_f32_dc6(int* count);
+const ShapeEntry* fused_shapes_f32_dcx(int* count);
+const ShapeEntry* fused_shapes_f64_dc6(int* count);
+const ShapeEntry* fused_shapes_f64_dcx(int* count);
+
+namespace {
+
+using u64 = unsigned long long;
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- needed where the index feeds an asm immediate
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ uint32_t half_of(const uint32_t (&tab)[(K + 1) / 2], int k) {
+    const uint32_t w = tab[k >> 1];
+    return (k & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+// Lane-contiguous LDS store without an address register: LDS[M0 + OFF + 4*lane] = v (ds_write_addtid_b32 moves one
+// source dword instead of two -> half the store-path cycles of ds_write_b32; MI355X_MICROARCH.md, LDS table).
+// Inline asm: the compiler does not count it in lgkmcnt; its own waits then only become more conservative
+// (LDS operations of a wave retire in order), never too early.
+template <int OFF>
+__device__ __forceinline__ void lds_st_tid(float v) {
+    static_assert(OFF >= 0 && OFF < 65536, "16-bit DS offset");
+    asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_set_m0(uint32_t base) { asm volatile("s_mov_b32 m0, %0" ::"s"(base) : "memory"); }
+
+// Workgroup barrier that also drains this wave's LDS queue: the ds_write_addtid stores above are inline asm, invisible to
+// the compiler's s_waitcnt insertion, so a plain __syncthreads() may reach s_barrier with such stores still in flight.
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
+__device__ __forceinline__ float lds_ld(const unsigned char* base, uint32_t byte_off) {
+    return *reinterpret_cast<const float*>(base + byte_off);
+}
+// gather through a table entry: a 16-bit LDS byte offset, or (BIG: frames beyond 64 KB of LDS) a 16-bit dword index
+template <bool BIG>
+__device__ __forceinline__ float lds_gat(const unsigned char* base, uint32_t entry) {
+    return *reinterpret_cast<const float*>(base + (BIG ? (entry << 2) : entry));
+}
+// c2v store of the BIG shape: ds_write_addtid reaches M0[15:0] + 16-bit offset only, so rows beyond that use an address
+// register (lane-contiguous all the same; 4 instead of 2 store-path cycles)
+// Two rows per instruction: ds_write2st64_b32 stores a at vaddr + R0*256 and b at vaddr + R1*256 (offsets in units of 64 dwords
+// == one lane-contiguous row); three source dwords -> 6 store-path cycles for two rows.
+template <int R0, int R1>
+__device__ __forceinline__ void lds_st2_rows(uint32_t vaddr, float a, float b) {
+    static_assert(R0 >= 0 && R0 < 256 && R1 >= 0 && R1 < 256, "8-bit row offsets");
+    asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(vaddr), "v"(a), "v"(b), "n"(R0), "n"(R1) : "memory");
+}
+
+struct FusedArgs {
+    const void* priors;             // [B,n] float (fp32 kernels) or double (fp64 min-sum kernel)
+    const uint8_t* y0;
+    long long B;
+    int n, max_iter;
+    unsigned flags;
+    const uint32_t* cn_tab;
+    const uint32_t* vn_tab;
+    const int32_t* var_of_slot;
+    const u64* cn_active;
+    uint8_t* xhat;
+    int32_t* iters;
+    void* soft;                     // optional [B,n] (float / double as the kernel): marginals of each frame's last executed sweep (src/bpa.py:35), 0 if none
+    u64* next_frame;
+    int zero_row;
+    int sync_off[4];                 // 1 < NW <= 4: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
+    int msync_off[4];                // 1 < NW <= 4: byte offset of a padded MARGINAL slot owned by wave w (end-of-sweep hand-off)
+    int sys_off;                     // NW = 16: byte offset of the system row (last marginal row, never written by the sweeps)
+    // fused simulate (SIM kernels): BI-AWGN noise generated in the kernel, errors counted in the kernel
+    const int32_t* slot_of_var;     // [n rounded up to 4] LDS dword index (marg area) of each variable
+    float sim_mean, sim_sigma, sim_k;  // y = mean + sigma z ; prior = -(k y), k = 2/sigma^2   (src/biawgn.py:17-28)
+    unsigned long long seed, frame0;
+    unsigned stream;
+    int codeword, hist_bins;
+    int sim_channel;                 // CH_BIAWGN or CH_BSC
+    unsigned long long bsc_thr;     // BSC: flip <=> Philox word < thr   (src/bsc.py:16)
+    float bsc_llr;                  // BSC: prior = llr * (1 - 2y)        (src/bsc.py:21,25), llr > 0 here
+    double sim_mean_d, sim_sigma_d, sim_k_d, bsc_llr_d;  // the same constants for the fp64 kernels (k_biawgn<double> / k_discrete<double>)
+    uint32_t certain_entry;         // gather-table entry of the "certain" variable slot that pads short check rows (0xffffffff: none)
+    unsigned long long* counters;   // [4 + hist_bins] tot, wec, bec, iter_sum, histogram of sweeps
+};
+
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 || DVX > 8 || (NW == 2 && DC >= 7)) ? 3 : 4)) void k_fused_bp(const FusedArgs A) {
+    // BIG: a frame takes the whole LDS of a CU (160 KB) and a 16-wave workgroup.  Table entries are dword indices, c2v stores
+    // use an address register, and the LAST marginal row is a system row that no sweep writes: dwords [0,16) hand-off
+    // channel A (one word per wave), [16,32) channel B, [32] frame hand-out, [33] always zero (target of missing edges).
+    constexpr bool BIG = NW > 4;
+    // SYS: the system row (hand-off words + zero word in the last marginal row) is also what lets SEVERAL waves share an
+    // irregular frame of the small shapes (they have no always-zero row and may have no padded slot per wave)
+    constexpr bool SYS = BIG || (NW > 1 && VRX > 0);
+    constexpr int VNK = VRX * DVX + (VRW - VRX) * DV;  // gathers of a variable phase: wide rounds first, then narrow ones
+    constexpr int VN0 = VRX * DVX;                      // first gather index of the narrow rounds
+    constexpr int CR = CRW * NW, VR = VRW * NW;
+    constexpr int NPAD = VR * 64;
+    constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
+    constexpr int VG_BEC = NW > 4 ? 1 : 2;  // variable rounds per pipeline stage of the erasure decoder
+    constexpr int VRN = VRW - VRX;  // narrow variable rounds (DV gathers); they follow the VRX wide rounds
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    float* lds_marg = reinterpret_cast<float*>(smem) + w * VRW * 64;  // this wave's marginal rows
+    const int32_t* vslot = A.var_of_slot + w * VRW * 64;
+    const u64* cn_active = A.cn_active + w * CRW;
+    const int n = A.n, max_iter = A.max_iter;
+
+    // gather addresses, resident in registers for the whole launch
+    uint32_t cn_idx[CNW], vn_idx[VNW];
+#pragma unroll
+    for (int i = 0; i < CNW; ++i) cn_idx[i] = A.cn_tab[(w * CNW + i) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < VNW; ++i) vn_idx[i] = A.vn_tab[(w * VNW + i) * 64 + lane];
+    // variable index of each owned slot (-1: padding): resident in registers where the budget allows, else re-read per frame
+    constexpr bool VMAP_RESIDENT = !SIM && !BIG && ((NW == 1) || (ALG == ALG_MSA));
+    int vmap_reg[VMAP_RESIDENT ? VRW : 1];
+    if constexpr (VMAP_RESIDENT) {
+#pragma unroll
+        for (int q = 0; q < VRW; ++q) vmap_reg[q] = vslot[q * 64 + lane];
+    }
+    // BIG: 128 VGPRs per wave do not hold both gather tables next to the messages and priors; the compiler spills part of the
+    // variable-phase table and reloads it after the barrier that ends the check phase.  Measured alternatives (n = 10 000,
+    // 16 384 frames x 48.7 sweeps): re-reading the whole table from L2 every sweep, issued BEFORE that barrier, removes every
+    // spill but is slower for min-sum (11.3 vs 10.0 ms) and sum-product (no change); it wins for the erasure decoder
+    // (14.0 vs 15.4 ms), which keeps it.
+    constexpr int VN_STREAM = (BIG && ALG == ALG_BEC) ? VNW : 0;
+    auto stream_vn = [&]() {
+        if constexpr (VN_STREAM > 0) {
+#pragma unroll
+            for (int i = VNW - VN_STREAM; i < VNW; ++i) vn_idx[i] = __builtin_nontemporal_load(A.vn_tab + (w * VNW + i) * 64 + lane);
+        }
+    };
+    auto vmap_of = [&](int q) -> int {
+        if constexpr (VMAP_RESIDENT) return vmap_reg[q]; else return vslot[q * 64 + lane];
+    };
+    if (A.zero_row && w == 0) reinterpret_cast<float*>(smem)[NPAD + CR * DC * 64 + lane] = 0.0f;  // the always-zero row
+    const bool own_last = !(SYS && w == NW - 1);  // with a system row, wave NW-1 never writes its last marginal row
+    auto sysw = [&](int i) { return reinterpret_cast<volatile uint32_t*>(smem + A.sys_off) + i; };
+    if constexpr (SYS) {
+        if (threadIdx.x == 0) *sysw(33) = 0u;  // published by the barrier at the top of the frame loop
+    }
+
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+    const uint32_t m0_c2v = lds_base + (uint32_t)(NPAD + w * CRW * DC * 64) * 4;  // this wave's c2v rows
+    const uint32_t m0_marg = lds_base + (uint32_t)(w * VRW * 64) * 4;            // this wave's marginal rows
+    const uint32_t my_sync = (uint32_t)A.sync_off[SYS ? 0 : w];
+    const uint32_t my_msync = (uint32_t)A.msync_off[SYS ? 0 : w];
+    const uint32_t c2v_vaddr = m0_c2v + (uint32_t)lane * 4u;  // BIG: address register of the c2v stores
+    const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
+    // SIM: per-workgroup counters live in wave 0 (scalars + one histogram bin per lane), flushed once at the end
+    unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
+    u64 acc_tot = 0, acc_wec = 0, acc_bec = 0, acc_it = 0;
+    unsigned hist_lane = 0;
+    unsigned dummy = 0;  // bit q: slot (q, lane) is the "certain" slot that pads short check rows (var_of_slot == -2)
+    if constexpr (SIM || ALG == ALG_BEC || VRX > 0) {
+#pragma unroll
+        for (int q = 0; q < VRW; ++q) {
+            valid |= (vslot[q * 64 + lane] >= 0) ? (1u << q) : 0u;
+            dummy |= (vslot[q * 64 + lane] == -2) ? (1u << q) : 0u;
+        }
+    }
+
+    // verdict exchange between the NW waves of a frame: each wave publishes "my checks see an unsatisfied syndrome" in a
+    // padded c2v slot it owns (nobody else ever writes it; its own garbage write precedes in program order) -> barrier ->
+    // everybody reads all verdicts.  The next write to those slots happens after the following barrier.
+    auto any_unsat = [&](bool mine) -> bool {
+        if constexpr (NW == 1) {
+            return mine;
+        } else if constexpr (SYS) {
+            if (lane == 0) *sysw(w) = mine ? 1u : 0u;
+            wg_barrier();
+            return __ballot(*sysw(lane & (NW - 1)) != 0u) != 0;
+        } else {
+            if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_sync) = mine ? 1u : 0u;
+            wg_barrier();
+            uint32_t v = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) v |= *reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[i]);
+            return v != 0u;
+        }
+    };
+
+    // second hand-off channel: values produced at the END of a variable phase (or after the last sweep) travel through a
+    // padded MARGINAL slot each wave owns -- those are next written in the following variable phase, i.e. behind a
+    // barrier, whereas the c2v hand-off words are overwritten by the very next check phase.
+    auto exchange_or = [&](uint32_t mine) -> uint32_t {  // OR of the words of all waves (contains one barrier)
+        if constexpr (NW == 1) {
+            return mine;
+        } else if constexpr (SYS) {
+            if (lane == 0) *sysw(16 + w) = mine;
+            wg_barrier();
+            const uint32_t v = *sysw(16 + (lane & (NW - 1)));
+            return (__ballot((v & 1u) != 0u) != 0 ? 1u : 0u) | (__ballot((v & 2u) != 0u) != 0 ? 2u : 0u);
+        } else {
+            if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_msync) = mine;
+            wg_barrier();
+            uint32_t v = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) v |= *reinterpret_cast<volatile uint32_t*>(smem + A.msync_off[i]);
+            return v;
+        }
+    };
+    // frame error counts after the last sweep: through whichever pair of hand-off words the sweep loop did NOT just use for
+    // its exit verdict (the other wave may still be reading that one): marginal slots for the LLR decoders, c2v slots for
+    // the erasure decoder
+    auto exchange_add = [&](int mine) -> int {
+        if constexpr (NW == 1) {
+            return mine;
+        } else if constexpr (SYS) {
+            constexpr int CH = ALG == ALG_BEC ? 0 : 16;  // the channel the sweep loop did not just use
+            if (lane == 0) *sysw(CH + w) = (uint32_t)mine;
+            wg_barrier();
+            int sum = lane < NW ? (int)*sysw(CH + (lane & (NW - 1))) : 0;
+#pragma unroll
+            for (int o = NW / 2; o; o >>= 1) sum += __shfl_xor(sum, o);
+            return __builtin_amdgcn_readfirstlane(sum);
+        } else {
+            const uint32_t mine_off = ALG == ALG_BEC ? my_sync : my_msync;
+            if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + mine_off) = mine;
+            wg_barrier();
+            int sum = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) sum += *reinterpret_cast<volatile int32_t*>(smem + (ALG == ALG_BEC ? A.sync_off[i] : A.msync_off[i]));
+            return sum;
+        }
+    };
+
+    // Frame hand-out.  One device-wide counter sustains only ~88 dequeues/us (MI355X_MICROARCH.md, row "dequeue"): 65 536
+    // single-frame dequeues alone would take 0.75 ms.  The frame range is therefore cut into NSHARD contiguous shards with
+    // one counter each (64 B apart); a workgroup drains its home shard (blockIdx % NSHARD -- the XCD it runs on, as
+    // observed) one frame at a time and then helps with the next shards.  Frame granularity keeps the load balanced when
+    // frames need different numbers of sweeps.
+    constexpr int NSHARD = 8;
+    const long long shard_len = (A.B + NSHARD - 1) / NSHARD;
+    int shard = (int)(blockIdx.x % NSHARD), shards_left = NSHARD;
+    auto next_frame = [&]() -> long long {  // wave-uniform; -1 when every shard is drained
+        long long got = -1;
+        while (shards_left > 0) {
+            const long long base = shard * shard_len;
+            const long long len = (base + shard_len <= A.B ? shard_len : A.B - base);
+            u64 t = 0;
+            if (lane == 0) t = atomicAdd(A.next_frame + shard * 8, 1ull);
+            const long long k = (long long)(((u64)__builtin_amdgcn_readfirstlane((unsigned)(t >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)t));
+            if (k < len) { got = base + k; break; }
+            shard = (shard + 1) % NSHARD;
+            --shards_left;
+        }
+        return got;
+    };
+    for (;;) {
+        long long fr_s = 0;
+        if constexpr (NW == 1) {
+            fr_s = next_frame();
+        } else {
+            wg_barrier();  // the verdict slots of the previous frame have been read by everybody
+            if (w == 0) {
+                const long long f0 = next_frame();
+                if (lane == 0) *(SYS ? sysw(32) : reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0])) = (uint32_t)(int32_t)f0;
+            }
+            wg_barrier();
+            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*(SYS ? sysw(32) : reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0])));
+        }
+        if (fr_s < 0) break;
+        const u64 fr = (u64)fr_s;
+        float prior[VRW];
+        float c2v_old[CRW][DC];
+        unsigned xb = 0;  // bit q = hard decision of variable slot (w*VRW + q, lane)
+        if constexpr (SIM) {
+            // channel + LLR in the kernel: the workgroup draws the frame's noise block by block (one Philox block = 4
+            // consecutive variables, exactly as k_biawgn does) and drops every prior into the LDS slot of its variable
+            for (int blk = threadIdx.x; blk * 4 < n; blk += 64 * NW) {
+                const Philox4 ph = philox_word_block(A.seed, A.stream, A.frame0 + fr, (uint32_t)blk);
+                const int4 sl = *reinterpret_cast<const int4*>(A.slot_of_var + blk * 4);
+                const int slots[4] = {sl.x, sl.y, sl.z, sl.w};
+                float pri4[4];
+                if (A.sim_channel == CH_BIAWGN) {
+                    float z[4];
+                    box_muller<float>(ph.w[0], ph.w[1], z[0], z[1]);
+                    box_muller<float>(ph.w[2], ph.w[3], z[2], z[3]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pri4[t] = -(A.sim_k * (A.sim_mean + A.sim_sigma * z[t]));
+                } else if (A.sim_channel == CH_BSC) {  // same integer threshold and the same LLR expression as k_discrete
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int y = A.codeword ^ ((u64)ph.w[t] < A.bsc_thr ? 1 : 0);
+                        pri4[t] = A.bsc_llr * (float)(1 - 2 * y);
+                    }
+                } else {  // BEC: erased where the word is below the threshold; ternary message {-1 (bit 0), +1 (bit 1), 0 (erased)}
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pri4[t] = (u64)ph.w[t] < A.bsc_thr ? 0.0f : (A.codeword ? 1.0f : -1.0f);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (blk * 4 + t < n) reinterpret_cast<float*>(smem)[slots[t]] = pri4[t];
+            }
+            if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                prior[q] = lds_marg[q * 64 + lane];  // padded slots: stale words, never used
+                if (A.sim_channel == CH_BSC) xb |= (__float_as_uint(prior[q]) >> 31) << q;  // x_hat starts as the received word
+            }
+        } else if constexpr (ALG == ALG_BEC) {
+            const uint8_t* yf = A.y0 + fr * n;  // received symbols {0,1,2}; message {-1,+1,0}[y] (src/bec.py:76,85)
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                const int v = vmap_of(q);
+                const int y = v >= 0 ? (int)yf[v] : 2;
+                prior[q] = y == 0 ? -1.0f : (y == 1 ? 1.0f : 0.0f);
+            }
+        } else {
+            const float* pf = reinterpret_cast<const float*>(A.priors) + fr * n;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                const int v = vmap_of(q);
+                prior[q] = v >= 0 ? pf[v] : 0.0f;
+            }
+        }
+        if constexpr (VRX > 0) {
+            // the padding slot of short check rows is a variable known with certainty: +inf LLR (bit 0) for the LLR decoders --
+            // it never wins a minimum, adds nothing to a join and has sign 0 -- and -inf (a known 0) for the erasure decoder
+#pragma unroll
+            for (int q = 0; q < VRW; ++q)
+                if ((dummy >> q) & 1u) prior[q] = ALG == ALG_BEC ? -__builtin_huge_valf() : __builtin_huge_valf();
+        }
+#pragma unroll
+        for (int r = 0; r < CRW; ++r)
+#pragma unroll
+            for (int j = 0; j < DC; ++j) c2v_old[r][j] = 0.0f;
+
+        int it = 0;
+        bool left_at_0 = false;
+
+        unsigned xe = 0;  // erasure decoder: bit q = variable slot (q, lane) still erased (xb then holds the known ones)
+        if constexpr (ALG == ALG_BEC) {
+            // Ternary message passing with the reference's two exits (src/bec.py:96-97,120): "no erasure left" before a
+            // sweep, "x_hat did not change" after it.  `it` counts executed sweeps (the one that finds no change included).
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                if (q < VRW - 1 || own_last) lds_marg[q * 64 + lane] = prior[q];
+                xb |= (prior[q] > 0.0f) ? (1u << q) : 0u;
+                xe |= (prior[q] == 0.0f) ? (1u << q) : 0u;
+            }
+            xe &= valid;
+            bool erased_any = exchange_or(__ballot(xe != 0u) != 0 ? 1u : 0u) != 0u;  // NW > 1: the barrier also publishes marg
+            if constexpr (NW == 1) __builtin_amdgcn_wave_barrier();
+            int updates = 0;  // the reference's iter_count: sweeps that changed x_hat
+            for (;;) {
+                if (max_iter > 0 && updates >= max_iter) break;
+                if (early && !erased_any) break;
+                lds_set_m0(m0_c2v);
+                float mg[2][DC];
+#pragma unroll
+                for (int j = 0; j < DC; ++j) mg[0][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, j));
+                static_for<0, CRW>([&](auto R_) {
+                    constexpr int r = decltype(R_)::value;
+                    if constexpr (r + 1 < CRW) {
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    float sgn[DC];
+                    float n_erased = 0.0f, n_ones = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) {
+                        const float dlt = mg[r & 1][j] - c2v_old[r][j];           // v2c = sign(marginal - c2v)  (src/bec.py:116)
+                        sgn[j] = dlt > 0.0f ? 1.0f : (dlt < 0.0f ? -1.0f : 0.0f);
+                        n_erased += 1.0f - __builtin_fabsf(sgn[j]);
+                        n_ones += sgn[j] > 0.0f ? 1.0f : 0.0f;
+                    }
+                    const float fill = ((int)n_ones & 1) ? 1.0f : -1.0f;  // parity of the known ones (src/bec.py:110-112)
+                    static_for<0, DC>([&](auto J_) {
+                        constexpr int j = decltype(J_)::value;
+                        // 0 erasures: echo; > 1: nothing known; exactly 1: the erased edge learns the parity of the others
+                        const float c = n_erased == 0.0f ? sgn[j] : (n_erased > 1.0f ? 0.0f : (sgn[j] == 0.0f ? fill : 0.0f));
+                        c2v_old[r][j] = c;
+                        if constexpr (!BIG) lds_st_tid<(r * DC + j) * 256>(c);
+                    });
+                    if constexpr (BIG) {
+                        static_assert(!BIG || DC % 2 == 0, "paired row stores");
+                        static_for<0, DC / 2>([&](auto P_) {
+                            constexpr int pj = 2 * decltype(P_)::value;
+                            lds_st2_rows<r * DC + pj, r * DC + pj + 1>(c2v_vaddr, c2v_old[r][pj], c2v_old[r][pj + 1]);
+                        });
+                    }
+                });
+                stream_vn();
+                if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
+                lds_set_m0(m0_marg);
+                unsigned nb = 0, ne = 0;
+                auto finish_var = [&](auto Q_, float sm) {
+                    constexpr int q = decltype(Q_)::value;
+                    const float m1 = prior[q] + sm;  // small integers: exact
+                    if (q < VRW - 1 || own_last) lds_st_tid<q * 256>(m1);
+                    nb |= (m1 > 0.0f) ? (1u << q) : 0u;
+                    ne |= (m1 == 0.0f) ? (1u << q) : 0u;
+                };
+                if constexpr (VRX > 0) {
+                    float cw[2][DVX];
+#pragma unroll
+                    for (int j = 0; j < DVX; ++j) cw[0][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, j));
+                    static_for<0, VRX>([&](auto Q_) {
+                        constexpr int q = decltype(Q_)::value;
+                        if constexpr (q + 1 < VRX) {
+#pragma unroll
+                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, (q + 1) * DVX + j));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        float sw = cw[q & 1][0];
+#pragma unroll
+                        for (int j = 1; j < DVX; ++j) sw += cw[q & 1][j];
+                        finish_var(Q_, sw);
+                    });
+                }
+                float cv[2][VG_BEC][DV];
+#pragma unroll
+                for (int u = 0; u < VG_BEC; ++u)
+#pragma unroll
+                    for (int j = 0; j < DV; ++j)
+                        if (u < VRN) cv[0][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                static_for<0, (VRN + VG_BEC - 1) / VG_BEC>([&](auto G_) {
+                    constexpr int g = decltype(G_)::value;
+                    if constexpr (g + 1 < (VRN + VG_BEC - 1) / VG_BEC) {
+#pragma unroll
+                        for (int u = 0; u < VG_BEC; ++u)
+#pragma unroll
+                            for (int j = 0; j < DV; ++j)
+                                if ((g + 1) * VG_BEC + u < VRN)
+                                    cv[(g + 1) & 1][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG_BEC + u) * DV + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, VG_BEC>([&](auto U_) {
+                        constexpr int u = decltype(U_)::value;
+                        if constexpr (g * VG_BEC + u < VRN) {
+                            float sm = cv[g & 1][u][0];
+#pragma unroll
+                            for (int j = 1; j < DV; ++j) sm += cv[g & 1][u][j];
+                            finish_var(std::integral_constant<int, VRX + g * VG_BEC + u>{}, sm);
+                        }
+                    });
+                });
+                ++it;
+                const unsigned chg = ((nb ^ xb) | (ne ^ xe)) & valid;
+                ne &= valid;
+                // bit 0: some decision changed, bit 1: some variable is still erased (barrier inside for NW > 1)
+                const uint32_t verdict = exchange_or((__ballot(chg != 0u) != 0 ? 1u : 0u) | (__ballot(ne != 0u) != 0 ? 2u : 0u));
+                if constexpr (NW == 1) __builtin_amdgcn_wave_barrier();
+                if (early && !(verdict & 1u)) break;  // stopping set: x_hat stays (it equals the new word anyway)
+                xb = nb;
+                xe = ne;
+                erased_any = (verdict & 2u) != 0u;
+                ++updates;
+            }
+        }
+        if (ALG != ALG_BEC && !SIM && A.y0 != nullptr) {
+            // iteration-0 test of the received hard word (src/bpa.py:20,29): park it in the marg area as -+1
+            const uint8_t* yf = A.y0 + fr * n;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                const int v = vmap_of(q);
+                const bool one = v >= 0 && yf[v] != 0;
+                if (q < VRW - 1 || own_last) lds_marg[q * 64 + lane] = one ? -1.0f : 1.0f;
+                xb |= one ? (1u << q) : 0u;
+            }
+            if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
+            u64 unsat = 0;
+#pragma unroll
+            for (int r = 0; r < CRW; ++r) {
+                u64 par = 0;
+#pragma unroll
+                for (int j = 0; j < DC; ++j) par ^= __ballot(lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, r * DC + j)) < 0.0f);
+                if constexpr (DC % 2 == 0) unsat |= par; else unsat |= par & cn_active[r];
+            }
+            left_at_0 = early && !any_unsat(unsat != 0);
+            if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
+        }
+        if (ALG != ALG_BEC && !left_at_0) {
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) if (q < VRW - 1 || own_last) lds_marg[q * 64 + lane] = prior[q];
+            if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
+            // The sweep is one software-pipelined stream of LDS traffic: the gathers of check round r+1 (variable
+            // group g+1) are issued before round r (group g) is computed, so a wave always has a full round of
+            // ds_reads in flight while it does arithmetic.
+            constexpr int VG = BIG ? 1 : ((ALG == ALG_MSA && NW == 1) ? 4 : 2);  // variable rounds per pipeline stage (register budget)
+            constexpr int NVG = (VRN + VG - 1) / VG;
+            for (;;) {
+                if (max_iter > 0 && it >= max_iter) break;
+                lds_set_m0(m0_c2v);
+                // ---------------- check phase (+ syndrome of the decisions of the previous sweep)
+                uint32_t synd = 0;  // bit 31: some owned check is unsatisfied by the previous decisions
+                float mg[2][DC];
+#pragma unroll
+                for (int j = 0; j < DC; ++j) mg[0][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, j));
+                static_for<0, CRW>([&](auto R_) {
+                    constexpr int r = decltype(R_)::value;
+                    if constexpr (r + 1 < CRW) {
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this round's arithmetic
+                    // Sign handling on the raw IEEE bits (bit 31), all in the vector ALU: row parity = XOR of the sign
+                    // bits, extrinsic sign = parity ^ own sign.  Equivalent to the reference's comparisons
+                    // ((v < 0) for the parity, (v >= 0) for the own sign, src/math_utils.py:10,38-43) because v is never
+                    // -0.0 here: marginals are built as prior + ((0.0 + c_a) + c_b + c_c) (see the variable phase).
+                    float v[DC], a[DC];
+                    uint32_t vx = 0, mx = 0;
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) {
+                        v[j] = mg[r & 1][j] - c2v_old[r][j];
+                        a[j] = __builtin_fabsf(v[j]);
+                    }
+                    // XOR of the raw words, three inputs per instruction (v_bitop3_b32, truth table 0x96)
+#pragma unroll
+                    for (int j = 0; j + 2 < DC; j += 3) {
+                        mx ^= xor3(__float_as_uint(mg[r & 1][j]), __float_as_uint(mg[r & 1][j + 1]), __float_as_uint(mg[r & 1][j + 2]));
+                        vx ^= xor3(__float_as_uint(v[j]), __float_as_uint(v[j + 1]), __float_as_uint(v[j + 2]));
+                    }
+#pragma unroll
+                    for (int j = DC - DC % 3; j < DC; ++j) {
+                        mx ^= __float_as_uint(mg[r & 1][j]);
+                        vx ^= __float_as_uint(v[j]);
+                    }
+                    if constexpr (DC % 2 == 0) synd |= mx; else synd |= ((cn_active[r] >> lane) & 1ull) ? mx : 0u;
+                    // leave-one-out reduction of |v|: minimum (min-sum) or join of 1 - tanh(|v|/2) (sum-product, ldpc_cn.hpp)
+                    float pre[DC], suf[DC];
+                    float preo[ALG == ALG_MSA ? 1 : DC], sufo[ALG == ALG_MSA ? 1 : DC];  // odd parts (sum-product only)
+                    if constexpr (ALG == ALG_MSA && DC == 6) {
+                        // 11 minimum instructions for the six leave-one-out minima (v_min3_f32 where three inputs meet)
+                        const float s3 = fminf(a[4], a[5]), s2 = fminf(fminf(a[3], a[4]), a[5]), s1 = fminf(a[2], s2);
+                        const float p2 = fminf(a[0], a[1]), p3 = fminf(fminf(a[0], a[1]), a[2]);
+                        pre[0] = fminf(fminf(a[1], a[2]), s2); suf[0] = pre[0];
+                        pre[1] = fminf(a[0], s1);              suf[1] = pre[1];
+                        pre[2] = fminf(p2, s2);                suf[2] = pre[2];
+                        pre[3] = fminf(p3, s3);                suf[3] = pre[3];
+                        pre[4] = fminf(fminf(p3, a[3]), a[5]); suf[4] = pre[4];
+                        pre[5] = fminf(fminf(p3, a[3]), a[4]); suf[5] = pre[5];
+                    } else if constexpr (ALG == ALG_MSA) {
+                        pre[0] = __builtin_huge_valf();
+#pragma unroll
+                        for (int j = 1; j < DC; ++j) pre[j] = fminf(pre[j - 1], a[j - 1]);
+                        suf[DC - 1] = __builtin_huge_valf();
+#pragma unroll
+                        for (int j = DC - 2; j >= 0; --j) suf[j] = fminf(suf[j + 1], a[j + 1]);
+                    } else {
+                        // sum-product: (E, O) pairs of prod (1 + u_i), prefix in (pre, preo), suffix in (suf, sufo) -- ldpc_cn.hpp
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) a[j] = spa_u_of_llr(a[j]);
+                        pre[0] = 1.0f; preo[0] = 0.0f;
+#pragma unroll
+                        for (int j = 1; j < DC; ++j) {
+                            pre[j] = pre[j - 1]; preo[j] = preo[j - 1];
+                            spa_eo_push(pre[j], preo[j], a[j - 1]);
+                        }
+                        suf[DC - 1] = 1.0f; sufo[DC - 1] = 0.0f;
+#pragma unroll
+                        for (int j = DC - 2; j >= 0; --j) {
+                            suf[j] = suf[j + 1]; sufo[j] = sufo[j + 1];
+                            spa_eo_push(suf[j], sufo[j], a[j + 1]);
+                        }
+                    }
+                    static_for<0, DC>([&](auto J_) {
+                        constexpr int j = decltype(J_)::value;
+                        float mag;
+                        if constexpr (ALG == ALG_MSA) mag = fminf(pre[j], suf[j]); else mag = spa_llr_of_eo(pre[j], preo[j], suf[j], sufo[j]);
+                        const float c = __uint_as_float(__float_as_uint(mag) | ((vx ^ __float_as_uint(v[j])) & 0x80000000u));
+                        c2v_old[r][j] = c;
+                        if constexpr (!BIG) lds_st_tid<(r * DC + j) * 256>(c);
+                    });
+                    if constexpr (BIG) {
+                        static_assert(!BIG || DC % 2 == 0, "paired row stores");
+                        static_for<0, DC / 2>([&](auto P_) {
+                            constexpr int pj = 2 * decltype(P_)::value;
+                            lds_st2_rows<r * DC + pj, r * DC + pj + 1>(c2v_vaddr, c2v_old[r][pj], c2v_old[r][pj + 1]);
+                        });
+                    }
+                });
+                stream_vn();
+                const bool unsat = any_unsat(__ballot((synd & 0x80000000u) != 0u) != 0);  // NW > 1: contains the barrier
+                // it == 0: only the BSC checks the received word itself (src/bpa.py:20,29); in SIM mode marg holds +-llr there
+                if (early && (it > 0 || (SIM && A.sim_channel == CH_BSC)) && !unsat) break;
+                if constexpr (NW == 1) __builtin_amdgcn_wave_barrier();
+                // ---------------- variable phase
+                lds_set_m0(m0_marg);
+                xb = 0;
+                // one variable: ordered sum from +0.0 (as scipy; keeps -0.0 out of the marginals), prior last, decision bit
+                auto finish_var = [&](auto Q_, float s) {
+                    constexpr int q = decltype(Q_)::value;
+                    const float m1 = prior[q] + s;
+                    if (q < VRW - 1 || own_last) lds_st_tid<q * 256>(m1);
+                    // decision: (m1 < 0); for min-sum the sign bit itself (m1 is never -0.0 and never NaN for finite priors)
+                    if constexpr (ALG == ALG_MSA) xb |= (__float_as_uint(m1) >> 31) << q; else xb |= (m1 < 0.0f) ? (1u << q) : 0u;
+                };
+                if constexpr (VRX > 0) {  // wide rounds of irregular codes: DVX gathers per variable, one round per stage
+                    float cw[2][DVX];
+#pragma unroll
+                    for (int j = 0; j < DVX; ++j) cw[0][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, j));
+                    static_for<0, VRX>([&](auto Q_) {
+                        constexpr int q = decltype(Q_)::value;
+                        if constexpr (q + 1 < VRX) {
+#pragma unroll
+                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, (q + 1) * DVX + j));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        float sw = 0.0f + cw[q & 1][0];
+#pragma unroll
+                        for (int j = 1; j < DVX; ++j) sw += cw[q & 1][j];
+                        finish_var(Q_, sw);
+                    });
+                }
+                float cv[2][VG][DV];
+#pragma unroll
+                for (int u = 0; u < VG; ++u)
+#pragma unroll
+                    for (int j = 0; j < DV; ++j)
+                        if (u < VRN) cv[0][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                static_for<0, NVG>([&](auto G_) {
+                    constexpr int g = decltype(G_)::value;
+                    if constexpr (g + 1 < NVG) {
+#pragma unroll
+                        for (int u = 0; u < VG; ++u)
+#pragma unroll
+                            for (int j = 0; j < DV; ++j)
+                                if ((g + 1) * VG + u < VRN)
+                                    cv[(g + 1) & 1][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG + u) * DV + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, VG>([&](auto U_) {
+                        constexpr int u = decltype(U_)::value;
+                        if constexpr (g * VG + u < VRN) {
+                            float sn = 0.0f + cv[g & 1][u][0];
+#pragma unroll
+                            for (int j = 1; j < DV; ++j) sn += cv[g & 1][u][j];
+                            finish_var(std::integral_constant<int, VRX + g * VG + u>{}, sn);
+                        }
+                    });
+                });
+                if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
+                ++it;
+            }
+        }
+        if constexpr (SIM) {
+            // errors against the all-`codeword` word (src/main.py:41-45), counted from the decision bits
+            const unsigned wrong = ((A.codeword ? ~xb : xb) | xe) & valid;  // an unresolved erasure counts as a bit error
+            int err = 0;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) err += __popcll(__ballot((wrong >> q) & 1u));
+            err = exchange_add(err);
+            err = __builtin_amdgcn_readfirstlane(err);  // wave-uniform: keep the accumulators in scalar registers
+            acc_tot += 1;
+            acc_wec += err > 0;
+            acc_bec += (u64)err;
+            acc_it += (u64)it;
+            const int bin = it < A.hist_bins ? it : A.hist_bins - 1;
+            hist_lane += (lane == bin) ? 1u : 0u;
+        } else {
+            if (w == 0 && lane == 0) A.iters[fr] = it;
+            uint8_t* xf = A.xhat + fr * n;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                const int v = vmap_of(q);
+                if (v >= 0) xf[v] = ((xe >> q) & 1u) ? (uint8_t)2 : (uint8_t)((xb >> q) & 1u);
+            }
+            if constexpr (ALG != ALG_BEC) {
+                // soft output: the marginal rows this wave wrote in its last variable phase are still in the LDS (the check phase
+                // that found the syndrome satisfied, or the sweep cap, does not touch them)
+                if (A.soft != nullptr) {
+                    float* sf = reinterpret_cast<float*>(A.soft) + fr * n;
+#pragma unroll
+                    for (int q = 0; q < VRW; ++q) {
+                        const int v = vmap_of(q);
+                        if (v >= 0) sf[v] = it > 0 ? lds_marg[q * 64 + lane] : 0.0f;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (SIM) {
+        if (w == 0) {
+            if (lane == 0) {
+                atomicAdd(&A.counters[0], acc_tot);
+                atomicAdd(&A.counters[1], acc_wec);
+                atomicAdd(&A.counters[2], acc_bec);
+                atomicAdd(&A.counters[3], acc_it);
+            }
+            if (lane < A.hist_bins && hist_lane) atomicAdd(&A.counters[4 + lane], (u64)hist_lane);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp64 belief propagation on the LDS: the reference's own arithmetic (src/bpa.py:17-63 computes in float64).
+//   ALG_MSA  min-sum (src/bpa.py:86-102): only add/sub/compare -> hard decisions and iteration counts bit-identical to the
+//            reference on identical priors -- at LDS speed instead of HBM speed.
+//   ALG_SPA  sum-product, the reference formula verbatim (src/bpa.py:66-75, src/math_utils.py:47-60: tanh, exp-sum-log product,
+//            divide, atanh, +-1 -> +-inf; inf - inf -> NaN -> decision 0) through cn_spa<double> of ldpc_cn.hpp, i.e. the very
+//            same device code as the streaming kernel: bit-identical to it.  The row sum of log|tanh| is order dependent, so
+//            the plan of an fp64 sum-product decoder keeps every check's edges in their canonical (ascending variable) order.
+// Check degrees DC in 4..8, NW waves per frame with the system-row hand-off protocol of the big fp32 shapes (last marginal row
+// reserved: dwords [0,16) verdict channel A, [16,32) channel B, [32] frame hand-out, [34,36) an always-zero double).  Same tables
+// and layout plan as the fp32 kernels with 8-byte elements; gathers are ds_read_b64 (2 LDS cycles, as b32), stores ds_write_b64.
+// SIM: channel + LLR in the kernel (Philox noise, the inline functions of the stand-alone channel kernels: bit-identical
+// priors) and error counting in the kernel -- priors and decisions never exist in HBM.
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const FusedArgs A) {
+    static_assert(ALG == ALG_MSA || ALG == ALG_SPA, "LLR decoders");
+    constexpr int VR = VRW * NW, NPAD = VR * 64;
+    constexpr int VNK = VRX * DVX + (VRW - VRX) * DV;  // gathers of a wave's variable phase: VRX wide rounds (irregular codes) first
+    constexpr int VN0 = VRX * DVX, VRN = VRW - VRX;
+    constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    double* const lds = reinterpret_cast<double*>(smem);
+    double* const my_marg = lds + w * VRW * 64 + lane;                  // row q of this wave at my_marg[q * 64]
+    double* const my_c2v = lds + NPAD + w * CRW * DC * 64 + lane;       // message (r, j) of this wave at my_c2v[(r * DC + j) * 64]
+    const int32_t* vslot = A.var_of_slot + w * VRW * 64;
+    const u64* cn_active = A.cn_active + w * CRW;
+    const int n = A.n, max_iter = A.max_iter;
+    const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
+    const bool own_last = !(NW > 1 && w == NW - 1);
+    auto sysw = [&](int i) { return reinterpret_cast<volatile uint32_t*>(smem + A.sys_off) + i; };
+    // table entries: 16-bit byte offsets, or -- frames beyond 64 KB of LDS (WIDE) -- 16-bit indices of 8-byte elements
+    constexpr bool WIDE = (size_t)(VR * 64 + CRW * NW * DC * 64) * 8 > 65536;
+    auto gat = [&](uint32_t entry) { return *reinterpret_cast<const double*>(smem + (WIDE ? (entry << 3) : entry)); };
+    if (threadIdx.x == 0) {  // the always-zero double (system-row bytes 136..143) that missing edges gather
+        *sysw(34) = 0u;
+        *sysw(35) = 0u;
+    }
+
+    uint32_t cn_idx[CNW], vn_idx[VNW];
+#pragma unroll
+    for (int i = 0; i < CNW; ++i) cn_idx[i] = A.cn_tab[(w * CNW + i) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < VNW; ++i) vn_idx[i] = A.vn_tab[(w * VNW + i) * 64 + lane];
+    int vmap[VRW];
+    unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
+    unsigned dummy = 0;  // bit q: the "certain" slot that pads short check rows (var_of_slot == -2): prior +inf
+#pragma unroll
+    for (int q = 0; q < VRW; ++q) {
+        vmap[q] = vslot[q * 64 + lane];
+        valid |= vmap[q] >= 0 ? (1u << q) : 0u;
+        dummy |= vmap[q] == -2 ? (1u << q) : 0u;
+    }
+    // sum-product: positions of short check rows that read the certain slot (bit r*DC+j).  Their message must stay 0: the certain
+    // marginal is +inf, and the verbatim rule would feed inf - (+-inf) = NaN back into the row once the other edges saturate
+    // (upstream has no such edge: tanh(inf/2) = 1 contributes log 1 = 0 to the row sum and leaves the parity alone).
+    u64 padpos = 0;
+    if constexpr (ALG == ALG_SPA) {
+        if (A.certain_entry != 0xffffffffu) {
+#pragma unroll
+            for (int k = 0; k < CRW * DC; ++k) padpos |= half_of<CRW * DC>(cn_idx, k) == A.certain_entry ? (1ull << k) : 0ull;
+        }
+    }
+    // counting mode (SIM, or A.counters != null): the Monte-Carlo counters of main.test (src/main.py:41-45) are accumulated here instead
+    // of writing decisions and iteration counts out -- per-workgroup sums in wave 0, one histogram bin per lane, flushed once
+    const bool counting = SIM || A.counters != nullptr;
+    u64 acc_tot = 0, acc_wec = 0, acc_bec = 0, acc_it = 0;
+    unsigned hist_lane = 0;
+
+    auto any_unsat = [&](bool mine) -> bool {  // contains the barrier that separates the phases
+        if constexpr (NW == 1) {
+            __builtin_amdgcn_wave_barrier();
+            return mine;
+        } else {
+            if (lane == 0) *sysw(w) = mine ? 1u : 0u;
+            __syncthreads();
+            return __ballot(*sysw(lane & (NW - 1)) != 0u) != 0;
+        }
+    };
+    auto phase_barrier = [&]() {
+        if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+    };
+
+    constexpr int NSHARD = 8;
+    const long long shard_len = (A.B + NSHARD - 1) / NSHARD;
+    int shard = (int)(blockIdx.x % NSHARD), shards_left = NSHARD;
+    auto next_frame = [&]() -> long long {
+        long long got = -1;
+        while (shards_left > 0) {
+            const long long base = shard * shard_len;
+            const long long len = (base + shard_len <= A.B ? shard_len : A.B - base);
+            u64 t = 0;
+            if (lane == 0) t = atomicAdd(A.next_frame + shard * 8, 1ull);
+            const long long k = (long long)(((u64)__builtin_amdgcn_readfirstlane((unsigned)(t >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)t));
+            if (k < len) { got = base + k; break; }
+            shard = (shard + 1) % NSHARD;
+            --shards_left;
+        }
+        return got;
+    };
+    const double* priors = reinterpret_cast<const double*>(A.priors);
+    for (;;) {
+        long long fr_s;
+        if constexpr (NW == 1) {
+            fr_s = next_frame();
+        } else {
+            __syncthreads();
+            if (w == 0) {
+                const long long f0 = next_frame();
+                if (lane == 0) *sysw(32) = (uint32_t)(int32_t)f0;
+            }
+            __syncthreads();
+            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*sysw(32));
+        }
+        if (fr_s < 0) break;
+        const u64 fr = (u64)fr_s;
+        double prior[VRW], c2v_old[CRW][DC];
+        unsigned xb = 0;
+        if constexpr (SIM) {
+            // channel + LLR in the kernel: one Philox block = 4 consecutive variables, exactly as k_biawgn<double> / k_discrete<double>
+            // do (same inline functions, same fp64 expressions -> bit-identical priors); every prior goes to the LDS slot of its variable
+            for (int blk = threadIdx.x; blk * 4 < n; blk += 64 * NW) {
+                const Philox4 ph = philox_word_block(A.seed, A.stream, A.frame0 + fr, (uint32_t)blk);
+                const int4 sl = *reinterpret_cast<const int4*>(A.slot_of_var + blk * 4);
+                const int slots[4] = {sl.x, sl.y, sl.z, sl.w};
+                double pri4[4];
+                if (A.sim_channel == CH_BIAWGN) {
+                    double z[4];
+                    box_muller<double>(ph.w[0], ph.w[1], z[0], z[1]);
+                    box_muller<double>(ph.w[2], ph.w[3], z[2], z[3]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pri4[t] = -(A.sim_k_d * (A.sim_mean_d + A.sim_sigma_d * z[t]));
+                } else {  // BSC: same integer threshold and the same LLR expression as k_discrete
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int y = A.codeword ^ ((u64)ph.w[t] < A.bsc_thr ? 1 : 0);
+                        pri4[t] = A.bsc_llr_d * (double)(1 - 2 * y);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (blk * 4 + t < n) lds[slots[t]] = pri4[t];
+            }
+            phase_barrier();
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                prior[q] = ((dummy >> q) & 1u) ? __builtin_huge_val() : ((q < VRW - 1 || own_last) ? my_marg[q * 64] : 0.0);  // padded slots: stale words, never used
+                if (A.sim_channel == CH_BSC) xb |= ((uint32_t)__double2hiint(prior[q]) >> 31) << q;  // x_hat starts as the received word
+            }
+        } else {
+            const double* pf = priors + fr * n;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) prior[q] = vmap[q] >= 0 ? pf[vmap[q]] : (((dummy >> q) & 1u) ? __builtin_huge_val() : 0.0);
+        }
+#pragma unroll
+        for (int r = 0; r < CRW; ++r)
+#pragma unroll
+            for (int j = 0; j < DC; ++j) c2v_old[r][j] = 0.0;
+        int it = 0;
+        bool left_at_0 = false;
+        if (!SIM && A.y0 != nullptr) {  // iteration-0 test of the received hard word (src/bpa.py:20,29)
+            const uint8_t* yf = A.y0 + fr * n;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                const bool one = vmap[q] >= 0 && yf[vmap[q]] != 0;
+                if (q < VRW - 1 || own_last) my_marg[q * 64] = one ? -1.0 : 1.0;
+                xb |= one ? (1u << q) : 0u;
+            }
+            phase_barrier();
+            u64 unsat = 0;
+#pragma unroll
+            for (int r = 0; r < CRW; ++r) {
+                u64 par = 0;
+#pragma unroll
+                for (int j = 0; j < DC; ++j) par ^= __ballot(gat(half_of<CRW * DC>(cn_idx, r * DC + j)) < 0.0);
+                // even dc: a padded check lane reads one marginal dc times -> even parity; odd dc: mask the padded lanes out
+                if constexpr (DC % 2 == 0) unsat |= par; else unsat |= par & cn_active[r];
+            }
+            left_at_0 = early && !any_unsat(unsat != 0);
+            phase_barrier();
+        }
+        if (!left_at_0) {
+            if constexpr (!SIM) {
+#pragma unroll
+                for (int q = 0; q < VRW; ++q)
+                    if (q < VRW - 1 || own_last) my_marg[q * 64] = prior[q];
+            } else if constexpr (VRX > 0) {
+                if (dummy) {
+#pragma unroll
+                    for (int q = 0; q < VRW; ++q)
+                        if ((dummy >> q) & 1u) my_marg[q * 64] = prior[q];  // the certain slot: +inf
+                }
+            }
+            phase_barrier();
+            for (;;) {
+                if (max_iter > 0 && it >= max_iter) break;
+                // ---- check phase (+ syndrome of the previous decisions: sign of the gathered marginals)
+                uint32_t synd = 0;   // min-sum: bit 31 = some owned check is unsatisfied (XOR of IEEE sign bits)
+                u64 synd_mask = 0;   // sum-product: lanes whose check is unsatisfied ((marginal < 0) compares: NaN counts as bit 0)
+                double mg[2][DC];
+#pragma unroll
+                for (int j = 0; j < DC; ++j) mg[0][j] = gat(half_of<CRW * DC>(cn_idx, j));
+                static_for<0, CRW>([&](auto R_) {
+                    constexpr int r = decltype(R_)::value;
+                    if constexpr (r + 1 < CRW) {
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = gat(half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double v[DC];
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) v[j] = mg[r & 1][j] - c2v_old[r][j];
+                    if constexpr (ALG == ALG_MSA) {
+                        double a[DC];
+                        uint32_t vx = 0, mx = 0;  // XOR of the sign words (high dwords); v is never -0.0 (marginals start from +0.0 sums)
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) a[j] = __builtin_fabs(v[j]);
+#pragma unroll
+                        for (int j = 0; j + 2 < DC; j += 3) {  // three inputs per instruction (v_bitop3_b32, truth table 0x96)
+                            vx ^= xor3((uint32_t)__double2hiint(v[j]), (uint32_t)__double2hiint(v[j + 1]), (uint32_t)__double2hiint(v[j + 2]));
+                            mx ^= xor3((uint32_t)__double2hiint(mg[r & 1][j]), (uint32_t)__double2hiint(mg[r & 1][j + 1]), (uint32_t)__double2hiint(mg[r & 1][j + 2]));
+                        }
+#pragma unroll
+                        for (int j = DC - DC % 3; j < DC; ++j) {
+                            vx ^= (uint32_t)__double2hiint(v[j]);
+                            mx ^= (uint32_t)__double2hiint(mg[r & 1][j]);
+                        }
+                        if constexpr (DC % 2 == 0) synd |= mx; else synd |= ((cn_active[r] >> lane) & 1ull) ? mx : 0u;
+                        double mag[DC];
+                        if constexpr (DC == 6) {  // 11 minimum instructions for the six leave-one-out minima
+                            const double s3 = fmin(a[4], a[5]), s2 = fmin(fmin(a[3], a[4]), a[5]), s1 = fmin(a[2], s2);
+                            const double p2 = fmin(a[0], a[1]), p3 = fmin(fmin(a[0], a[1]), a[2]);
+                            mag[0] = fmin(fmin(a[1], a[2]), s2);
+                            mag[1] = fmin(a[0], s1);
+                            mag[2] = fmin(p2, s2);
+                            mag[3] = fmin(p3, s3);
+                            mag[4] = fmin(fmin(p3, a[3]), a[5]);
+                            mag[5] = fmin(fmin(p3, a[3]), a[4]);
+                        } else {  // prefix / suffix minima: the leave-one-out minimum == "second minimum at the first arg-min, first elsewhere"
+                            double pre[DC], suf[DC];
+                            pre[0] = __builtin_huge_val();
+#pragma unroll
+                            for (int j = 1; j < DC; ++j) pre[j] = fmin(pre[j - 1], a[j - 1]);
+                            suf[DC - 1] = __builtin_huge_val();
+#pragma unroll
+                            for (int j = DC - 2; j >= 0; --j) suf[j] = fmin(suf[j + 1], a[j + 1]);
+#pragma unroll
+                            for (int j = 0; j < DC; ++j) mag[j] = fmin(pre[j], suf[j]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) {
+                            const uint32_t sgn = (vx ^ (uint32_t)__double2hiint(v[j])) & 0x80000000u;
+                            const double c = __hiloint2double((int)((uint32_t)__double2hiint(mag[j]) | sgn), __double2loint(mag[j]));
+                            c2v_old[r][j] = c;
+                            my_c2v[(r * DC + j) * 64] = c;
+                        }
+                    } else {
+                        u64 par = 0;
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) par ^= __ballot(mg[r & 1][j] < 0.0);
+                        if constexpr (DC % 2 == 0) synd_mask |= par; else synd_mask |= par & cn_active[r];
+                        cn_spa<DC>(v, DC);  // the streaming kernel's rule, edges in canonical order (see the plan)
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) {
+                            const double c = ((padpos >> (r * DC + j)) & 1ull) ? 0.0 : v[j];
+                            c2v_old[r][j] = c;
+                            my_c2v[(r * DC + j) * 64] = c;
+                        }
+                    }
+                });
+                const bool unsat = any_unsat(ALG == ALG_MSA ? (__ballot((synd & 0x80000000u) != 0u) != 0) : (synd_mask != 0));
+                // it == 0: only the BSC checks the received word itself (src/bpa.py:20,29); in SIM mode marg holds +-llr there
+                if (early && (it > 0 || (SIM && A.sim_channel == CH_BSC)) && !unsat) break;
+                // ---- variable phase: ordered sum from +0.0 (scipy COO), prior last, decision bit
+                xb = 0;
+                auto finish_var = [&](auto Q_, double sn) {
+                    constexpr int q = decltype(Q_)::value;
+                    const double m1 = prior[q] + sn;
+                    if (q < VRW - 1 || own_last) my_marg[q * 64] = m1;
+                    // (m1 < 0).  Min-sum: the sign bit itself -- m1 is never -0.0 (sums start from +0.0) nor NaN for finite priors
+                    if constexpr (ALG == ALG_MSA) xb |= ((uint32_t)__double2hiint(m1) >> 31) << q; else xb |= (m1 < 0.0) ? (1u << q) : 0u;
+                };
+                if constexpr (VRX > 0) {  // wide rounds: DVX gathers per variable (missing edges read the zero double)
+                    double cw[2][DVX];
+#pragma unroll
+                    for (int j = 0; j < DVX; ++j) cw[0][j] = gat(half_of<VNK>(vn_idx, j));
+                    static_for<0, VRX>([&](auto Q_) {
+                        constexpr int q = decltype(Q_)::value;
+                        if constexpr (q + 1 < VRX) {
+#pragma unroll
+                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = gat(half_of<VNK>(vn_idx, (q + 1) * DVX + j));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        double sw = 0.0 + cw[q & 1][0];
+#pragma unroll
+                        for (int j = 1; j < DVX; ++j) sw += cw[q & 1][j];
+                        finish_var(Q_, sw);
+                    });
+                }
+                double cv[2][DV];
+#pragma unroll
+                for (int j = 0; j < DV; ++j) cv[0][j] = gat(half_of<VNK>(vn_idx, VN0 + j));
+                static_for<0, VRN>([&](auto Q_) {
+                    constexpr int q = decltype(Q_)::value;
+                    if constexpr (q + 1 < VRN) {
+#pragma unroll
+                        for (int j = 0; j < DV; ++j) cv[(q + 1) & 1][j] = gat(half_of<VNK>(vn_idx, VN0 + (q + 1) * DV + j));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double sn = 0.0 + cv[q & 1][0];
+#pragma unroll
+                    for (int j = 1; j < DV; ++j) sn += cv[q & 1][j];
+                    finish_var(std::integral_constant<int, VRX + q>{}, sn);
+                });
+                phase_barrier();
+                ++it;
+            }
+        }
+        if (counting) {
+            const unsigned wrong = (A.codeword ? ~xb : xb) & valid;
+            int err = 0;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) err += __popcll(__ballot((wrong >> q) & 1u));
+            if constexpr (NW > 1) {  // channel B of the system row (the sweep loop's last exchange used channel A)
+                if (lane == 0) *sysw(16 + w) = (uint32_t)err;
+                __syncthreads();
+                int sum = lane < NW ? (int)*sysw(16 + (lane & (NW - 1))) : 0;
+#pragma unroll
+                for (int o = NW / 2; o; o >>= 1) sum += __shfl_xor(sum, o);
+                err = sum;
+            }
+            err = __builtin_amdgcn_readfirstlane(err);
+            acc_tot += 1;
+            acc_wec += err > 0;
+            acc_bec += (u64)err;
+            acc_it += (u64)it;
+            const int bin = it < A.hist_bins ? it : A.hist_bins - 1;
+            hist_lane += (lane == bin) ? 1u : 0u;
+        } else {
+            if (w == 0 && lane == 0) A.iters[fr] = it;
+            uint8_t* xf = A.xhat + fr * n;
+#pragma unroll
+            for (int q = 0; q < VRW; ++q)
+                if (vmap[q] >= 0) xf[vmap[q]] = (uint8_t)((xb >> q) & 1u);
+            if (A.soft != nullptr) {  // marginals of the last executed sweep: still in this wave's LDS rows
+                double* sf = reinterpret_cast<double*>(A.soft) + fr * n;
+#pragma unroll
+                for (int q = 0; q < VRW; ++q)
+                    if (vmap[q] >= 0) sf[vmap[q]] = it > 0 ? my_marg[q * 64] : 0.0;
+            }
+        }
+    }
+    if (counting && w == 0) {
+        if (lane == 0) {
+            atomicAdd(&A.counters[0], acc_tot);
+            atomicAdd(&A.counters[1], acc_wec);
+            atomicAdd(&A.counters[2], acc_bec);
+            atomicAdd(&A.counters[3], acc_it);
+        }
+        if (lane < A.hist_bins && hist_lane) atomicAdd(&A.counters[4 + lane], (u64)hist_lane);
+    }
+}
+
+
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, int VRX = 0, int DVX = DV>
+constexpr ShapeEntry shape_entry64() {
+    static_assert(CRW * DC <= 64, "pad-position mask is one 64-bit word");
+    return ShapeEntry{ALG, DC, DV, CRW, VRW, NW, VRX, DVX, (const void*)k_fused_f64<ALG, DC, DV, CRW, VRW, NW, false, VRX, DVX>,
+                      (const void*)k_fused_f64<ALG, DC, DV, CRW, VRW, NW, true, VRX, DVX>, 8};
+}
+
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, int VRX = 0, int DVX = DV>
+constexpr ShapeEntry shape_entry() {
+    return ShapeEntry{ALG, DC, DV, CRW, VRW, NW, VRX, DVX, (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW, false, VRX, DVX>,
+                      (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW, true, VRX, DVX>};
+}
+
+}  // namespace
+}  // namespace ldpc

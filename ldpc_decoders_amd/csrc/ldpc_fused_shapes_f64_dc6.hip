@@ -1,0 +1,20 @@
+// fp64 kernels of the fused backend (the reference's own arithmetic), check degree 6: min-sum and sum-product.
+#include "ldpc_fused_kernels.hpp"
+
+namespace ldpc {
+
+#define LDPC_LLR_ALGS(...) shape_entry64<ALG_MSA, __VA_ARGS__>(), shape_entry64<ALG_SPA, __VA_ARGS__>()
+
+const ShapeEntry* fused_shapes_f64_dc6(int* count) {
+    static const ShapeEntry k[] = {
+        // (3,6)-regular, n <= 1216 (one marginal row reserved).  Two waves per frame (40 KB of LDS per frame, 4 frames per CU) measured
+        // 3 % faster than four (46 KB, 3 frames): 6.66 vs 6.87 ms per 65 536 frames
+        LDPC_LLR_ALGS(6, 3, 5, 10, 2),
+        LDPC_LLR_ALGS(6, 3, 5, 10, 2, 2, 8),  // irregular n <= 1215: two wide variable rounds per wave, short check rows padded
+        LDPC_LLR_ALGS(6, 3, 3, 6, 8),         // (3,6)-regular n <= 3008 (Margulis n = 2640): 96 KB per frame, one frame = 8 waves per CU
+    };
+    *count = (int)(sizeof(k) / sizeof(k[0]));
+    return k;
+}
+
+}  // namespace ldpc

@@ -217,10 +217,12 @@ void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint6
     for (int v = 0; v < n; ++v) L->var_slot[v] = slot_of(vgrp[v], vbank[v]);
     for (int k = 0; k < E; ++k) L->var_pos[k] = vpos(c.edge_var[k], edge_vj[k]);
 
-    // ---- positions inside each check: edge-colour every check group against the variable banks
+    // ---- positions inside each check: edge-colour every check group against the variable banks (unless the order is prescribed)
     std::vector<std::vector<int>> group_checks(NGC);
-    for (int cc = 0; cc < m; ++cc) group_checks[cgrp[cc]].push_back(cc);
-    for (int g = 0; g < NGC; ++g) {
+    if (vr.fixed_edge_order) group_checks.clear();
+    if (!vr.fixed_edge_order)
+        for (int cc = 0; cc < m; ++cc) group_checks[cgrp[cc]].push_back(cc);
+    for (int g = 0; g < (int)group_checks.size(); ++g) {
         std::vector<int> edges;  // edge ids of this group
         for (int cc : group_checks[g])
             for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) edges.push_back(k);
@@ -312,6 +314,7 @@ uint64_t layout_key(const Code& c, int DC, int CR, const VarRounds& vr, int NW) 
     const int32_t hdr[10] = {(int32_t)kPlannerVersion, c.m, c.n, DC, CR, vr.VR, vr.DV, vr.vrx, vr.dvx, NW};
     h = fnv(h, hdr, sizeof(hdr));
     if (vr.reserved) h = fnv(h, &vr.reserved, sizeof(vr.reserved));
+    if (vr.fixed_edge_order) h = fnv(h, "fixed-edge-order", 16);
     h = fnv(h, c.edge_chk.data(), c.edge_chk.size() * sizeof(int32_t));
     h = fnv(h, c.edge_var.data(), c.edge_var.size() * sizeof(int32_t));
     return h;
@@ -334,6 +337,7 @@ bool layout_valid(const Code& c, int DC, int CR, const VarRounds& vr, const Fuse
         for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) {
             const int p = L.edge_pos[k];
             if (p < 0 || p >= DC || ((mask >> p) & 1u)) return false;
+            if (vr.fixed_edge_order && p != k - c.row_ptr[cc]) return false;
             mask |= 1u << p;
         }
     }

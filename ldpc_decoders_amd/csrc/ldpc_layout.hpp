@@ -41,6 +41,7 @@ struct FusedLayout {
 struct VarRounds {
     int VR = 0, DV = 0, vrx = 0, dvx = 0;
     int nw = 1, reserved = 0;
+    bool fixed_edge_order = false;  // every check keeps its edges in ascending-variable order (fp64 sum-product: the row sum of logs is order dependent)
     int vrw() const { return VR / nw; }
     int per_wave() const { return vrx * dvx + (vrw() - vrx) * DV; }
     int width(int q) const { return (q % vrw()) < vrx ? dvx : DV; }

@@ -1,0 +1,155 @@
+"""GPU parity tests of the LDS-resident (fused) kernels beyond check degree 6: the reference's generators take any (l, r)
+(src/codes.py:108-120,165-171) and any rho (src/ldpc.py:149-155, check degree rho + 1).  Generated (3,4)-, (4,8)-, (3,5)-regular and
+rho = x^4 / x^6 irregular codes, fp32 and fp64, against the C oracle (min-sum, erasure decoder: bit-exact) and the streaming kernels."""
+import numpy as np
+import pytest
+
+import bp_oracle as O
+import c_oracle as C
+
+pytestmark = pytest.mark.gpu
+
+CODES = {
+    "reg_3_4": lambda codes: codes.rand_reg_ldpc(1200, 3, 4, np.random.RandomState(11)),
+    "reg_4_8": lambda codes: codes.rand_reg_ldpc(1200, 4, 8, np.random.RandomState(12)),
+    "reg_3_5": lambda codes: codes.rand_reg_ldpc(1200, 3, 5, np.random.RandomState(13)),
+    "rho_x4": lambda codes: codes.rand_irregular_ldpc(1200, codes.LAMBDA_HALF_RATE[4], 5, np.random.RandomState(14)),
+    "rho_x6": lambda codes: codes.rand_irregular_ldpc(1200, codes.LAMBDA_HALF_RATE[6], 7, np.random.RandomState(15)),
+}
+SNR = {"reg_3_4": -1.0, "reg_4_8": 2.4, "reg_3_5": 0.6, "rho_x4": 1.6, "rho_x6": 1.4}  # around each code's waterfall: a mix of exits
+_cache = {}
+
+
+def _code(name):
+    from ldpc_decoders_amd import codes
+
+    if name not in _cache:
+        code = CODES[name](codes)
+        _cache[name] = (O.Edges(code.m, code.n, code.edge_chk, code.edge_var), code)
+    return _cache[name]
+
+
+def _priors(g, snr, B, seed):
+    rng = np.random.RandomState(seed)
+    return O.biawgn_priors(-1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(snr)), (B, g.n)), snr)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("name", sorted(CODES))
+def test_min_sum_bit_exact_on_the_fused_kernels(name, prec):
+    from ldpc_decoders_amd import bpa
+
+    g, code = _code(name)
+    dt = np.float64 if prec == "f64" else np.float32
+    dec = bpa.MSA(code, max_iter=50, precision=prec, backend="fused")
+    fi = dec.handle.fused_info()
+    assert fi["waves_per_frame"] == 2
+    for B, seed in ((5, 1), (257, 2)):
+        pri = _priors(g, SNR[name], B, seed).astype(dt)
+        xhat, iters = dec.decode_batch(None, pri)
+        assert dec.handle.last_stats()[0] == "fused"
+        xo, io = C.bp_decode(g, "MSA", None, pri, 50, dtype=dt)
+        assert (xhat == xo).all() and (iters == io).all()
+    assert len(np.unique(io)) > 3  # early exits and capped frames both present
+    print("%s %s: %d checks of degree %s, variable degrees up to %d, LDS %d B/frame, %.0f conflict cycles/sweep (identity %.0f)" % (
+        name, prec, g.m, sorted(set(code.row_degrees().tolist())), code.col_degrees().max(), fi["lds_bytes_per_frame"], fi["conflict_cycles_planned"],
+        fi["conflict_cycles_identity"]))
+
+
+@pytest.mark.parametrize("name", sorted(CODES))
+def test_erasure_decoder_exact_on_the_fused_kernels(name):
+    import torch
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    g, code = _code(name)
+    h = DecoderHandle(code, "BEC", "f32", "fused")
+    eps = {"reg_3_4": 0.62, "reg_4_8": 0.36, "reg_3_5": 0.48, "rho_x4": 0.42, "rho_x6": 0.44}[name]
+    _, y = h.channel_device("bec", eps, 0, 5, 1, 0, 700)
+    for mi in (50, 3):
+        xh, it = h.decode_device(None, y, mi)
+        xo, io = C.bec_decode(g, y.cpu().numpy(), mi)
+        assert (xh.cpu().numpy() == xo).all() and (it.cpu().numpy() == io).all()
+    cnt = torch.zeros(4 + 51, dtype=torch.int64, device="cuda")
+    h.simulate("bec", eps, 0, 5, 1, 0, 700, 50, cnt, hist_bins=51)  # channel + decode + count in one kernel
+    xo, io = C.bec_decode(g, y.cpu().numpy(), 50)
+    err = (xo != 0).sum(axis=1)
+    assert cnt[:4].cpu().tolist() == [700, int((err > 0).sum()), int(err.sum()), int(io.sum())]
+    assert 0 < (err > 0).sum() < 700
+
+
+@pytest.mark.parametrize("name", sorted(CODES) + ["1200_3_6_rand_ldpc_1", "1200_rho_x5_rand_ldpc_5", "margulis"])
+def test_fp64_sum_product_on_the_lds_equals_the_streaming_kernel(name):
+    # the reference's sum-product arithmetic (src/bpa.py:66-75 verbatim) through the same device function on both backends, the row
+    # sum of logs in the reference's edge order on both: decisions, iteration counts AND marginals bit-identical
+    import torch
+    from helpers import golden_edges
+    from ldpc_decoders_amd import bpa
+    from ldpc_decoders_amd.codes import Code
+
+    if name in CODES:
+        g, code = _code(name)
+        snr = SNR[name]
+    else:
+        g = golden_edges(name)
+        code = Code.from_edges(g.m, g.n, g.chk, g.var)
+        snr = 1.8
+    pri = torch.from_numpy(_priors(g, snr, 150, 9)).cuda()
+    outs = []
+    for backend in ("stream", "fused"):
+        dec = bpa.SPA(code, max_iter=40, precision="f64", backend=backend)
+        x, it, mg = dec.handle.decode_soft_device(pri, None, 40)
+        assert dec.handle.last_stats()[0] == backend
+        outs.append((x.cpu().numpy(), it.cpu().numpy(), mg.cpu().numpy()))
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+    same = (outs[0][2] == outs[1][2]) | (np.isnan(outs[0][2]) & np.isnan(outs[1][2]))
+    assert same.all()
+    assert len(np.unique(outs[0][1])) > 3
+
+
+@pytest.mark.parametrize("name", sorted(CODES))
+def test_fp32_sum_product_on_the_fused_kernels(name):
+    # fp32 sum-product (phi-domain rule): decisions against the fp64 statement of the same rule (numpy oracle) -- >= 95 % of frames
+    # identical, as for the degree-6 shapes (tests/test_gpu_parity.py::test_spa_fp32_decisions) -- and against the streaming kernel
+    from ldpc_decoders_amd import bpa
+
+    g, code = _code(name)
+    pri = _priors(g, SNR[name], 48, 17)
+    dec = bpa.SPA(code, max_iter=30, precision="f32", backend="fused")
+    xhat, iters = dec.decode_batch(None, pri.astype(np.float32))
+    xo, io = O.bp_decode(g, "SPA_PHI", -pri, pri, 30)  # (y only matters for the iteration-0 test: real valued, never passes)
+    same = (xhat == xo).all(axis=1)
+    xs, its = bpa.SPA(code, max_iter=30, precision="f32", backend="stream").decode_batch(None, pri.astype(np.float32))
+    same_s = (xhat == xs).all(axis=1)
+    print("%s: fused fp32 sum-product == fp64 phi oracle on %.1f %% of frames, == streaming kernel on %.1f %%" % (name, 100 * same.mean(), 100 * same_s.mean()))
+    assert same.mean() >= 0.95 and same_s.mean() >= 0.95
+    assert (np.abs(iters - io) <= 1)[io < 30].mean() >= 0.9
+
+
+@pytest.mark.parametrize("alg,channel,param", [("MSA", "biawgn", 2.0), ("MSA", "bsc", 0.05), ("SPA", "biawgn", 1.6), ("SPA", "bsc", 0.07)])
+@pytest.mark.parametrize("name", ["1200_3_6_rand_ldpc_1", "1200_rho_x5_rand_ldpc_5", "reg_4_8", "rho_x6"])
+def test_fp64_in_kernel_channel_equals_the_channel_kernel(name, alg, channel, param):
+    # fp64 simulate = ONE kernel (Philox noise -> LLR -> decode -> count, priors never in HBM).  Its counters must equal the
+    # composition channel kernel -> HBM -> ldpc_decode -> ldpc_count_errors frame for frame (same inline noise functions).
+    import torch
+    from helpers import golden_edges
+    from ldpc_decoders_amd import _lib
+    from ldpc_decoders_amd._device import DecoderHandle
+    from ldpc_decoders_amd.codes import Code
+
+    if name in CODES:
+        g, code = _code(name)
+    else:
+        g = golden_edges(name)
+        code = Code.from_edges(g.m, g.n, g.chk, g.var)
+    h = DecoderHandle(code, alg, "f64", "fused")
+    B, frame0 = 1500, 123456
+    for cw in (0, 1):
+        cnt = torch.zeros(4 + 41, dtype=torch.int64, device="cuda")
+        h.simulate(channel, param, cw, 99, 3, frame0, B, 40, cnt, hist_bins=41)
+        pri, y = h.channel_device(channel, param, cw, 99, 3, frame0, B)
+        xh, it = h.decode_device(pri, y, 40)
+        ref = torch.zeros(4 + 41, dtype=torch.int64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.load().ldpc_count_errors(xh.data_ptr(), None, cw, it.data_ptr(), B, g.n, 41, ref.data_ptr(), st))
+        assert cnt.cpu().tolist() == ref.cpu().tolist()
+        assert cnt[0].item() == B and cnt[3].item() > B

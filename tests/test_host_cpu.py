@@ -216,3 +216,30 @@ def test_exact_mode_leaves_the_random_stream_where_the_reference_does(n):
         outs.append((pts, np.random.normal()))
     assert outs[0] == outs[1] == outs[2]
     assert outs[0][0][0]["tot"] % 5 != 0 or outs[0][0][1]["tot"] % 5 != 0  # the stop really fell inside a chunk
+
+
+def test_irregular_ensembles_match_the_reference_node_counts():
+    # tests/golden/irregular_ensembles.json: lambda(x) of ldpc.solve_dist and int(L_i n) of gen_L_R for rho = x^4, x^5, x^6
+    # (captured from the reference by oracle/make_goldens_gen.py): 742/211/107/58/80 for the rho = x^5, n = 1200 ensemble
+    from ldpc_decoders_amd import codes
+
+    with open(os.path.join(GOLDEN, "irregular_ensembles.json")) as fp:
+        want = json.load(fp)
+    for rho in (4, 5, 6):
+        lam = codes.LAMBDA_HALF_RATE[rho]
+        ref = {int(k): v for k, v in want[str(rho)]["lambda_edge"].items()}
+        assert sorted(lam) == sorted(ref) and all(abs(lam[d] - ref[d]) < 1e-4 for d in lam)
+        for n in (1200, 10000):
+            counts, extra = codes.irregular_degree_counts(n, lam, rho + 1)
+            base = dict(counts)
+            for d in extra:
+                base[d] -= 1
+            ref_counts = {int(k): v for k, v in want[str(rho)]["node_counts"][str(n)].items()}
+            if (rho, n) == (5, 10000):  # the published 4-digit lambda of rho = x^5 moves a handful of nodes at n = 10 000
+                assert sum(abs(base[d] - ref_counts[d]) for d in base) <= 6
+            else:
+                assert base == ref_counts
+            assert sum(counts.values()) == n and sum(d * c for d, c in counts.items()) % (rho + 1) == 0
+    assert {int(k): v for k, v in want["5"]["node_counts"]["1200"].items()} == {2: 742, 3: 211, 4: 107, 7: 58, 8: 80}
+    code = codes.rand_irregular_ldpc(1200, codes.LAMBDA_HALF_RATE[6], 7, np.random.RandomState(15))
+    assert code.n == 1200 and code.row_degrees().max() == 7 and code.col_degrees().max() <= 16
