@@ -111,7 +111,7 @@ for prec in ("f64", "f32"):
                     cus = info.get("cus", 256)
                     clk = None
                     if dur_s > 0 and "GRBM_GUI_ACTIVE" in v:
-                        clk = sum(v["GRBM_GUI_ACTIVE"]) / dur_s
+                        clk = sum(v["GRBM_GUI_ACTIVE"]) / 8 / dur_s  # the counter is summed over the 8 XCDs
                     elif dur_s > 0 and "SQ_BUSY_CYCLES" in v:
                         clk = sum(v["SQ_BUSY_CYCLES"]) / 32 / dur_s  # summed over the 32 shader engines
                     entry = {"kernel": k, "launches": nl, "frame_sweeps": fs, "workload": "%s %s %.1f dB batch %d" % (info["code"], info["alg"], info["snr"], info["batch"]),
@@ -121,7 +121,7 @@ for prec in ("f64", "f32"):
                              "insts_valu_per_frame_sweep": round(sum(v.get("SQ_INSTS_VALU", [0])) / fs, 2),
                              "kernel_ms_per_launch_in_pmc_pass": round(1e3 * dur_s / max(nl, 1), 4) if dur_s else None,
                              "effective_clock_hz": round(clk, 0) if clk else None,
-                             "effective_clock_from": "GRBM_GUI_ACTIVE / kernel time" if (dur_s > 0 and "GRBM_GUI_ACTIVE" in v) else "SQ_BUSY_CYCLES / 32 SEs / kernel time",
+                             "effective_clock_from": "GRBM_GUI_ACTIVE / 8 XCDs / kernel time" if (dur_s > 0 and "GRBM_GUI_ACTIVE" in v) else "SQ_BUSY_CYCLES / 32 SEs / kernel time",
                              "lds_pipe_busy_in_pmc_pass": round(sum(v["SQ_LDS_IDX_ACTIVE"]) / (dur_s * clk * cus), 4) if (dur_s and clk) else None}
                     lds["%s:%s" % (prec, k)] = entry
                     out.append("\nLDS roofline inputs: `%s`" % json.dumps(entry))
