@@ -58,11 +58,24 @@ int ldpc_decoder_create(ldpc_code_t code, int alg, int dtype, int backend, ldpc_
 int ldpc_decoder_destroy(ldpc_decoder_t dec);
 /* backend actually used by the last decode (LDPC_BACKEND_*) and the number of sweeps the batch ran */
 int ldpc_decoder_last_stats(ldpc_decoder_t dec, int* backend, int* sweeps);
+/* streaming backend: how often the last decode gathered its live frames into dense tiles (per-frame early termination,
+ * src/bpa.py:28-29: a frame that has left costs nothing; tiles of 64 frames are re-formed from the live ones) */
+int ldpc_decoder_last_repacks(ldpc_decoder_t dec, int* repacks);
 
 /* Fused-backend plan of this decoder: out8 = {wavefronts per frame (0 = fused backend unavailable), conflict-free LDS gather cycles per sweep, extra bank-conflict
  * cycles with the trivial placement, extra cycles with the planned placement, resident waves per CU, LDS bytes per
  * frame, check rounds, variable rounds}. */
 int ldpc_decoder_fused_info(ldpc_decoder_t dec, double* out8);
+
+/* Host-only (no GPU needed): the LDS layout plan the fused backend would use for this (graph, algorithm, arithmetic) -- chosen
+ * kernel shape, bank-conflict-minimising placement of checks / variables / edge positions (csrc/ldpc_layout.hpp) -- annealed with
+ * `moves` moves (<= 0: the default short run) and stored as <key>.plan in out_dir (NULL: not stored).  Decoders find such files in
+ * $LDPC_FUSED_PLAN_DIR, in <package>/plans and in the per-user cache.  No upstream counterpart (the placement is a property of this
+ * implementation; the graph arguments are those of ldpc_code_create, i.e. BPA.__init__'s edge lists, src/bpa.py:9-15).
+ * info4 = {wavefronts per frame (0: no fused shape for this graph), conflict-free LDS gather cycles per sweep, extra bank-conflict
+ * cycles of the trivial placement, extra cycles of the plan}. */
+int ldpc_plan_layout(int32_t m, int32_t n, int64_t E, const int32_t* edge_chk, const int32_t* edge_var, int alg, int dtype,
+                     int64_t moves, const char* out_dir, double* info4);
 
 /* Per-kernel timing for roofline reports: when enabled, decode calls bracket their dominant kernels with HIP events
  * recorded ON THE DECODE STREAM and accumulate elapsed milliseconds / launch counts per kernel class:

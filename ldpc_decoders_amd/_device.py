@@ -178,6 +178,12 @@ class DecoderHandle:
         _lib.check(_lib.load().ldpc_decoder_last_stats(self.h, ctypes.byref(b), ctypes.byref(s)))
         return _lib.BACKEND_NAME.get(b.value, "?"), s.value
 
+    def last_repacks(self):
+        """Streaming backend: how often the last decode re-formed its tiles from the live frames."""
+        r = ctypes.c_int(0)
+        _lib.check(_lib.load().ldpc_decoder_last_repacks(self.h, ctypes.byref(r)))
+        return r.value
+
 
 class MlHandle:
     """Codebook of a short code resident in HBM + the exhaustive-search kernels (``ldpc_ml_*``)."""

@@ -32,7 +32,10 @@ SIGNATURES = {
     "ldpc_decoder_create": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_P)]),
     "ldpc_decoder_destroy": (_c.c_int, [_P]),
     "ldpc_decoder_last_stats": (_c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    "ldpc_decoder_last_repacks": (_c.c_int, [_P, _c.POINTER(_c.c_int)]),
     "ldpc_decoder_fused_info": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),
+    "ldpc_plan_layout": (_c.c_int, [_c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_char_p,
+                                    _c.POINTER(_c.c_double)]),
     "ldpc_decoder_profile": (_c.c_int, [_P, _c.c_int]),
     "ldpc_decoder_profile_read": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.c_int]),
     "ldpc_decode": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P, _P]),

@@ -80,29 +80,12 @@ int pick_backend(Decoder* d) {
     return BK_STREAM;
 }
 }  // namespace
-}  // namespace ldpc
 
-using namespace ldpc;
-
-extern "C" {
-
-const char* ldpc_last_error(void) { return last_error(); }
-int ldpc_abi_version(void) { return 1; }
-
-int ldpc_device_count(int* count) {
-    if (!count) return LDPC_E_ARG;
-    LDPC_HIP_TRY(hipGetDeviceCount(count));
-    return LDPC_OK;
-}
-
-int ldpc_code_create(int device, int32_t m, int32_t n, int64_t E, const int32_t* chk, const int32_t* var, ldpc_code_t* out) {
-    if (!out || !chk || !var || m <= 0 || n <= 0 || E <= 0 || E > (int64_t)1 << 30) {
-        set_error("ldpc_code_create: bad arguments (m=%d n=%d E=%lld)", m, n, (long long)E);
+int code_build_host(int32_t m, int32_t n, int64_t E, const int32_t* chk, const int32_t* var, Code* c) {
+    if (!chk || !var || m <= 0 || n <= 0 || E <= 0 || E > (int64_t)1 << 30) {
+        set_error("bad graph arguments (m=%d n=%d E=%lld)", m, n, (long long)E);
         return LDPC_E_ARG;
     }
-    Code* c = new (std::nothrow) Code();
-    if (!c) return LDPC_E_NOMEM;
-    c->device = device;
     c->m = m;
     c->n = n;
     c->E = E;
@@ -113,12 +96,10 @@ int ldpc_code_create(int device, int32_t m, int32_t n, int64_t E, const int32_t*
     for (int64_t k = 0; k < E; ++k) {
         if (chk[k] < 0 || chk[k] >= m || var[k] < 0 || var[k] >= n) {
             set_error("edge %lld = (%d,%d) outside a %dx%d matrix", (long long)k, chk[k], var[k], m, n);
-            delete c;
             return LDPC_E_GRAPH;
         }
         if (k && (chk[k] < chk[k - 1] || (chk[k] == chk[k - 1] && var[k] <= var[k - 1]))) {
             set_error("edge list must be strictly row-major sorted (np.where order); violated at edge %lld", (long long)k);
-            delete c;
             return LDPC_E_GRAPH;
         }
         c->row_ptr[chk[k] + 1]++;
@@ -139,9 +120,36 @@ int ldpc_code_create(int device, int32_t m, int32_t n, int64_t E, const int32_t*
         c->col_ptr[i + 1] += c->col_ptr[i];
     }
     c->col_edge.assign((size_t)E, 0);
-    {
-        std::vector<int32_t> fill(c->col_ptr.begin(), c->col_ptr.end() - 1);
-        for (int64_t k = 0; k < E; ++k) c->col_edge[fill[var[k]]++] = (int32_t)k;  // ascending edge order per variable
+    std::vector<int32_t> fill(c->col_ptr.begin(), c->col_ptr.end() - 1);
+    for (int64_t k = 0; k < E; ++k) c->col_edge[fill[var[k]]++] = (int32_t)k;  // ascending edge order per variable
+    return LDPC_OK;
+}
+}  // namespace ldpc
+
+using namespace ldpc;
+
+extern "C" {
+
+const char* ldpc_last_error(void) { return last_error(); }
+int ldpc_abi_version(void) { return 1; }
+
+int ldpc_device_count(int* count) {
+    if (!count) return LDPC_E_ARG;
+    LDPC_HIP_TRY(hipGetDeviceCount(count));
+    return LDPC_OK;
+}
+
+int ldpc_code_create(int device, int32_t m, int32_t n, int64_t E, const int32_t* chk, const int32_t* var, ldpc_code_t* out) {
+    if (!out) {
+        set_error("ldpc_code_create: out is null");
+        return LDPC_E_ARG;
+    }
+    Code* c = new (std::nothrow) Code();
+    if (!c) return LDPC_E_NOMEM;
+    c->device = device;
+    if (int rc0 = code_build_host(m, n, E, chk, var, c)) {
+        delete c;
+        return rc0;
     }
     int rc = LDPC_OK;
     hipError_t e = hipSetDevice(device);
@@ -181,6 +189,17 @@ int ldpc_code_info(ldpc_code_t h, int32_t* m, int32_t* n, int64_t* E, int32_t* m
     return LDPC_OK;
 }
 
+int ldpc_plan_layout(int32_t m, int32_t n, int64_t E, const int32_t* chk, const int32_t* var, int alg, int dtype, int64_t moves,
+                     const char* out_dir, double* info4) {
+    if (!info4 || alg < 0 || alg > 2 || dtype < 0 || dtype > 1) {
+        set_error("ldpc_plan_layout: bad arguments (alg=%d dtype=%d)", alg, dtype);
+        return LDPC_E_ARG;
+    }
+    Code c;
+    LDPC_TRY(code_build_host(m, n, E, chk, var, &c));
+    return fused_plan_host(&c, alg, dtype, (long)moves, out_dir, info4);
+}
+
 int ldpc_decoder_create(ldpc_code_t code, int alg, int dtype, int backend, ldpc_decoder_t* out) {
     if (!code || !out || alg < 0 || alg > 2 || dtype < 0 || dtype > 1 || backend < 0 || backend > 2) {
         set_error("ldpc_decoder_create: bad arguments (alg=%d dtype=%d backend=%d)", alg, dtype, backend);
@@ -218,12 +237,19 @@ int ldpc_decoder_destroy(ldpc_decoder_t h) {
     if (!d) return LDPC_OK;
     (void)hipSetDevice(d->code->device);
     fused_plan_destroy(d);
-    for (DevBuf* b : {&d->msg, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->h_in, &d->h_y0, &d->h_out,
+    for (DevBuf* b : {&d->msg, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->msg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap, &d->fmap2, &d->rbase, &d->h_in, &d->h_y0, &d->h_out,
                       &d->h_iters})
         b->release();
     if (d->pinned) (void)hipHostFree(d->pinned);
     for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
     delete d;
+    return LDPC_OK;
+}
+
+int ldpc_decoder_last_repacks(ldpc_decoder_t h, int* repacks) {
+    Decoder* d = (Decoder*)h;
+    if (!d || !repacks) return LDPC_E_ARG;
+    *repacks = d->last_backend == BK_STREAM ? d->last_repacks : 0;
     return LDPC_OK;
 }
 

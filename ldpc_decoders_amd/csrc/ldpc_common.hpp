@@ -67,6 +67,9 @@ struct Code {
     std::vector<int32_t> row_ptr, edge_var, edge_chk, col_ptr, col_edge;
 };
 
+// host part of ldpc_code_create: validates the edge list and fills the host mirrors (no device call)
+int code_build_host(int32_t m, int32_t n, int64_t E, const int32_t* chk, const int32_t* var, Code* c);
+
 // Growable device buffer owned by a decoder (workspace is kept between calls).
 struct DevBuf {
     void* p = nullptr;
@@ -82,6 +85,7 @@ struct Decoder {
     int alg = ALG_MSA, dtype = DT_F32, backend = BK_AUTO;
     // streaming workspace
     DevBuf msg, prior, xbits, xera, live, flags, scratch;
+    DevBuf msg2, prior2, xbits2, live2, fmap, fmap2, rbase;  // second state set + frame maps of the early-termination repack
     // fused backend
     FusedPlan* fused = nullptr;
     // staging used by the *_host entry points
@@ -95,6 +99,7 @@ struct Decoder {
     // statistics of the last decode call
     int last_sweeps = 0;
     int last_backend = BK_STREAM;
+    int last_repacks = 0;  // frame repacks of the last streaming decode
 };
 
 // event-pair bookkeeping used when Decoder::profile is set
@@ -110,6 +115,7 @@ int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, 
                   uint8_t* xhat, int32_t* iters, void* soft_out, hipStream_t st);
 
 int fused_plan_create(Decoder* d);
+int fused_plan_host(const Code* c, int alg, int dtype, long moves, const char* out_dir, double* info4);  // host only, no device
 void fused_plan_destroy(Decoder* d);
 bool fused_supported(const Decoder* d);
 bool fused_simulate_supported(const Decoder* d, int channel, double param, int hist_bins);

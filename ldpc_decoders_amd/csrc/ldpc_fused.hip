@@ -1,6 +1,8 @@
 // Fused on-chip backend, host side: chooses a kernel shape for a (code, algorithm, arithmetic), plans the LDS layout, builds the
 // gather tables and launches.  The kernels are in ldpc_fused_kernels.hpp, instantiated by the ldpc_fused_shapes_*.hip units.
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -59,7 +61,28 @@ const std::vector<ShapeEntry>& all_shapes() {
 
 }  // namespace
 
-// directories searched for stored layout plans: $LDPC_FUSED_PLAN_DIR (colon-separated), then <package>/plans next to csrc/
+// per-user plan cache: $XDG_CACHE_HOME/ldpc_decoders_amd/plans or ~/.cache/ldpc_decoders_amd/plans ("" if neither variable is set)
+static std::string user_plan_dir() {
+    if (const char* x = std::getenv("XDG_CACHE_HOME"))
+        if (*x) return std::string(x) + "/ldpc_decoders_amd/plans";
+    if (const char* h = std::getenv("HOME"))
+        if (*h) return std::string(h) + "/.cache/ldpc_decoders_amd/plans";
+    return std::string();
+}
+
+// where a freshly annealed plan is kept: $LDPC_FUSED_PLAN_SAVE ("none" = nowhere), by default the per-user cache -- so the
+// second construction of a decoder for the same (code, shape) finds its plan instead of annealing again
+static std::string plan_save_dir() {
+    if (const char* e = std::getenv("LDPC_FUSED_PLAN_SAVE")) return std::string(e) == "none" ? std::string() : std::string(e);
+    return user_plan_dir();
+}
+
+static void make_dirs(const std::string& path) {
+    for (size_t i = 1; i <= path.size(); ++i)
+        if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0777);
+}
+
+// directories searched for stored layout plans: $LDPC_FUSED_PLAN_DIR (colon-separated), the per-user cache, then <package>/plans next to csrc/
 static std::vector<std::string> plan_dirs() {
     std::vector<std::string> dirs;
     if (const char* e = std::getenv("LDPC_FUSED_PLAN_DIR")) {
@@ -78,8 +101,10 @@ static std::vector<std::string> plan_dirs() {
         std::string lib(info.dli_fname);
         const size_t slash = lib.rfind('/');
         const std::string here = slash == std::string::npos ? std::string(".") : lib.substr(0, slash);
-        dirs.push_back(here + "/../plans");
+        dirs.push_back(here + "/../plans");  // shipped plans (long annealing runs) before the user's own short ones
     }
+    const std::string user = user_plan_dir();
+    if (!user.empty()) dirs.push_back(user);
     return dirs;
 }
 
@@ -100,27 +125,32 @@ int fused_info(const Decoder* d, double* out8) {
     return LDPC_OK;
 }
 
-int fused_plan_create(Decoder* d) {
-    const Code* c = d->code;
-    d->fused = new FusedPlan();
-    FusedPlan* p = d->fused;
+namespace {
+
+// The kernel shape the fused backend uses for (code, algorithm, arithmetic), or -1 -- host-only logic, no device needed.
+struct ShapeChoice {
+    int si = -1;
+    VarRounds vr;
+    bool SYS = false;
+    int esz = 4;
+};
+
+ShapeChoice choose_shape(const Code* c, int alg, int dtype) {
+    ShapeChoice out;
     // fp64 message arithmetic (min-sum, sum-product): the 8-byte kernels; the erasure decoder is integer valued, one kernel family
-    const int want_esz = (d->alg != ALG_BEC && d->dtype == DT_F64) ? 8 : 4;
-    // fp64 sum-product sums log|tanh| over a row in the reference's order (ascending variable): its plans keep the edge order
-    const bool fixed_order = d->alg == ALG_SPA && d->dtype == DT_F64;
+    const int want_esz = (alg != ALG_BEC && dtype == DT_F64) ? 8 : 4;
     const bool full_dv = c->min_dv == c->max_dv;  // every variable has all its DV edges: no zero row needed
     const bool short_rows = c->min_dc != c->max_dc;
-    if (c->min_dc < 1) return LDPC_OK;
+    if (c->min_dc < 1) return out;
     int force_nw = 0;
     if (const char* e = std::getenv("LDPC_FUSED_NW")) force_nw = atoi(e);
-    int si = -1;
     const std::vector<ShapeEntry>& kShapes = all_shapes();
-    for (int i = 0; i < (int)kShapes.size() && si < 0; ++i) {
+    for (int i = 0; i < (int)kShapes.size() && out.si < 0; ++i) {
         const ShapeEntry& s = kShapes[i];
         const int CR = s.CRW * s.NW, VR = s.VRW * s.NW;
-        const bool big = s.NW > 4 || (s.NW > 1 && s.VRX > 0) || s.esz == 8;  // shapes with a system row: one row of variable slots is reserved
+        const bool big = s.NW > 4 || (s.NW > 1 && s.VRX > 0) || s.esz == 8;  // shapes with a system row: (half) a row of variable slots is reserved
         if (s.esz != want_esz) continue;
-        if (s.alg != d->alg || c->max_dc != s.DC || c->m > CR * 64 || c->n + (short_rows ? 1 : 0) > (VR - (big ? 1 : 0)) * 64) continue;
+        if (s.alg != alg || c->max_dc != s.DC || c->m > CR * 64 || c->n + (short_rows ? 1 : 0) > VR * 64 - (big ? (s.esz == 8 ? 32 : 64) : 0)) continue;
         if (force_nw && s.NW != force_nw) continue;
         if (s.VRX == 0) {
             if (short_rows || c->max_dv > s.DV) continue;
@@ -130,19 +160,82 @@ int fused_plan_create(Decoder* d) {
             if (c->max_dv > s.DVX || wide > s.VRX * s.NW * 64) continue;
         }
         if (s.NW > 1 && !big && (!full_dv || c->max_dv != s.DV || CR * 64 - c->m < s.NW)) continue;  // needs padded check slots for the hand-off
-        si = i;
+        out.si = i;
     }
+    if (out.si < 0) return out;
+    const ShapeEntry& shape = kShapes[out.si];
+    out.esz = shape.esz;
+    out.SYS = shape.NW > 4 || (shape.NW > 1 && shape.VRX > 0) || shape.esz == 8;  // system row (see the kernels)
+    VarRounds& vr = out.vr;
+    vr.VR = shape.VRW * shape.NW; vr.DV = shape.DV; vr.vrx = shape.VRX; vr.dvx = shape.DVX; vr.nw = shape.NW; vr.reserved = out.SYS ? 1 : 0;
+    vr.reserved_half = shape.esz == 8;  // the fp64 kernels' system words (36 dwords) fit the upper half of the last marginal row
+    // fp64 sum-product sums log|tanh| over a row in the reference's order (ascending variable): its plans keep the edge order
+    vr.fixed_edge_order = alg == ALG_SPA && dtype == DT_F64;
+    return out;
+}
+
+// Layout of a chosen shape: a stored plan (a long annealing run done once, ldpc_layout.hpp "plan store") or an annealing run now
+// (`moves` <= 0: $LDPC_FUSED_PLAN_MOVES / $LDPC_FUSED_PLAN_MS / the default), which is then kept in `save_dir` (if not empty).
+bool obtain_layout(const Code* c, const ShapeChoice& ch, bool use_store, long moves, const std::string& save_dir, FusedLayout* L) {
+    const ShapeEntry& shape = all_shapes()[ch.si];
+    const int CR = shape.CRW * shape.NW;
+    const uint64_t key = layout_key(*c, shape.DC, CR, ch.vr, shape.NW);
+    char name[40];
+    snprintf(name, sizeof(name), "%016llx.plan", (unsigned long long)key);
+    if (use_store)
+        for (const std::string& dir : plan_dirs())
+            if (layout_load(dir + "/" + name, key, *c, shape.DC, CR, ch.vr, L)) return true;
+    if (moves <= 0) {
+        moves = kDefaultPlanMoves;
+        if (const char* e = std::getenv("LDPC_FUSED_PLAN_MOVES")) moves = atol(e);
+        else if (const char* ms = std::getenv("LDPC_FUSED_PLAN_MS")) moves = (long)(atof(ms) * 1700.0);
+    }
+    plan_fused_layout(*c, shape.DC, CR, ch.vr, 0x1200u, moves, L);
+    if (!save_dir.empty()) {
+        make_dirs(save_dir);
+        const std::string tmp = save_dir + "/." + name + "." + std::to_string((long)getpid());
+        if (layout_save(tmp, key, *c, *L)) (void)rename(tmp.c_str(), (save_dir + "/" + name).c_str());  // atomic: readers never see half a file
+    }
+    return false;
+}
+
+}  // namespace
+
+// Host-only planning (no GPU): which shape the fused backend would use and its layout plan, annealed with `moves` moves and stored
+// in `out_dir` -- what tools/plan_codes.py calls to produce the shipped plans.  info4 = {waves per frame (0: no fused shape),
+// conflict-free gather cycles, extra cycles of the trivial placement, extra cycles of the plan}.
+int fused_plan_host(const Code* c, int alg, int dtype, long moves, const char* out_dir, double* info4) {
+    for (int i = 0; i < 4; ++i) info4[i] = 0;
+    const ShapeChoice ch = choose_shape(c, alg, dtype);
+    if (ch.si < 0) return LDPC_OK;
+    FusedLayout L;
+    (void)obtain_layout(c, ch, false, moves, out_dir ? std::string(out_dir) : std::string(), &L);
+    info4[0] = all_shapes()[ch.si].NW;
+    info4[1] = L.base_cycles;
+    info4[2] = L.extra_cycles_identity;
+    info4[3] = L.extra_cycles_planned;
+    return LDPC_OK;
+}
+
+int fused_plan_create(Decoder* d) {
+    const Code* c = d->code;
+    d->fused = new FusedPlan();
+    FusedPlan* p = d->fused;
+    const bool full_dv = c->min_dv == c->max_dv;
+    const bool short_rows = c->min_dc != c->max_dc;
+    (void)full_dv;
+    const ShapeChoice ch = choose_shape(c, d->alg, d->dtype);
+    const int si = ch.si;
     if (si < 0) return LDPC_OK;
+    const std::vector<ShapeEntry>& kShapes = all_shapes();
     const ShapeEntry& shape = kShapes[si];
     const int DC = shape.DC, DV = shape.DV, NW = shape.NW, CRW = shape.CRW, VRW = shape.VRW;
     const int CR = CRW * NW, VR = VRW * NW, NPAD = VR * 64;
-    VarRounds vr;
+    const VarRounds& vr = ch.vr;
     const bool BIG = NW > 4;                         // dword-index tables, 160 KB frame
     const int esz = shape.esz;
-    const bool SYS = BIG || (NW > 1 && shape.VRX > 0) || esz == 8;  // system row (see the kernels)
-    vr.VR = VR; vr.DV = DV; vr.vrx = shape.VRX; vr.dvx = shape.DVX; vr.nw = NW; vr.reserved = SYS ? 1 : 0;
-    vr.fixed_edge_order = fixed_order;
-    p->sys_off = SYS ? (NPAD - 64) * esz : 0;
+    const bool SYS = ch.SYS;
+    p->sys_off = SYS ? (NPAD - (vr.reserved_half ? 32 : 64)) * esz : 0;
     p->shape = si; p->DC = DC; p->DV = DV; p->CR = CR; p->VR = VR; p->NW = NW;
     p->zero_row = (NW == 1) ? 1 : 0;
 
@@ -158,24 +251,7 @@ int fused_plan_create(Decoder* d) {
         L.base_cycles = 2.0 * (CR * DC + vr.total_gathers());
         L.extra_cycles_identity = L.extra_cycles_planned = layout_extra_cycles(*c, DC, CR, vr, L);
     } else {
-        // stored plan (a long annealing run done once, ldpc_layout.hpp "plan store") or a short run now
-        const uint64_t key = layout_key(*c, DC, CR, vr, NW);
-        char name[40];
-        snprintf(name, sizeof(name), "%016llx.plan", (unsigned long long)key);
-        bool loaded = false;
-        const bool use_store = !(mode && std::string(mode) == "replan");
-        for (const std::string& dir : plan_dirs()) {
-            if (!use_store || loaded) break;
-            loaded = layout_load(dir + "/" + name, key, *c, DC, CR, vr, &L);
-        }
-        if (!loaded) {
-            long moves = kDefaultPlanMoves;
-            if (const char* e = std::getenv("LDPC_FUSED_PLAN_MOVES")) moves = atol(e);
-            else if (const char* ms = std::getenv("LDPC_FUSED_PLAN_MS")) moves = (long)(atof(ms) * 4000.0);
-            plan_fused_layout(*c, DC, CR, vr, 0x1200u, moves, &L);
-            if (const char* out = std::getenv("LDPC_FUSED_PLAN_SAVE")) (void)layout_save(std::string(out) + "/" + name, key, *c, L);
-        }
-        p->plan_from_store = loaded;
+        p->plan_from_store = obtain_layout(c, ch, !(mode && std::string(mode) == "replan"), 0, plan_save_dir(), &L);
     }
     p->extra_identity = L.extra_cycles_identity;
     p->extra_planned = L.extra_cycles_planned;
@@ -203,7 +279,7 @@ int fused_plan_create(Decoder* d) {
     // short check rows are padded with reads of one "certain" variable slot (marked -2): +-inf marginal, see the kernel
     int certain_slot = -1;
     if (short_rows) {
-        for (int s = (VR - vr.reserved) * 64 - 1; s >= 0 && certain_slot < 0; --s)
+        for (int s = vr.usable_slots() - 1; s >= 0 && certain_slot < 0; --s)
             if (var_of_slot[s] == -1) certain_slot = s;
         if (certain_slot < 0) return LDPC_OK;
         var_of_slot[certain_slot] = -2;

@@ -750,7 +750,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
 //            divide, atanh, +-1 -> +-inf; inf - inf -> NaN -> decision 0) through cn_spa<double> of ldpc_cn.hpp, i.e. the very
 //            same device code as the streaming kernel: bit-identical to it.  The row sum of log|tanh| is order dependent, so
 //            the plan of an fp64 sum-product decoder keeps every check's edges in their canonical (ascending variable) order.
-// Check degrees DC in 4..8, NW waves per frame with the system-row hand-off protocol of the big fp32 shapes (last marginal row
+// Check degrees DC in 4..8, NW waves per frame with the system-row hand-off protocol of the big fp32 shapes (upper half of the last marginal row
 // reserved: dwords [0,16) verdict channel A, [16,32) channel B, [32] frame hand-out, [34,36) an always-zero double).  Same tables
 // and layout plan as the fp32 kernels with 8-byte elements; gathers are ds_read_b64 (2 LDS cycles, as b32), stores ds_write_b64.
 // SIM: channel + LLR in the kernel (Philox noise, the inline functions of the stand-alone channel kernels: bit-identical
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
     const u64* cn_active = A.cn_active + w * CRW;
     const int n = A.n, max_iter = A.max_iter;
     const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
-    const bool own_last = !(NW > 1 && w == NW - 1);
+    const bool own_last = !(NW > 1 && w == NW - 1) || lane < 32;  // the system words live in the upper half of the last marginal row
     auto sysw = [&](int i) { return reinterpret_cast<volatile uint32_t*>(smem + A.sys_off) + i; };
     // table entries: 16-bit byte offsets, or -- frames beyond 64 KB of LDS (WIDE) -- 16-bit indices of 8-byte elements
     constexpr bool WIDE = (size_t)(VR * 64 + CRW * NW * DC * 64) * 8 > 65536;
@@ -1042,20 +1042,36 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
                         finish_var(Q_, sw);
                     });
                 }
-                double cv[2][DV];
+                // narrow rounds, VG of them per pipeline stage: the gathers of stage g+1 are in flight while stage g is summed.  Measured on
+                // the headline workload (min-sum, 65 536 frames x 49.4 sweeps): VG = 1 / 2 / 3 -> 6.37 / 6.28 / 6.21 ms; sum-product has no
+                // registers to spare (VG = 3 adds spills there)
+                constexpr int VG = ALG == ALG_MSA ? 3 : 1;
+                constexpr int NVG = (VRN + VG - 1) / VG;
+                double cv[2][VG][DV];
 #pragma unroll
-                for (int j = 0; j < DV; ++j) cv[0][j] = gat(half_of<VNK>(vn_idx, VN0 + j));
-                static_for<0, VRN>([&](auto Q_) {
-                    constexpr int q = decltype(Q_)::value;
-                    if constexpr (q + 1 < VRN) {
+                for (int u = 0; u < VG; ++u)
 #pragma unroll
-                        for (int j = 0; j < DV; ++j) cv[(q + 1) & 1][j] = gat(half_of<VNK>(vn_idx, VN0 + (q + 1) * DV + j));
+                    for (int j = 0; j < DV; ++j)
+                        if (u < VRN) cv[0][u][j] = gat(half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                static_for<0, NVG>([&](auto G_) {
+                    constexpr int g = decltype(G_)::value;
+                    if constexpr (g + 1 < NVG) {
+#pragma unroll
+                        for (int u = 0; u < VG; ++u)
+#pragma unroll
+                            for (int j = 0; j < DV; ++j)
+                                if ((g + 1) * VG + u < VRN) cv[(g + 1) & 1][u][j] = gat(half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG + u) * DV + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    double sn = 0.0 + cv[q & 1][0];
+                    static_for<0, VG>([&](auto U_) {
+                        constexpr int u = decltype(U_)::value;
+                        if constexpr (g * VG + u < VRN) {
+                            double sn = 0.0 + cv[g & 1][u][0];
 #pragma unroll
-                    for (int j = 1; j < DV; ++j) sn += cv[q & 1][j];
-                    finish_var(std::integral_constant<int, VRX + q>{}, sn);
+                            for (int j = 1; j < DV; ++j) sn += cv[g & 1][u][j];
+                            finish_var(std::integral_constant<int, VRX + g * VG + u>{}, sn);
+                        }
+                    });
                 });
                 phase_barrier();
                 ++it;

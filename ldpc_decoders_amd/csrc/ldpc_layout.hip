@@ -39,8 +39,8 @@ void identity_layout(const Code& c, int DC, const VarRounds& vr, FusedLayout* L)
     // (spilling into left-over wide slots when the narrow ones are full); reserved rounds stay empty
     std::vector<int> wide_free, narrow_free;
     for (int q = 0; q < vr.VR; ++q) {
-        if (!vr.usable(q)) continue;
-        for (int l = 0; l < 64; ++l) (vr.width(q) > vr.DV ? wide_free : narrow_free).push_back(q * 64 + l);
+        for (int l = 0; l < 64; ++l)
+            if (vr.usable_slot(q * 64 + l)) (vr.width(q) > vr.DV ? wide_free : narrow_free).push_back(q * 64 + l);
     }
     size_t next_wide = 0, next_narrow = 0;
     for (int v = 0; v < c.n; ++v)
@@ -87,66 +87,98 @@ double layout_extra_cycles(const Code& c, int DC, int CR, const VarRounds& vr, c
     return extra;
 }
 
-void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint64_t seed, long moves, FusedLayout* L) {
-    identity_layout(c, DC, vr, L);
-    L->base_cycles = 2.0 * (CR * DC + vr.total_gathers());
-    L->extra_cycles_identity = layout_extra_cycles(c, DC, CR, vr, *L);
-    const int VR = vr.VR, DVM = std::max(vr.DV, vr.dvx);
-    const int NGC = 2 * CR, NGV = 2 * VR, m = c.m, n = c.n;
-    const int64_t E = c.E;
-    Rng rng(seed);
+namespace {
 
-    // ---- state
-    std::vector<int> cgrp(m), cbank(m), vgrp(n), vbank(n), vflip(n, 0);
-    std::vector<int> chk_at((size_t)NGC * 32, -1), var_at((size_t)NGV * 32, -1);
-    for (int cc = 0; cc < m; ++cc) {
-        cgrp[cc] = group_of_slot(cc);
-        cbank[cc] = bank_of_slot(cc);
-        chk_at[(size_t)cgrp[cc] * 32 + cbank[cc]] = cc;
+// Annealing state of one replica: slot assignments + the incremental surrogate cost.  Copyable (replicas adopt the best state
+// of a generation), every move is an involution.
+struct Anneal {
+    const Code& c;
+    const VarRounds& vr;
+    int DC, DVM, NGC, NGV, m, n;
+    std::vector<int> cgrp, cbank, vgrp, vbank, vflip, chk_at, var_at, cnA, cnB;
+    const std::vector<int>* edge_vj;  // canonical index of edge k in its variable's list (shared, read-only)
+    long cost = 0;
+    // check-phase cells: (check group, variable bank) with capacity DC when the edge positions are free (edge colouring places them
+    // afterwards), (check group, position, variable bank) with capacity 1 when every check keeps its canonical edge order
+    bool fixed = false;
+    int capA = 0;
+
+    Anneal(const Code& c_, int DC_, int CR, const VarRounds& vr_, const FusedLayout& L, const std::vector<int>* evj)
+        : c(c_), vr(vr_), DC(DC_), DVM(std::max(vr_.DV, vr_.dvx)), NGC(2 * CR), NGV(2 * vr_.VR), m(c_.m), n(c_.n), edge_vj(evj) {
+        fixed = vr_.fixed_edge_order;
+        capA = fixed ? 1 : DC;
+        cgrp.resize(m); cbank.resize(m); vgrp.resize(n); vbank.resize(n); vflip.assign(n, 0);
+        chk_at.assign((size_t)NGC * 32, -1); var_at.assign((size_t)NGV * 32, -1);
+        for (int cc = 0; cc < m; ++cc) {
+            cgrp[cc] = group_of_slot(L.chk_slot[cc]);
+            cbank[cc] = bank_of_slot(L.chk_slot[cc]);
+            chk_at[(size_t)cgrp[cc] * 32 + cbank[cc]] = cc;
+        }
+        for (int v = 0; v < n; ++v) {
+            vgrp[v] = group_of_slot(L.var_slot[v]);
+            vbank[v] = bank_of_slot(L.var_slot[v]);
+            var_at[(size_t)vgrp[v] * 32 + vbank[v]] = v;
+        }
+        cnA.assign((size_t)NGC * (fixed ? DC : 1) * 32, 0);
+        cnB.assign((size_t)NGV * DVM * 32, 0);
+        for (int v = 0; v < n; ++v) touch_var(v, +1);
     }
-    for (int v = 0; v < n; ++v) {
-        vgrp[v] = group_of_slot(L->var_slot[v]);
-        vbank[v] = bank_of_slot(L->var_slot[v]);
-        var_at[(size_t)vgrp[v] * 32 + vbank[v]] = v;
+    Anneal& operator=(const Anneal& o) {  // same problem instance: copy the mutable state only
+        cgrp = o.cgrp; cbank = o.cbank; vgrp = o.vgrp; vbank = o.vbank; vflip = o.vflip; chk_at = o.chk_at; var_at = o.var_at;
+        cnA = o.cnA; cnB = o.cnB; cost = o.cost;
+        return *this;
     }
     // placement constraint: a variable with more than DV edges only fits a slot of a wide round (group g = 2*round + half)
-    auto fits = [&](int v, int s) { return v < 0 || (vr.usable((s / 32) / 2) && c.col_ptr[v + 1] - c.col_ptr[v] <= vr.width((s / 32) / 2)); };
-    std::vector<int> edge_vj(E);  // canonical index of edge k in its variable's list
-    for (int v = 0; v < n; ++v)
-        for (int p = c.col_ptr[v]; p < c.col_ptr[v + 1]; ++p) edge_vj[c.col_edge[p]] = p - c.col_ptr[v];
-    auto vpos = [&](int v, int j) { return (j < 2 && vflip[v] && (c.col_ptr[v + 1] - c.col_ptr[v]) >= 2) ? 1 - j : j; };
-
-    std::vector<int> cnA((size_t)NGC * 32, 0), cnB((size_t)NGV * DVM * 32, 0);
-    long cost = 0;
-    auto addA = [&](int gc, int bv, int d) {
-        int& x = cnA[(size_t)gc * 32 + bv];
-        cost -= std::max(0, x - DC);
+    bool fits(int v, int s) const { return v < 0 || (vr.usable_slot(slot_of(s / 32, s % 32)) && c.col_ptr[v + 1] - c.col_ptr[v] <= vr.width((s / 32) / 2)); }
+    int vpos(int v, int j) const { return (j < 2 && vflip[v] && (c.col_ptr[v + 1] - c.col_ptr[v]) >= 2) ? 1 - j : j; }
+    size_t cellA(int k, int bv) const {  // cell of edge k (row-major edge index) when its variable sits on bank bv
+        const int cc = c.edge_chk[k];
+        return fixed ? ((size_t)cgrp[cc] * DC + (k - c.row_ptr[cc])) * 32 + bv : (size_t)cgrp[cc] * 32 + bv;
+    }
+    void addA(int k, int bv, int d) {
+        int& x = cnA[cellA(k, bv)];
+        cost -= std::max(0, x - capA);
         x += d;
-        cost += std::max(0, x - DC);
-    };
-    auto addB = [&](int gv, int pos, int bc, int d) {
+        cost += std::max(0, x - capA);
+    }
+    void addB(int gv, int pos, int bc, int d) {
         int& x = cnB[((size_t)gv * DVM + pos) * 32 + bc];
         cost -= std::max(0, x - 1);
         x += d;
         cost += std::max(0, x - 1);
-    };
-    auto touch_var = [&](int v, int d) {
+    }
+    void touch_var(int v, int d) {
         for (int p = c.col_ptr[v]; p < c.col_ptr[v + 1]; ++p) {
             const int k = c.col_edge[p], cc = c.edge_chk[k];
-            addA(cgrp[cc], vbank[v], d);
+            addA(k, vbank[v], d);
             addB(vgrp[v], vpos(v, p - c.col_ptr[v]), cbank[cc], d);
         }
-    };
-    auto touch_chk = [&](int cc, int d) {
+    }
+    void touch_chk(int cc, int d) {
         for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) {
             const int v = c.edge_var[k];
-            addA(cgrp[cc], vbank[v], d);
-            addB(vgrp[v], vpos(v, edge_vj[k]), cbank[cc], d);
+            addA(k, vbank[v], d);
+            addB(vgrp[v], vpos(v, (*edge_vj)[k]), cbank[cc], d);
         }
-    };
-    for (int v = 0; v < n; ++v) touch_var(v, +1);
-
-    auto swap_vars = [&](int s1, int s2) {
+    }
+    // does this variable / check sit on an overloaded cell?  (directed move selection)
+    bool hot_var(int v) const {
+        for (int p = c.col_ptr[v]; p < c.col_ptr[v + 1]; ++p) {
+            const int k = c.col_edge[p], cc = c.edge_chk[k];
+            if (cnA[cellA(k, vbank[v])] > capA) return true;
+            if (cnB[((size_t)vgrp[v] * DVM + vpos(v, p - c.col_ptr[v])) * 32 + cbank[cc]] > 1) return true;
+        }
+        return false;
+    }
+    bool hot_chk(int cc) const {
+        for (int k = c.row_ptr[cc]; k < c.row_ptr[cc + 1]; ++k) {
+            const int v = c.edge_var[k];
+            if (cnA[cellA(k, vbank[v])] > capA) return true;
+            if (cnB[((size_t)vgrp[v] * DVM + vpos(v, (*edge_vj)[k])) * 32 + cbank[cc]] > 1) return true;
+        }
+        return false;
+    }
+    void swap_vars(int s1, int s2) {
         const int a = var_at[s1], b = var_at[s2];
         if (a >= 0) touch_var(a, -1);
         if (b >= 0) touch_var(b, -1);
@@ -155,8 +187,8 @@ void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint6
         std::swap(var_at[s1], var_at[s2]);
         if (a >= 0) touch_var(a, +1);
         if (b >= 0) touch_var(b, +1);
-    };
-    auto swap_chks = [&](int s1, int s2) {
+    }
+    void swap_chks(int s1, int s2) {
         const int a = chk_at[s1], b = chk_at[s2];
         if (a >= 0) touch_chk(a, -1);
         if (b >= 0) touch_chk(b, -1);
@@ -165,53 +197,89 @@ void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint6
         std::swap(chk_at[s1], chk_at[s2]);
         if (a >= 0) touch_chk(a, +1);
         if (b >= 0) touch_chk(b, +1);
-    };
-    auto flip_var = [&](int v) {
+    }
+    void flip_var(int v) {
         touch_var(v, -1);
         vflip[v] ^= 1;
         touch_var(v, +1);
-    };
+    }
 
-    // ---- annealing
-    // the schedule is a function of the move count only, so a plan depends on (code, shape, seed, moves) and not on the
-    // machine it was computed on
-    const auto t_start = std::chrono::steady_clock::now();
-    auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
-    const int nvs = NGV * 32, ncs = NGC * 32;
-    double T = 1.5;
-    const double T_end = 0.08;
-    long best = cost;
-    std::vector<int> b_cgrp = cgrp, b_cbank = cbank, b_vgrp = vgrp, b_vbank = vbank, b_vflip = vflip;
-    const long max_moves = moves < 1 ? 1 : moves;
-    for (long it = 0; it < max_moves && best > 0; ++it) {
-        if ((it & 4095) == 0) T = 1.5 * std::pow(T_end / 1.5, (double)it / (double)max_moves);
-        const long before = cost;
-        const int kind = rng.below(100);
-        int a = 0, b = 0;
-        if (kind < 45) {
-            a = rng.below(nvs); b = rng.below(nvs);
-            if (a == b || (var_at[a] < 0 && var_at[b] < 0) || !fits(var_at[a], b) || !fits(var_at[b], a)) continue;
-            swap_vars(a, b);
-        } else if (kind < 85) {
-            a = rng.below(ncs); b = rng.below(ncs);
-            if (a == b || (chk_at[a] < 0 && chk_at[b] < 0)) continue;
-            swap_chks(a, b);
-        } else {
-            a = rng.below(n);
-            flip_var(a);
-        }
-        const long delta = cost - before;
-        if (delta > 0 && rng.unit() >= std::exp(-(double)delta / T)) {  // reject: every move is an involution
-            if (kind < 45) swap_vars(a, b);
-            else if (kind < 85) swap_chks(a, b);
-            else flip_var(a);
-        } else if (cost < best) {
-            best = cost;
-            b_cgrp = cgrp; b_cbank = cbank; b_vgrp = vgrp; b_vbank = vbank; b_vflip = vflip;
+    // moves [it0, it1) of a schedule of `total` moves (the temperature is a function of the move index only); keeps the state
+    // with the lowest cost seen in `best` (which starts as a copy of the entry state)
+    void run(Rng& rng, long it0, long it1, long total, Anneal* best) {
+        const int nvs = NGV * 32, ncs = NGC * 32;
+        const double T0 = 0.8, T_end = 0.08;
+        double T = T0 * std::pow(T_end / T0, (double)it0 / (double)total);
+        for (long it = it0; it < it1 && best->cost > 0; ++it) {
+            if ((it & 4095) == 0) T = T0 * std::pow(T_end / T0, (double)it / (double)total);
+            const long before = cost;
+            const int kind = rng.below(100);
+            int a = 0, b = 0;
+            // directed selection: three moves in four start from an item that sits on an overloaded cell (a few tries to find one)
+            const bool directed = (rng.next() >> 62) != 0;
+            if (kind < 45) {
+                a = rng.below(nvs);
+                if (directed)
+                    for (int t = 0; t < 6 && (var_at[a] < 0 || !hot_var(var_at[a])); ++t) a = rng.below(nvs);
+                // partner: any slot, or -- the check-phase cost depends on a variable's BANK only, the variable-phase cost on its
+                // GROUP only -- a slot of the same group (another bank) or of the same bank (another group): such a move repairs
+                // one phase without disturbing the other
+                const int shape = rng.below(8);
+                b = shape < 3 ? (a / 32) * 32 + rng.below(32) : (shape < 6 ? rng.below(NGV) * 32 + a % 32 : rng.below(nvs));
+                if (a == b || (var_at[a] < 0 && var_at[b] < 0) || !fits(var_at[a], b) || !fits(var_at[b], a)) continue;
+                swap_vars(a, b);
+            } else if (kind < 85) {
+                a = rng.below(ncs);
+                if (directed)
+                    for (int t = 0; t < 6 && (chk_at[a] < 0 || !hot_chk(chk_at[a])); ++t) a = rng.below(ncs);
+                const int shape = rng.below(8);  // likewise: a check's GROUP enters the check-phase cost only, its BANK the variable-phase cost only
+                b = shape < 3 ? (a / 32) * 32 + rng.below(32) : (shape < 6 ? rng.below(NGC) * 32 + a % 32 : rng.below(ncs));
+                if (a == b || (chk_at[a] < 0 && chk_at[b] < 0)) continue;
+                swap_chks(a, b);
+            } else {
+                a = rng.below(n);
+                if (directed)
+                    for (int t = 0; t < 6 && !hot_var(a); ++t) a = rng.below(n);
+                flip_var(a);
+            }
+            const long delta = cost - before;
+            if (delta > 0 && rng.unit() >= std::exp(-(double)delta / T)) {  // reject: every move is an involution
+                if (kind < 45) swap_vars(a, b);
+                else if (kind < 85) swap_chks(a, b);
+                else flip_var(a);
+            } else if (cost < best->cost) {
+                *best = *this;
+            }
         }
     }
-    cgrp = b_cgrp; cbank = b_cbank; vgrp = b_vgrp; vbank = b_vbank; vflip = b_vflip;
-    if (std::getenv("LDPC_PLAN_DEBUG")) fprintf(stderr, "[plan] annealing: surrogate cost %ld after %.2fs\n", best, elapsed());
+};
+
+}  // namespace
+
+void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint64_t seed, long moves, FusedLayout* L) {
+    identity_layout(c, DC, vr, L);
+    L->base_cycles = 2.0 * (CR * DC + vr.total_gathers());
+    L->extra_cycles_identity = layout_extra_cycles(c, DC, CR, vr, *L);
+    const int m = c.m, n = c.n;
+    const int NGC = 2 * CR;
+    const int64_t E = c.E;
+    std::vector<int> edge_vj(E);  // canonical index of edge k in its variable's list
+    for (int v = 0; v < n; ++v)
+        for (int p = c.col_ptr[v]; p < c.col_ptr[v + 1]; ++p) edge_vj[c.col_edge[p]] = p - c.col_ptr[v];
+
+    // ---- annealing: one chain; the schedule is a function of the move count only, so a plan depends on (code, shape, seed, moves)
+    // and not on the machine it was computed on.  (Independent or best-state-sharing replicas on several host threads were
+    // measured: 8 x 2.5 M moves end where ONE chain of 2.5 M moves ends -- the result is set by the length of the chain.)
+    const auto t_start = std::chrono::steady_clock::now();
+    auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+    const long max_moves = moves < 1 ? 1 : moves;
+    Anneal chain(c, DC, CR, vr, *L, &edge_vj);
+    Anneal champion = chain;
+    Rng rng(seed);
+    chain.run(rng, 0, max_moves, max_moves, &champion);
+    const std::vector<int>&cgrp = champion.cgrp, &cbank = champion.cbank, &vgrp = champion.vgrp, &vbank = champion.vbank;
+    auto vpos = [&](int v, int j) { return champion.vpos(v, j); };
+    if (std::getenv("LDPC_PLAN_DEBUG")) fprintf(stderr, "[plan] annealing: surrogate cost %ld after %.2fs\n", champion.cost, elapsed());
 
     for (int cc = 0; cc < m; ++cc) L->chk_slot[cc] = slot_of(cgrp[cc], cbank[cc]);
     for (int v = 0; v < n; ++v) L->var_slot[v] = slot_of(vgrp[v], vbank[v]);
@@ -314,6 +382,7 @@ uint64_t layout_key(const Code& c, int DC, int CR, const VarRounds& vr, int NW) 
     const int32_t hdr[10] = {(int32_t)kPlannerVersion, c.m, c.n, DC, CR, vr.VR, vr.DV, vr.vrx, vr.dvx, NW};
     h = fnv(h, hdr, sizeof(hdr));
     if (vr.reserved) h = fnv(h, &vr.reserved, sizeof(vr.reserved));
+    if (vr.reserved && vr.reserved_half) h = fnv(h, "half-row", 8);
     if (vr.fixed_edge_order) h = fnv(h, "fixed-edge-order", 16);
     h = fnv(h, c.edge_chk.data(), c.edge_chk.size() * sizeof(int32_t));
     h = fnv(h, c.edge_var.data(), c.edge_var.size() * sizeof(int32_t));
@@ -330,7 +399,7 @@ bool layout_valid(const Code& c, int DC, int CR, const VarRounds& vr, const Fuse
     for (int v = 0; v < c.n; ++v) {
         const int s = L.var_slot[v];
         if (s < 0 || s >= vr.VR * 64 || seen_v[s]++) return false;
-        if (!vr.usable(s / 64) || c.col_ptr[v + 1] - c.col_ptr[v] > vr.width(s / 64)) return false;
+        if (!vr.usable_slot(s) || c.col_ptr[v + 1] - c.col_ptr[v] > vr.width(s / 64)) return false;
     }
     for (int cc = 0; cc < c.m; ++cc) {  // positions inside a check: distinct, below DC
         unsigned mask = 0;

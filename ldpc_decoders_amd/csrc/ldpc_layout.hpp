@@ -16,6 +16,10 @@
 //
 // plan_fused_layout() minimises the excess over those capacities by simulated annealing (swap two variable
 // slots / two check slots / flip a variable's first two positions), then edge-colours every check group.
+// Two things make the annealer about ten times more effective per move than uniform random swaps: (1) the check-phase cost
+// depends on (check GROUP, variable BANK) only and the variable-phase cost on (variable GROUP, position, check BANK) only, so
+// most proposals keep the group and change the bank, or keep the bank and change the group -- they repair one phase without
+// disturbing the other; (2) three proposals in four start from an item that currently sits on an overloaded cell.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -37,10 +41,12 @@ struct FusedLayout {
 
 // Variable rounds come in two widths: each wave owns VR/nw consecutive rounds, the first `vrx` of them gather `dvx` messages
 // per variable ("wide" rounds, for the high-degree variables of irregular codes), the others gather DV.  vrx = 0 for regular
-// codes.  `reserved` trailing rounds hold no variables (the system row of the 16-wave shape, ldpc_fused.hip).
+// codes.  `reserved` trailing rounds hold no variables (the system row of the 16-wave shape, ldpc_fused.hip); with `reserved_half`
+// only the upper 32 slots of that last round are reserved (the fp64 shapes: their system words fit 32 eight-byte slots).
 struct VarRounds {
     int VR = 0, DV = 0, vrx = 0, dvx = 0;
     int nw = 1, reserved = 0;
+    bool reserved_half = false;
     bool fixed_edge_order = false;  // every check keeps its edges in ascending-variable order (fp64 sum-product: the row sum of logs is order dependent)
     int vrw() const { return VR / nw; }
     int per_wave() const { return vrx * dvx + (vrw() - vrx) * DV; }
@@ -50,7 +56,8 @@ struct VarRounds {
         return w * per_wave() + (l < vrx ? l * dvx : vrx * dvx + (l - vrx) * DV);
     }
     int total_gathers() const { return nw * per_wave(); }
-    bool usable(int q) const { return q < VR - reserved; }
+    int usable_slots() const { return VR * 64 - (reserved ? (reserved_half ? 32 : reserved * 64) : 0); }
+    bool usable_slot(int s) const { return s < usable_slots(); }
 };
 
 // exact conflict model: sum over gather instructions and half-waves of (max distinct-address multiplicity - 1)
@@ -59,8 +66,8 @@ double layout_extra_cycles(const Code& c, int DC, int CR, const VarRounds& vr, c
 // trivial placement: checks in index order; variables in index order, except that variables with more than DV edges are
 // moved into the wide rounds (the only placement constraint)
 void identity_layout(const Code& c, int DC, const VarRounds& vr, FusedLayout* L);
-// `moves` = annealing steps (about 4 M per second on one host core); the result is a deterministic function of the arguments
-constexpr long kDefaultPlanMoves = 2500000;
+// `moves` = annealing steps (about 1.7 M per second on one host core); the result is a deterministic function of the arguments
+constexpr long kDefaultPlanMoves = 4000000;
 void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint64_t seed, long moves, FusedLayout* L);
 
 

@@ -14,6 +14,8 @@
 //   iteration-0 check of the received word (BSC) ............................ src/bpa.py:20,29
 //   variable update: prior + (((0 + c_a) + c_b) + ...) in ascending edge order  src/bpa.py:35, src/math_utils.py:7
 //   erasure decoder incl. "no change" (stopping set) exit .................... src/bec.py:83-122
+#include <cstdlib>
+
 #include "ldpc_cn.hpp"
 #include "ldpc_common.hpp"
 
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
 __global__ __launch_bounds__(256) void k_syndrome(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
                                                   const u64* __restrict__ xbits, u64* __restrict__ live,
                                                   int32_t* __restrict__ iters, int* __restrict__ live_tiles, int m, int n,
-                                                  int64_t B, int sweeps) {
+                                                  int64_t B, int sweeps, const int32_t* __restrict__ frame_of) {
     __shared__ u64 s_un;
     const int tile = blockIdx.x, t = threadIdx.x;
     const u64 lv = live[tile];
@@ -304,11 +306,97 @@ __global__ __launch_bounds__(256) void k_syndrome(const int32_t* __restrict__ ro
     const u64 stay = lv & unsat, leave = lv & ~unsat;
     if (t == 0) {
         live[tile] = stay;
-        if (stay && live_tiles) atomicAdd(live_tiles, 1);
+        if (stay && live_tiles) {
+            atomicAdd(live_tiles, 1);                    // tiles that still hold a live frame
+            atomicAdd(live_tiles + 1, __popcll(stay));   // live frames
+        }
     }
     if (t < 64 && ((leave >> t) & 1ull)) {
-        const int64_t fr = (int64_t)tile * 64 + t;
-        if (fr < B) iters[fr] = sweeps;
+        const int64_t fr = frame_of ? (int64_t)frame_of[(int64_t)tile * 64 + t] : (int64_t)tile * 64 + t;
+        if (fr >= 0 && fr < B) iters[fr] = sweeps;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Frame repack (early termination): when many tiles hold only a few live frames, the live frames are gathered into dense
+// tiles -- the reference leaves per FRAME (src/bpa.py:28-29); a tile keeps streaming its whole message block for as long as
+// one of its 64 frames is live.  k_repack_plan ranks the live frames (prefix sums of the tiles' live counts); k_repack moves
+// message lines, priors and decision bit-planes: destination lane j reads (source tile, source lane) of the j-th live frame;
+// lanes that share a source tile share the 256-byte line, so a line of a source tile is fetched once per destination tile
+// that draws from it.  The decisions of every frame of the old tiles are written out before (k_unpack), the moved frames
+// overwrite theirs at the end.
+__global__ __launch_bounds__(1024) void k_repack_plan(const u64* __restrict__ live, int tiles, int32_t* __restrict__ base) {
+    // base[t] = number of live frames in tiles [0, t); base[tiles] = total.  One workgroup, tiles <= 65535.
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (tiles + 1023) / 1024;
+    int sum = 0;
+    for (int i = t * per; i < min(tiles, (t + 1) * per); ++i) sum += __popcll(live[i]);
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = t ? part[t - 1] : 0;
+    for (int i = t * per; i < min(tiles, (t + 1) * per); ++i) {
+        base[i] = run;
+        run += __popcll(live[i]);
+    }
+    if (t == 1023) base[tiles] = part[1023];
+}
+
+__device__ __forceinline__ int nth_set_bit(u64 x, int k) {  // position of the k-th (0-based) set bit of x
+    for (int i = 0; i < k; ++i) x &= x - 1;
+    return __ffsll((long long)x) - 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_repack(const T* __restrict__ msg_src, T* __restrict__ msg_dst, const T* __restrict__ prior_src,
+                                                T* __restrict__ prior_dst, const u64* __restrict__ xb_src, u64* __restrict__ xb_dst,
+                                                const u64* __restrict__ live_src, u64* __restrict__ live_dst,
+                                                const int32_t* __restrict__ base, const int32_t* __restrict__ frame_src,
+                                                int32_t* __restrict__ frame_dst, int tiles_src, int n, int64_t E, int rows_per_wave) {
+    const int lane = threadIdx.x;
+    const int dt = blockIdx.y;  // destination tile
+    const int total = base[tiles_src];
+    const int j = dt * 64 + lane;
+    // source of this lane's frame: the tile whose rank interval holds j (binary search over the prefix sums)
+    int st = 0, sl = 0;
+    const bool has = j < total;
+    if (has) {
+        int lo = 0, hi = tiles_src - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (base[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        st = lo;
+        sl = nth_set_bit(live_src[st], j - base[st]);
+    }
+    const int chunk = blockIdx.x * 4 + threadIdx.y;
+    const int64_t rows = E + n;  // message lines, then prior lines (+ one bit-plane word per prior line)
+    const int64_t r0 = (int64_t)chunk * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
+    const T* ms = msg_src + (int64_t)st * E * 64 + sl;
+    T* md = msg_dst + (int64_t)dt * E * 64 + lane;
+    const T* ps = prior_src + (int64_t)st * n * 64 + sl;
+    T* pd = prior_dst + (int64_t)dt * n * 64 + lane;
+    for (int64_t r = r0; r < r1; ++r) {
+        if (r < E) {
+            if (has) md[r * 64] = ms[r * 64];
+        } else {
+            const int64_t v = r - E;
+            if (has) pd[v * 64] = ps[v * 64];
+            const u64 w = has ? xb_src[(int64_t)st * n + v] : 0ull;
+            const u64 plane = __ballot(has && ((w >> sl) & 1ull));
+            if (lane == 0) xb_dst[(int64_t)dt * n + v] = plane;
+        }
+    }
+    if (chunk == 0) {
+        frame_dst[(int64_t)dt * 64 + lane] = has ? (frame_src ? frame_src[(int64_t)st * 64 + sl] : st * 64 + sl) : -1;
+        const u64 lv = __ballot(has);
+        if (lane == 0) live_dst[dt] = lv;
     }
 }
 
@@ -335,11 +423,12 @@ __global__ void k_bec_check(u64* __restrict__ flags, u64* __restrict__ live, int
 }
 
 // Frames that hit max_iter: iters = sweeps ; then planes -> x_hat bytes [B,n] in {0,1} ({0,1,2} for BEC).
-__global__ void k_finish_iters(const u64* __restrict__ live, int32_t* __restrict__ iters, int64_t B, int sweeps) {
+__global__ void k_finish_iters(const u64* __restrict__ live, int32_t* __restrict__ iters, int64_t B, int sweeps,
+                               const int32_t* __restrict__ frame_of) {
     const int tile = blockIdx.x, t = threadIdx.x;
     const u64 lv = live[tile];
-    const int64_t fr = (int64_t)tile * 64 + t;
-    if (((lv >> t) & 1ull) && fr < B) iters[fr] = sweeps;
+    const int64_t fr = frame_of ? (int64_t)frame_of[(int64_t)tile * 64 + t] : (int64_t)tile * 64 + t;
+    if (((lv >> t) & 1ull) && fr >= 0 && fr < B) iters[fr] = sweeps;
 }
 
 // marginal tile [n][64] -> [B,n] (diagnostic / soft-output path; not on the throughput path)
@@ -353,7 +442,7 @@ __global__ void k_soft_out(const T* __restrict__ soft_t, T* __restrict__ out, in
 
 template <int ALG>
 __global__ __launch_bounds__(256) void k_unpack(const u64* __restrict__ xbits, const u64* __restrict__ xera,
-                                                uint8_t* __restrict__ xhat, int64_t B, int n) {
+                                                uint8_t* __restrict__ xhat, int64_t B, int n, const int32_t* __restrict__ frame_of) {
     const int tile = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= n) return;
@@ -361,6 +450,13 @@ __global__ __launch_bounds__(256) void k_unpack(const u64* __restrict__ xbits, c
     u64 era = 0;
     if constexpr (ALG == ALG_BEC) era = xera[(int64_t)tile * n + v];
     const int64_t f0 = (int64_t)tile * 64;
+    if (frame_of) {  // repacked tiles: lane f holds frame frame_of[tile][f] (-1: none)
+        for (int f = 0; f < 64; ++f) {
+            const int64_t fr = frame_of[f0 + f];
+            if (fr >= 0 && fr < B) xhat[fr * n + v] = (uint8_t)((one >> f) & 1ull);
+        }
+        return;
+    }
     const int fmax = (int)min((int64_t)64, B - f0);
     for (int f = 0; f < fmax; ++f) {
         uint8_t s = (uint8_t)((one >> f) & 1ull);
@@ -494,10 +590,26 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
 
     const bool early = !(flags_in & FLAG_NO_EARLY_EXIT);
     const int cap = max_iter > 0 ? max_iter : 100000;  // max_iter <= 0 == unlimited upstream (src/bpa.py:28); bounded here
-    // how often the host looks at the live-tile counter: about every 300 us of streaming work
+    // how often the host looks at the live counters: about every 300 us of streaming work
     const double iter_us = 15.0 + (double)tiles * 64.0 * sizeof(T) * (4.0 * E + n) / 4.0e6;
     int poll_every = (int)(300.0 / iter_us);
     poll_every = poll_every < 1 ? 1 : (poll_every > 16 ? 16 : poll_every);
+    // Frame repack (see k_repack): LLR decoders without soft output.  Policy: at a poll, when the live frames would fill less than
+    // `fill` of the tiles that still hold one, gather them into dense tiles -- a repack moves (E + n) lines per tile once, a sweep
+    // moves (4E + n), so it pays as soon as about one more sweep follows.
+    bool repack_ok = early && ALG != ALG_BEC && soft_t == nullptr;
+    double repack_fill = 0.75;
+    if (const char* e = std::getenv("LDPC_STREAM_REPACK")) repack_ok = repack_ok && atoi(e) != 0;
+    if (const char* e = std::getenv("LDPC_STREAM_REPACK_FILL")) repack_fill = atof(e);
+    DevBuf* set_msg[2] = {&d->msg, &d->msg2};
+    DevBuf* set_prior[2] = {&d->prior, &d->prior2};
+    DevBuf* set_xbits[2] = {&d->xbits, &d->xbits2};
+    DevBuf* set_live[2] = {&d->live, &d->live2};
+    DevBuf* set_fmap[2] = {&d->fmap, &d->fmap2};
+    int cur = 0;                 // which buffer set holds the state
+    int32_t* fmap = nullptr;     // frame index of (tile, lane); null = identity (never repacked)
+    int cur_tiles = tiles;
+    int repacks = 0;
     int sweeps = 0;
     std::vector<ProfSpan> spans;
     size_t ev_next = 0;
@@ -505,18 +617,46 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
         const bool check = early && (ALG == ALG_BEC || it > 0 || y0 != nullptr);
         if (check) {
             const bool poll = (it % poll_every) == 0 || max_iter <= 0;
-            if (poll) LDPC_HIP_TRY(hipMemsetAsync(live_tiles, 0, sizeof(int), st));
+            if (poll) LDPC_HIP_TRY(hipMemsetAsync(live_tiles, 0, 2 * sizeof(int), st));
             if (ALG == ALG_BEC) {
-                hipLaunchKernelGGL(k_bec_check, dim3(tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr,
-                                   B, tiles, sweeps);
+                hipLaunchKernelGGL(k_bec_check, dim3(cur_tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr,
+                                   B, cur_tiles, sweeps);
             } else {
-                hipLaunchKernelGGL(k_syndrome, dim3(tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, xbits, live, iters,
-                                   poll ? live_tiles : nullptr, m, n, B, sweeps);
+                hipLaunchKernelGGL(k_syndrome, dim3(cur_tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, xbits, live, iters,
+                                   poll ? live_tiles : nullptr, m, n, B, sweeps, fmap);
             }
             if (poll) {
-                LDPC_HIP_TRY(hipMemcpyAsync(h_poll, live_tiles, sizeof(int), hipMemcpyDeviceToHost, st));
+                LDPC_HIP_TRY(hipMemcpyAsync(h_poll, live_tiles, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
                 LDPC_HIP_TRY(hipStreamSynchronize(st));
-                if (*h_poll == 0) break;
+                const int lt = h_poll[0], lf = h_poll[1];
+                if (lt == 0) break;
+                if (repack_ok && it > 0 && lt >= 2 && (double)lf <= repack_fill * 64.0 * lt && it + 1 < cap) {
+                    const int nt = (lf + 63) / 64;
+                    const int nx = 1 - cur;
+                    LDPC_TRY(set_msg[nx]->reserve((size_t)nt * E * 64 * sizeof(T)));
+                    LDPC_TRY(set_prior[nx]->reserve((size_t)nt * n * 64 * sizeof(T)));
+                    LDPC_TRY(set_xbits[nx]->reserve((size_t)nt * n * 8));
+                    LDPC_TRY(set_live[nx]->reserve((size_t)nt * 8));
+                    LDPC_TRY(set_fmap[nx]->reserve((size_t)nt * 64 * sizeof(int32_t)));
+                    LDPC_TRY(d->rbase.reserve(((size_t)cur_tiles + 1) * sizeof(int32_t)));
+                    // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs later)
+                    hipLaunchKernelGGL((k_unpack<ALG>), dim3((n + 255) / 256, cur_tiles), dim3(256), 0, st, xbits, xera, xhat, B, n, fmap);
+                    hipLaunchKernelGGL(k_repack_plan, dim3(1), dim3(1024), 0, st, live, cur_tiles, (int32_t*)d->rbase.p);
+                    const int rows_per_wave = 128;
+                    const int chunks = (int)((E + n + rows_per_wave - 1) / rows_per_wave);
+                    hipLaunchKernelGGL((k_repack<T>), dim3((chunks + 3) / 4, nt), dim3(64, 4), 0, st, msg, (T*)set_msg[nx]->p, prior,
+                                       (T*)set_prior[nx]->p, xbits, (u64*)set_xbits[nx]->p, live, (u64*)set_live[nx]->p,
+                                       (const int32_t*)d->rbase.p, fmap, (int32_t*)set_fmap[nx]->p, cur_tiles, n, E, rows_per_wave);
+                    cur = nx;
+                    msg = (T*)set_msg[cur]->p;
+                    prior = (T*)set_prior[cur]->p;
+                    xbits = (u64*)set_xbits[cur]->p;
+                    live = (u64*)set_live[cur]->p;
+                    fmap = (int32_t*)set_fmap[cur]->p;
+                    cur_tiles = nt;
+                    g.tiles = nt;
+                    ++repacks;
+                }
             }
         }
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -536,8 +676,8 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
         }
         ++sweeps;
     }
-    hipLaunchKernelGGL(k_finish_iters, dim3(tiles), dim3(64), 0, st, live, iters, B, sweeps);
-    hipLaunchKernelGGL((k_unpack<ALG>), dim3((n + 255) / 256, tiles), dim3(256), 0, st, xbits, xera, xhat, B, n);
+    hipLaunchKernelGGL(k_finish_iters, dim3(cur_tiles), dim3(64), 0, st, live, iters, B, sweeps, fmap);
+    hipLaunchKernelGGL((k_unpack<ALG>), dim3((n + 255) / 256, cur_tiles), dim3(256), 0, st, xbits, xera, xhat, B, n, fmap);
     if (soft_t)
         hipLaunchKernelGGL(k_soft_out<T>, dim3((n + 3) / 4, tiles), dim3(256), 0, st, soft_t, (T*)soft_out, B, n);
     LDPC_HIP_TRY(hipGetLastError());
@@ -545,6 +685,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
         LDPC_HIP_TRY(hipStreamSynchronize(st));
         LDPC_TRY(prof_collect(d, spans));
     }
+    d->last_repacks = repacks;
     d->last_sweeps = sweeps;
     d->last_backend = BK_STREAM;
     return LDPC_OK;

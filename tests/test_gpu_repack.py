@@ -1,0 +1,88 @@
+"""Per-frame early termination on the streaming backend (src/bpa.py:28-29: a frame that has left costs nothing): live frames are
+re-gathered into dense tiles while a batch thins out.  The repack only moves state, so every result must stay bit-identical --
+checked against the C oracle, against a run with the repack switched off, and against the LDS-resident backend."""
+import numpy as np
+import pytest
+
+import bp_oracle as O
+import c_oracle as C
+from helpers import golden_edges
+
+pytestmark = pytest.mark.gpu
+
+
+def _priors(seed, B, n, snr):
+    rng = np.random.RandomState(seed)
+    y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(snr)), (B, n))
+    return O.biawgn_priors(y, snr)
+
+
+@pytest.mark.parametrize("prec,dt", [("f64", np.float64), ("f32", np.float32)])
+@pytest.mark.parametrize("alg", ["MSA", "SPA"])
+def test_repack_is_bit_transparent(monkeypatch, prec, dt, alg):
+    from ldpc_decoders_amd import bpa
+    from ldpc_decoders_amd.codes import Code
+
+    g = golden_edges("1200_3_6_rand_ldpc_1")
+    code = Code.from_edges(g.m, g.n, g.chk, g.var)
+    B = 64 * 40 + 17  # ragged last tile
+    pri = _priors(11, B, g.n, 2.2).astype(dt)  # frames leave after 5..50 sweeps, a few never do
+    cls = bpa.MSA if alg == "MSA" else bpa.SPA
+    monkeypatch.setenv("LDPC_STREAM_REPACK", "0")
+    ref = cls(code, max_iter=50, precision=prec, backend="stream")
+    x0, i0 = ref.decode_batch(None, pri)
+    assert ref.handle.last_repacks() == 0
+    monkeypatch.setenv("LDPC_STREAM_REPACK", "1")
+    monkeypatch.setenv("LDPC_STREAM_REPACK_FILL", "0.97")  # eager: several repacks in one decode
+    dec = cls(code, max_iter=50, precision=prec, backend="stream")
+    x1, i1 = dec.decode_batch(None, pri)
+    assert dec.handle.last_stats()[0] == "stream" and dec.handle.last_repacks() >= 2
+    assert (x1 == x0).all() and (i1 == i0).all()
+    assert (i1 < 50).any() and (i1 == 50).any() and len(np.unique(i1)) > 8
+    if alg == "MSA":  # min-sum is exact arithmetic: the C oracle in the same precision gives the same bits
+        xo, io = C.bp_decode(g, "MSA", None, pri, 50, dtype=dt)
+        assert (x1 == xo).all() and (i1 == io).all()
+    monkeypatch.delenv("LDPC_STREAM_REPACK_FILL")
+    dflt = cls(code, max_iter=50, precision=prec, backend="stream")
+    x2, i2 = dflt.decode_batch(None, pri)
+    assert (x2 == x0).all() and (i2 == i0).all()
+
+
+def test_repack_with_received_word(monkeypatch):
+    # BSC: the iteration-0 exit of the received word (src/bpa.py:20,29) happens before any repack
+    from ldpc_decoders_amd import bpa
+    from ldpc_decoders_amd.codes import Code
+
+    g = golden_edges("1200_3_6_rand_ldpc_1")
+    code = Code.from_edges(g.m, g.n, g.chk, g.var)
+    rng = np.random.RandomState(3)
+    B, p = 64 * 24, 0.02
+    y = (rng.random_sample((B, g.n)) < p).astype(np.uint8)
+    y[:5] = 0  # frames that leave at iteration 0
+    pri = (np.log((1 - p) / p) * (1 - 2.0 * y)).astype(np.float64)
+    monkeypatch.setenv("LDPC_STREAM_REPACK_FILL", "0.97")
+    dec = bpa.MSA(code, max_iter=200, precision="f64", backend="stream")
+    x1, i1 = dec.decode_batch(y, pri)
+    xo, io = C.bp_decode(g, "MSA", y, pri, 200, dtype=np.float64)
+    assert dec.handle.last_repacks() >= 1
+    assert (i1[:5] == 0).all() and (x1 == xo).all() and (i1 == io).all()
+
+
+def test_repack_large_code_mid_snr():
+    # the (3,6) n = 64 800 shape of BASELINE config 5 at an SNR where every frame converges after a different number of sweeps:
+    # repacked streaming decode == C oracle on the frames the oracle is given, iteration counts included
+    from ldpc_decoders_amd import bpa, codes
+
+    code = codes.rand_reg_ldpc(64800, 3, 6, np.random.RandomState(20261002))
+    B = 64 * 6
+    pri = _priors(5, B, code.n, 2.0).astype(np.float32)  # frames leave after 12..22 sweeps
+    dec = bpa.MSA(code, max_iter=60, precision="f32", backend="stream")
+    x1, i1 = dec.decode_batch(None, pri)
+
+    class G:
+        m, n, chk, var = code.m, code.n, code.edge_chk, code.edge_var
+
+    sel = np.r_[0:24, B - 8:B]
+    xo, io = C.bp_decode(G, "MSA", None, pri[sel], 60, dtype=np.float32)
+    assert (x1[sel] == xo).all() and (i1[sel] == io).all()
+    assert dec.handle.last_repacks() >= 1 and i1.min() < i1.max()

@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
         printf("stored %.0f\n", S.extra_cycles_planned);
     }
     for (int v = 0; v < c.n; ++v)  // placement constraint: more than 3 edges only in the wide rounds
-        if (c.col_ptr[v + 1] - c.col_ptr[v] > vr.width(L.var_slot[v] / 64) || !vr.usable(L.var_slot[v] / 64)) return 5;
+        if (c.col_ptr[v + 1] - c.col_ptr[v] > vr.width(L.var_slot[v] / 64) || !vr.usable_slot(L.var_slot[v])) return 5;
     // the plan must be a permutation of slots and of the positions inside every check
     std::vector<int> seen(CR * 64, 0); for (int s : L.chk_slot) { if (s < 0 || s >= CR * 64 || seen[s]++) return 2; }
     std::vector<int> seenv(VR * 64, 0); for (int s : L.var_slot) { if (s < 0 || s >= VR * 64 || seenv[s]++) return 3; }

@@ -1,57 +1,63 @@
-"""Long annealing runs of the fused backend's LDS layout planner, stored as plan files (ldpc_layout.hpp, "plan store").
+"""Long annealing runs of the fused backend's LDS layout planner, stored as plan files (csrc/ldpc_layout.hpp, "plan store").
 
-    python tools/plan_codes.py --moves 1000000000 --out gpurun_out/plans [--codes NAME ...]
+    python tools/plan_codes.py --moves 300000000 --out ldpc_decoders_amd/plans [--codes-dir DIR] [--codes NAME ...] [--jobs 6]
 
-Each code is planned in its own process (the planner is single-threaded host code inside fused_plan_create, which needs
-a GPU only because the decoder handle allocates its tables there).  Copy the resulting <key>.plan files into
-ldpc_decoders_amd/plans/ to ship them."""
+Host-only: the planner runs behind `ldpc_plan_layout` (include/ldpc_hip.h), which needs no GPU.  For every code the plans of the
+shapes a user meets are produced: fp32 (one plan serves min-sum, sum-product and the erasure decoder), fp64 min-sum, fp64
+sum-product (edge order fixed).  One process per (code, shape); plans already present in --out are kept unless --force.
+`gen:reg:<n>:<l>:<r>` / `gen:irg:<n>` name the generated ensembles of bench.py."""
 import argparse
+import ctypes
+import glob
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CODES = ["1200_3_6_rand_ldpc_1", "1200_3_6_ldpc", "512_3_6_rand_ldpc_2", "1200_rho_x5_rand_ldpc_5", "margulis", "gen:irg:10000"]
+SHAPES = [("MSA", "f32"), ("MSA", "f64"), ("SPA", "f64")]
 
 CHILD = r"""
-import os, sys, time
+import ctypes, os, sys, time
 sys.path.insert(0, %(root)r)
-from ldpc_decoders_amd import codes
-from ldpc_decoders_amd._device import DecoderHandle
+import numpy as np
+from ldpc_decoders_amd import _lib, codes
 from bench import load_code
+name, alg, prec = %(code)r, %(alg)r, %(prec)r
+code = load_code(name) if name.startswith("gen:") else codes.load_parity_mtx(os.path.join(%(dir)r, name + ".txt"))
+lib = _lib.load()
+info = (ctypes.c_double * 4)()
+chk = np.ascontiguousarray(code.edge_chk, dtype=np.int32)
+var = np.ascontiguousarray(code.edge_var, dtype=np.int32)
 t0 = time.time()
-code = load_code(%(code)r) if %(code)r.startswith("gen:") else codes.get_code(%(code)r)  # gen:reg:<n>:<l>:<r> / gen:irg:<n> as in bench.py
-try:
-    h = DecoderHandle(code, "MSA", os.environ.get("LDPC_PLAN_PRECISION", "f32"), "fused")
-except Exception as e:  # no fused shape for this (code, LDPC_FUSED_NW): nothing to plan
-    print(%(code)r, "nw", os.environ.get("LDPC_FUSED_NW", "auto"), "skipped:", e, flush=True)
-    sys.exit(0)
-print(%(code)r, "nw", os.environ.get("LDPC_FUSED_NW", "auto"), "%%.0fs" %% (time.time() - t0), h.fused_info(), flush=True)
+_lib.check(lib.ldpc_plan_layout(code.m, code.n, code.E, chk.ctypes.data, var.ctypes.data, {"MSA": 0, "SPA": 1, "BEC": 2}[alg],
+                                {"f32": 0, "f64": 1}[prec], %(moves)d, %(out)r.encode(), info))
+print("%%-28s %%s %%s nw=%%d  gathers %%d cycles, conflicts %%d -> %%d  (%%.0f s)" %% (name, alg, prec, info[0], info[1], info[2], info[3], time.time() - t0), flush=True)
 """
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--moves", type=int, default=1000000000)
+    ap.add_argument("--moves", type=int, default=300000000)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "plans"))
-    ap.add_argument("--codes", nargs="*", default=CODES)
+    ap.add_argument("--codes", nargs="*", default=None, help="default: every *.txt of --codes-dir")
     ap.add_argument("--codes-dir", default=os.path.join(ROOT, "tests", "golden", "codes"))
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="f64: the shapes of the fp64 min-sum kernel")
-    ap.add_argument("--nw", nargs="*", default=["", "1"], help="LDPC_FUSED_NW values to plan for ('' = the default shape)")
+    ap.add_argument("--jobs", type=int, default=max(1, (os.cpu_count() or 2) - 2))
+    ap.add_argument("--nw", default="", help="LDPC_FUSED_NW: plan a non-default number of waves per frame")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
-    procs = []
-    for code in a.codes:
-        for nw in a.nw:  # by default: the default shape and the one-wave-per-frame shape (LDPC_FUSED_NW=1)
-            env = dict(os.environ, LDPC_FUSED_PLAN_MOVES=str(a.moves), LDPC_FUSED_PLAN_SAVE=a.out, LDPC_FUSED_LAYOUT="replan",
-                       FILE_CODES_DIR=a.codes_dir, LDPC_PLAN_PRECISION=a.precision)
-            if nw:
-                env["LDPC_FUSED_NW"] = nw
-            procs.append(subprocess.Popen([sys.executable, "-c", CHILD % dict(root=ROOT, code=code)], env=env))
-    rc = 0
-    for p in procs:
-        rc |= p.wait()
-    print(sorted(os.listdir(a.out)))
+    names = a.codes if a.codes is not None else sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(a.codes_dir, "*.txt")))
+    env = dict(os.environ)
+    if a.nw:
+        env["LDPC_FUSED_NW"] = a.nw
+    todo = [(n, alg, prec) for n in names for alg, prec in SHAPES]
+    running, rc = [], 0
+    while todo or running:
+        while todo and len(running) < a.jobs:
+            n, alg, prec = todo.pop(0)
+            src = CHILD % dict(root=ROOT, code=n, alg=alg, prec=prec, dir=a.codes_dir, moves=a.moves, out=a.out)
+            running.append(subprocess.Popen([sys.executable, "-c", src], env=env))
+        rc |= running.pop(0).wait()
+    print(len(os.listdir(a.out)), "files in", a.out)
     return rc
 
 
