@@ -111,11 +111,21 @@ int ldpc_decode_host(ldpc_decoder_t dec, const void* priors, const uint8_t* y0, 
 int ldpc_channel(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0,
                  int64_t B, int32_t n, void* priors_dev, uint8_t* y_dev, void* stream);
 
+/* The same for a RANDOM codeword per frame -- `--codeword -1`, src/main.py:38: x = code.cb[np.random.choice(K)] -- frame f sends
+ * word floor(w * K / 2^32) of codebook_dev ([K,n] uint8, Code.cb of src/codes.py:11-14, K <= 2^31), w = first Philox word of block
+ * 0xFFFFFFFE of the frame; sent_dev [B,n] uint8 receives the word each frame sent (for ldpc_count_errors_words). */
+int ldpc_channel_words(int channel, int dtype, double param, const uint8_t* codebook_dev, int64_t K, uint64_t seed, uint64_t stream_id,
+                       uint64_t frame0, int64_t B, int32_t n, void* priors_dev, uint8_t* y_dev, uint8_t* sent_dev, void* stream);
+
 /* Monte-Carlo counters of main.test (src/main.py:41-45), ACCUMULATED into counters_dev (int64[4 + hist_bins]):
  * tot += B, wec += #frames with errors, bec += bit errors, iter_sum += sum(iters), hist[min(iters, bins-1)] += 1.
  * `sent_dev` is the transmitted word [n] or NULL for the all-`codeword` word; iters_dev may be NULL. */
 int ldpc_count_errors(const uint8_t* xhat_dev, const uint8_t* sent_dev, int codeword, const int32_t* iters_dev, int64_t B,
                       int32_t n, int32_t hist_bins, int64_t* counters_dev, void* stream);
+
+/* The same against one sent word PER FRAME: sent_dev [B,n] (ldpc_channel_words). */
+int ldpc_count_errors_words(const uint8_t* xhat_dev, const uint8_t* sent_dev, const int32_t* iters_dev, int64_t B, int32_t n,
+                            int32_t hist_bins, int64_t* counters_dev, void* stream);
 
 /* ---- Maximum-likelihood decoding of the short codes by codebook search -----------------------------------------
  * Replaces biawgn.ML (src/biawgn.py:66-78), bsc.ML (src/bsc.py:63-75) and bec.ML (src/bec.py:21-36).  `codebook` is

@@ -153,8 +153,35 @@ class DecoderHandle:
         import torch
 
         st = torch.cuda.current_stream(counters.device).cuda_stream
+        if int(codeword) == -1:
+            return self._simulate_random_words(channel, param, seed, stream_id, frame0, B, max_iter, counters, flags, hist_bins, st)
         _lib.check(_lib.load().ldpc_simulate(self.h, _lib.CHANNEL[channel], float(param), int(codeword), int(seed), int(stream_id),
                                              int(frame0), int(B), int(max_iter), flags, hist_bins, counters.data_ptr(), st))
+
+    def _simulate_random_words(self, channel, param, seed, stream_id, frame0, B, max_iter, counters, flags, hist_bins, st):
+        """``--codeword -1`` (src/main.py:38): every frame sends a random word of the code book (small codes only, as upstream).  A
+        composition on the device -- channel kernel (picks the word, adds the noise) -> decode -> count against the sent words."""
+        import torch
+
+        lib = _lib.load()
+        if getattr(self, "_cb_dev", None) is None:
+            cb = getattr(self.code, "cb", None)
+            if cb is None:
+                raise ValueError("--codeword -1 needs the code book of a small code (Code.cb)")
+            self._cb_dev = torch.from_numpy(np.ascontiguousarray(cb, dtype=np.uint8)).cuda()
+        n, K = self.code.n, int(self._cb_dev.shape[0])
+        dt = torch.float64 if self.precision == "f64" else torch.float32
+        step = 1 << 17
+        for b0 in range(0, int(B), step):
+            nb = min(step, int(B) - b0)
+            pri = None if channel == "bec" else torch.empty((nb, n), dtype=dt, device="cuda")
+            y = None if channel == "biawgn" else torch.empty((nb, n), dtype=torch.uint8, device="cuda")
+            sent = torch.empty((nb, n), dtype=torch.uint8, device="cuda")
+            _lib.check(lib.ldpc_channel_words(_lib.CHANNEL[channel], _lib.DTYPE[self.precision], float(param), self._cb_dev.data_ptr(), K,
+                                              int(seed), int(stream_id), int(frame0) + b0, nb, n, None if pri is None else pri.data_ptr(),
+                                              None if y is None else y.data_ptr(), sent.data_ptr(), st))
+            xhat, iters = self.decode_device(pri, y, max_iter, flags)
+            _lib.check(lib.ldpc_count_errors_words(xhat.data_ptr(), sent.data_ptr(), iters.data_ptr(), nb, n, hist_bins, counters.data_ptr(), st))
 
     def fused_info(self):
         out = (ctypes.c_double * 8)()

@@ -43,6 +43,9 @@ SIGNATURES = {
     "ldpc_decode_host": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P]),
     "ldpc_channel": (_c.c_int, [_c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_int64,
                                 _c.c_int32, _P, _P, _P]),
+    "ldpc_channel_words": (_c.c_int, [_c.c_int, _c.c_int, _c.c_double, _P, _c.c_int64, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_int64,
+                                      _c.c_int32, _P, _P, _P, _P]),
+    "ldpc_count_errors_words": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_int32, _P, _P]),
     "ldpc_count_errors": (_c.c_int, [_P, _P, _c.c_int, _P, _c.c_int64, _c.c_int32, _c.c_int32, _P, _P]),
     "ldpc_debug_copy4": (_c.c_int, [_P, _P, _c.c_int64, _P]),
     "ldpc_simulate": (_c.c_int, [_P, _c.c_int, _c.c_double, _c.c_int, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_int64,

@@ -374,6 +374,24 @@ int ldpc_channel(int channel, int dtype, double param, int codeword, uint64_t se
     return channel_generate(channel, dtype, param, codeword, seed, stream_id, frame0, B, n, priors, y, (hipStream_t)stream);
 }
 
+int ldpc_channel_words(int channel, int dtype, double param, const uint8_t* codebook, int64_t K, uint64_t seed, uint64_t stream_id,
+                       uint64_t frame0, int64_t B, int32_t n, void* priors, uint8_t* y, uint8_t* sent, void* stream) {
+    if (B < 0 || n <= 0 || dtype < 0 || dtype > 1 || !codebook || !sent) {
+        set_error("ldpc_channel_words: bad arguments");
+        return LDPC_E_ARG;
+    }
+    return channel_generate_words(channel, dtype, param, 0, codebook, K, seed, stream_id, frame0, B, n, priors, y, sent, (hipStream_t)stream);
+}
+
+int ldpc_count_errors_words(const uint8_t* xhat, const uint8_t* sent, const int32_t* iters, int64_t B, int32_t n, int32_t hist_bins,
+                            int64_t* counters, void* stream) {
+    if (!xhat || !sent || !counters || B < 0 || n <= 0 || hist_bins < 0) {
+        set_error("ldpc_count_errors_words: bad arguments");
+        return LDPC_E_ARG;
+    }
+    return count_errors_words(xhat, sent, 1, 0, iters, B, n, hist_bins, counters, (hipStream_t)stream);
+}
+
 int ldpc_debug_copy4(const void* src_dev, void* dst_dev, int64_t nbytes, void* stream) {
     if (!src_dev || !dst_dev || nbytes < 0) return LDPC_E_ARG;
     return debug_copy4(src_dev, dst_dev, nbytes, (hipStream_t)stream);

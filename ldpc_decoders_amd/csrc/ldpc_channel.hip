@@ -13,10 +13,22 @@
 namespace ldpc {
 namespace {
 
+// Random codeword of a frame (--codeword -1, src/main.py:38: x = code.cb[np.random.choice(K)]): word floor(w * K / 2^32) of the
+// codebook, w = first Philox word of block 0xFFFFFFFE of the frame (the noise uses blocks 0 .. n/4, the ML tie-break 0xFFFFFFFF).
+struct WordBook {
+    const uint8_t* cb;  // [K, n] bytes in {0,1} (Code.cb, src/codes.py:11-14); null: the all-`codeword` word
+    int64_t K;
+    uint8_t* sent;      // [B, n] out: the word each frame sent
+};
+__device__ __forceinline__ int64_t word_of_frame(const WordBook& wb, uint64_t seed, uint32_t stream, uint64_t frame) {
+    const Philox4 p = philox_word_block(seed, stream, frame, 0xFFFFFFFEu);
+    return (int64_t)(((unsigned long long)p.w[0] * (unsigned long long)wb.K) >> 32);
+}
+
 // one thread = 4 consecutive variables of one frame (one Philox block)
-template <typename T>
+template <typename T, bool WORDS>
 __global__ __launch_bounds__(256) void k_biawgn(double sigma, double inv_var2, int codeword, uint64_t seed, uint32_t stream,
-                                                uint64_t frame0, int64_t B, int n, int blocks_per_frame, T* __restrict__ priors) {
+                                                uint64_t frame0, int64_t B, int n, int blocks_per_frame, T* __restrict__ priors, WordBook wb) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t f = gid / blocks_per_frame;
     const int j = (int)(gid - f * blocks_per_frame);
@@ -25,11 +37,24 @@ __global__ __launch_bounds__(256) void k_biawgn(double sigma, double inv_var2, i
     T z[4];
     box_muller<T>(p.w[0], p.w[1], z[0], z[1]);
     box_muller<T>(p.w[2], p.w[3], z[2], z[3]);
-    const T mean = (T)(2 * codeword - 1), sg = (T)sigma, k = (T)inv_var2;
+    const T sg = (T)sigma, k = (T)inv_var2;
+    T mean4[4];
+    if constexpr (WORDS) {
+        const uint8_t* word = wb.cb + word_of_frame(wb, seed, stream, frame0 + (uint64_t)f) * n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint8_t bit = 4 * j + q < n ? word[4 * j + q] : (uint8_t)0;
+            mean4[q] = (T)(2 * (int)bit - 1);
+            if (4 * j + q < n) wb.sent[f * n + 4 * j + q] = bit;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mean4[q] = (T)(2 * codeword - 1);
+    }
     T out[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const T y = mean + sg * z[q];
+        const T y = mean4[q] + sg * z[q];
         out[q] = -(k * y);  // -2y/sigma^2 with k = 2/sigma^2
     }
     T* dst = priors + f * n + 4 * j;
@@ -48,26 +73,33 @@ __global__ __launch_bounds__(256) void k_biawgn(double sigma, double inv_var2, i
 }
 
 // BSC / BEC: one word per variable; event <=> (w + 0.5) * 2^-32 < p <=> w < thr
-template <typename T, int CH>
+template <typename T, int CH, bool WORDS>
 __global__ __launch_bounds__(256) void k_discrete(uint64_t thr, double llr, int codeword, uint64_t seed, uint32_t stream,
                                                   uint64_t frame0, int64_t B, int n, int blocks_per_frame,
-                                                  T* __restrict__ priors, uint8_t* __restrict__ y) {
+                                                  T* __restrict__ priors, uint8_t* __restrict__ y, WordBook wb) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t f = gid / blocks_per_frame;
     const int j = (int)(gid - f * blocks_per_frame);
     if (f >= B) return;
     const Philox4 p = philox_word_block(seed, stream, frame0 + (uint64_t)f, (uint32_t)j);
+    const uint8_t* word = nullptr;
+    if constexpr (WORDS) word = wb.cb + word_of_frame(wb, seed, stream, frame0 + (uint64_t)f) * n;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int v = 4 * j + q;
         if (v < n) {
             const bool hit = (uint64_t)p.w[q] < thr;
+            int bit = codeword;
+            if constexpr (WORDS) {
+                bit = word[v];
+                wb.sent[f * n + v] = (uint8_t)bit;
+            }
             uint8_t s;
             if constexpr (CH == CH_BSC) {
-                s = (uint8_t)(codeword ^ (hit ? 1 : 0));
+                s = (uint8_t)(bit ^ (hit ? 1 : 0));
                 if (priors) priors[f * n + v] = (T)llr * (T)(1 - 2 * (int)s);
             } else {
-                s = hit ? (uint8_t)2 : (uint8_t)codeword;
+                s = hit ? (uint8_t)2 : (uint8_t)bit;
             }
             y[f * n + v] = s;
         }
@@ -77,7 +109,7 @@ __global__ __launch_bounds__(256) void k_discrete(uint64_t thr, double llr, int 
 // one wavefront per frame, grid-stride; counters are combined per block (LDS) before touching global atomics
 __global__ __launch_bounds__(256) void k_count(const uint8_t* __restrict__ xhat, const uint8_t* __restrict__ sent, int codeword,
                                                const int32_t* __restrict__ iters, int64_t B, int n, int hist_bins,
-                                               unsigned long long* __restrict__ counters) {
+                                               unsigned long long* __restrict__ counters, int sent_per_frame) {
     extern __shared__ unsigned int s_hist[];  // [hist_bins]
     __shared__ unsigned long long s_cnt[4];
     for (int i = threadIdx.x; i < hist_bins; i += 256) s_hist[i] = 0;
@@ -89,7 +121,7 @@ __global__ __launch_bounds__(256) void k_count(const uint8_t* __restrict__ xhat,
         int err = 0;
         const uint8_t* row = xhat + f * n;
         for (int v = lane; v < n; v += 64) {
-            const uint8_t want = sent ? sent[v] : (uint8_t)codeword;
+            const uint8_t want = sent ? sent[sent_per_frame ? f * n + v : v] : (uint8_t)codeword;
             err += row[v] != want;
         }
 #pragma unroll
@@ -133,11 +165,23 @@ int debug_copy4(const void* src, void* dst, int64_t nbytes, hipStream_t st) {
 
 int channel_generate(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0,
                      int64_t B, int32_t n, void* priors, uint8_t* y, hipStream_t st) {
+    return channel_generate_words(channel, dtype, param, codeword, nullptr, 0, seed, stream_id, frame0, B, n, priors, y, nullptr, st);
+}
+
+int channel_generate_words(int channel, int dtype, double param, int codeword, const uint8_t* codebook, int64_t K, uint64_t seed,
+                           uint64_t stream_id, uint64_t frame0, int64_t B, int32_t n, void* priors, uint8_t* y, uint8_t* sent,
+                           hipStream_t st) {
     if (B <= 0) return LDPC_OK;
-    if (codeword != 0 && codeword != 1) {
+    const bool words = codebook != nullptr;
+    if (words && (K <= 0 || K > ((int64_t)1 << 31) || !sent)) {
+        set_error("random-codeword channel: needs 1 <= K <= 2^31 codebook words and the sent-word output buffer");
+        return LDPC_E_ARG;
+    }
+    if (!words && codeword != 0 && codeword != 1) {
         set_error("device channel kernels send the all-zero (0) or all-one (1) word; got codeword=%d", codeword);
         return LDPC_E_ARG;
     }
+    const WordBook wb{codebook, K, sent};
     const bool raw = (channel & CH_RAW_OBSERVATION) != 0;
     channel &= ~CH_RAW_OBSERVATION;
     if (raw && channel != CH_BIAWGN) {
@@ -154,10 +198,13 @@ int channel_generate(int channel, int dtype, double param, int codeword, uint64_
         }
         const double var = pow(10.0, -param / 10.0);  // src/biawgn.py:10
         const double sigma = sqrt(var), k = raw ? -1.0 : 2.0 / var;  // the kernel writes -(k*y): k = -1 hands over y itself
-        if (dtype == DT_F64)
-            hipLaunchKernelGGL(k_biawgn<double>, grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors);
-        else
-            hipLaunchKernelGGL(k_biawgn<float>, grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors);
+        if (dtype == DT_F64) {
+            if (words) hipLaunchKernelGGL((k_biawgn<double, true>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, wb);
+            else hipLaunchKernelGGL((k_biawgn<double, false>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, wb);
+        } else {
+            if (words) hipLaunchKernelGGL((k_biawgn<float, true>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, wb);
+            else hipLaunchKernelGGL((k_biawgn<float, false>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, wb);
+        }
     } else if (channel == CH_BSC || channel == CH_BEC) {
         if (!y) {
             set_error("discrete channels need the y output buffer");
@@ -173,12 +220,16 @@ int channel_generate(int channel, int dtype, double param, int codeword, uint64_
         const uint64_t thr = (uint64_t)t;
         const double llr = log(1.0 - param) - log(param);  // src/bsc.py:21
         if (channel == CH_BSC) {
-            if (dtype == DT_F64)
-                hipLaunchKernelGGL((k_discrete<double, CH_BSC>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, y);
-            else
-                hipLaunchKernelGGL((k_discrete<float, CH_BSC>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, y);
+            if (dtype == DT_F64) {
+                if (words) hipLaunchKernelGGL((k_discrete<double, CH_BSC, true>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, y, wb);
+                else hipLaunchKernelGGL((k_discrete<double, CH_BSC, false>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, y, wb);
+            } else {
+                if (words) hipLaunchKernelGGL((k_discrete<float, CH_BSC, true>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, y, wb);
+                else hipLaunchKernelGGL((k_discrete<float, CH_BSC, false>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, y, wb);
+            }
         } else {
-            hipLaunchKernelGGL((k_discrete<float, CH_BEC>), grid, block, 0, st, thr, 0.0, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)nullptr, y);
+            if (words) hipLaunchKernelGGL((k_discrete<float, CH_BEC, true>), grid, block, 0, st, thr, 0.0, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)nullptr, y, wb);
+            else hipLaunchKernelGGL((k_discrete<float, CH_BEC, false>), grid, block, 0, st, thr, 0.0, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)nullptr, y, wb);
         }
     } else {
         set_error("unknown channel id %d", channel);
@@ -190,6 +241,11 @@ int channel_generate(int channel, int dtype, double param, int codeword, uint64_
 
 int count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const int32_t* iters, int64_t B, int32_t n,
                  int32_t hist_bins, int64_t* counters, hipStream_t st) {
+    return count_errors_words(xhat, sent, 0, codeword, iters, B, n, hist_bins, counters, st);
+}
+
+int count_errors_words(const uint8_t* xhat, const uint8_t* sent, int sent_per_frame, int codeword, const int32_t* iters, int64_t B, int32_t n,
+                       int32_t hist_bins, int64_t* counters, hipStream_t st) {
     if (B <= 0) return LDPC_OK;
     if (hist_bins > 8192) {
         set_error("at most 8192 histogram bins");
@@ -198,7 +254,7 @@ int count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const i
     const int64_t want = (B + 3) / 4;
     const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
     hipLaunchKernelGGL(k_count, dim3(grid), dim3(256), (size_t)hist_bins * sizeof(unsigned int), st, xhat, sent, codeword, iters, B, n,
-                       hist_bins, (unsigned long long*)counters);
+                       hist_bins, (unsigned long long*)counters, sent_per_frame);
     LDPC_HIP_TRY(hipGetLastError());
     return LDPC_OK;
 }

@@ -128,6 +128,10 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
 // ---- channel / counting kernels -------------------------------------------------------------------
 int channel_generate(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id,
                      uint64_t frame0, int64_t B, int32_t n, void* priors, uint8_t* y, hipStream_t st);
+int channel_generate_words(int channel, int dtype, double param, int codeword, const uint8_t* codebook, int64_t K, uint64_t seed,
+                           uint64_t stream_id, uint64_t frame0, int64_t B, int32_t n, void* priors, uint8_t* y, uint8_t* sent, hipStream_t st);
+int count_errors_words(const uint8_t* xhat, const uint8_t* sent, int sent_per_frame, int codeword, const int32_t* iters, int64_t B, int32_t n,
+                       int32_t hist_bins, int64_t* counters, hipStream_t st);
 int count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const int32_t* iters, int64_t B, int32_t n,
                  int32_t max_iter_hist, int64_t* counters, hipStream_t st);
 

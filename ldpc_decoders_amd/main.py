@@ -28,7 +28,9 @@ def test(args, comm=None):
     code = codes.get_code(args.code)
     code_n = code.get_n()
     saver = utils.Saver(args.data_dir, list(zip(id_keys, id_val))) if comm.is_root else None
-    exact = bool(args.exact) or args.codeword == -1
+    # --codeword -1 (a random word of the code book per frame, src/main.py:38): on the device for the BP decoders, the reference's
+    # sequential loop on host noise for the others
+    exact = bool(args.exact) or (args.codeword == -1 and args.decoder not in ("SPA", "MSA"))
     if exact and comm.world > 1:
         raise SystemExit("--exact / --codeword -1 follow the reference's sequential rule and run on a single rank")
     if exact and args.np_seed is not None:
@@ -83,8 +85,8 @@ def test(args, comm=None):
             c = run_point_exact(channel, decoder, x, args.min_wec, chunk=chunk, on_progress=progress, pick_word=pick)
         else:
             handle = decoder.handle if hasattr(decoder, "handle") else decoder.dec.handle
-            if args.codeword not in (0, 1):
-                raise SystemExit("the device channel sends the all-zero or all-one word; use --exact for other --codeword values")
+            if args.codeword == -1 and getattr(code, "cb", None) is None:
+                raise SystemExit("--codeword -1 draws from the code book, which only the small codes have (as upstream)")
             # a decoder that reports statistics (ADMM: iteration histogram, src/main.py:34) gets them from the REDUCED counters, so
             # that `dec` describes the same frames as tot/wec/bec -- the whole job, not rank 0's shard
             own_hist = hasattr(decoder, "stats") and hasattr(inner, "iter")

@@ -93,3 +93,68 @@ def test_rccl_all_reduce_of_the_counters_on_one_gpu(tmp_path):
     assert not outs["plain"]["initialized"]
     assert outs["rccl"]["point"] == outs["plain"]["point"] and outs["rccl"]["point"]["wec"] >= 40
     assert outs["rccl"]["big"] == [i << 40 for i in range(5)] and outs["rccl"]["max"] == 1.5
+
+
+@pytest.mark.parametrize("channel,param,alg", [("biawgn", 3.0, "SPA"), ("bsc", 0.05, "MSA"), ("bec", 0.3, "SPA")])
+def test_random_codeword_per_frame_on_the_device(channel, param, alg):
+    # --codeword -1 (src/main.py:38): every frame sends a random word of the code book.  The device channel picks word
+    # floor(w K / 2^32), w = first Philox word of block 0xFFFFFFFE of the frame (checked against the oracle's integer stream), the
+    # received values are that word + the same noise the all-zero path draws, and the counters equal a host recount.
+    import torch
+
+    import bp_oracle as O
+    from ldpc_decoders_amd import _lib, codes
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    code = codes.get_code("7_4_hamming")
+    cb = np.ascontiguousarray(code.cb, dtype=np.uint8)
+    K, n, B, seed, stream, frame0 = cb.shape[0], code.n, 4096, 99, 5, 1000
+    bp_alg = "BEC" if channel == "bec" else alg
+    h = DecoderHandle(code, bp_alg, "f64", "auto")
+    lib = _lib.load()
+    cbd = torch.from_numpy(cb).cuda()
+    pri = None if channel == "bec" else torch.empty((B, n), dtype=torch.float64, device="cuda")
+    y = None if channel == "biawgn" else torch.empty((B, n), dtype=torch.uint8, device="cuda")
+    sent = torch.empty((B, n), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ldpc_channel_words(_lib.CHANNEL[channel], 1, param, cbd.data_ptr(), K, seed, stream, frame0, B, n,
+                                      None if pri is None else pri.data_ptr(), None if y is None else y.data_ptr(), sent.data_ptr(), st))
+    sent_h = sent.cpu().numpy()
+    want_idx = np.array([(int(O.philox4x32(np.array([[0xFFFFFFFE, stream, (frame0 + f) & 0xFFFFFFFF, (frame0 + f) >> 32]], dtype=np.uint32),
+                                           np.array([[seed & 0xFFFFFFFF, seed >> 32]], dtype=np.uint32))[0, 0]) * K) >> 32 for f in range(B)])
+    assert (sent_h == cb[want_idx]).all() and len(np.unique(want_idx)) == K  # every word of the book is drawn
+    # same noise as the all-zero path, shifted by the word: BI-AWGN priors differ by -2(2x)/sigma^2 per bit; BSC / BEC symbols by the word
+    p0, y0 = h.channel_device(channel, param, 0, seed, stream, frame0, B)
+    if channel == "biawgn":
+        var = O.biawgn_noise_var(param)
+        assert np.allclose(pri.cpu().numpy(), p0.cpu().numpy() - 4.0 * sent_h / var, rtol=1e-12, atol=1e-12)
+    elif channel == "bsc":
+        assert ((y.cpu().numpy() ^ y0.cpu().numpy()) == sent_h).all()
+    else:
+        yy, y00 = y.cpu().numpy(), y0.cpu().numpy()
+        assert ((yy == 2) == (y00 == 2)).all() and (yy[yy != 2] == sent_h[yy != 2]).all()
+    # whole path: DecoderHandle.simulate(codeword=-1) == decode of those very frames + host recount
+    cnt = torch.zeros(4 + 11, dtype=torch.int64, device="cuda")
+    h.simulate(channel, param, -1, seed, stream, frame0, B, 10, cnt, hist_bins=11)
+    xhat, iters = h.decode_device(pri, y, 10)
+    xh, it = xhat.cpu().numpy(), iters.cpu().numpy()
+    err = (xh != sent_h).sum(axis=1)
+    c = cnt.cpu().numpy()
+    assert c[0] == B and c[1] == (err > 0).sum() and c[2] == err.sum() and c[3] == it.sum()
+    assert (c[4:] == np.bincount(np.minimum(it, 10), minlength=11)).all()
+    assert 0 < c[1] < B  # the operating point has both outcomes
+
+
+def test_main_py_random_codeword_runs_on_the_device(tmp_path):
+    # `main.py bsc 7_4_hamming MSA --codeword -1` without --exact: device Monte-Carlo; WER close to the all-zero word's (min-sum over
+    # the BSC is symmetric in the sent word up to its tie rule)
+    from ldpc_decoders_amd import main as M
+
+    res = {}
+    for cw in ("-1", "0"):
+        r = M.main(["biawgn", "7_4_hamming", "SPA", "--codeword", cw, "--min-wec", "3000", "--max-iter", "10", "--params", "3", "--seed", "7",
+                    "--data_dir", str(tmp_path), "--console"])
+        res[cw] = r[3.0]
+    assert res["-1"]["wec"] >= 3000 and res["0"]["wec"] >= 3000
+    # fp32 sum-product over BI-AWGN is codeword-symmetric: both runs estimate the same word-error rate
+    assert abs(res["-1"]["wer"] - res["0"]["wer"]) < 0.1 * res["0"]["wer"]

@@ -243,3 +243,33 @@ def test_irregular_ensembles_match_the_reference_node_counts():
     assert {int(k): v for k, v in want["5"]["node_counts"]["1200"].items()} == {2: 742, 3: 211, 4: 107, 7: 58, 8: 80}
     code = codes.rand_irregular_ldpc(1200, codes.LAMBDA_HALF_RATE[6], 7, np.random.RandomState(15))
     assert code.n == 1200 and code.row_degrees().max() == 7 and code.col_degrees().max() <= 16
+
+
+def test_host_only_layout_planning_and_plan_store(tmp_path):
+    # ldpc_plan_layout needs no GPU: shape choice + annealed LDS placement, stored as <key>.plan; a second call with the store
+    # directory on the search path would load it.  The plan of the headline code must beat the trivial placement by far.
+    import ctypes
+
+    from ldpc_decoders_amd import _lib, codes
+
+    lib = _lib.load()
+    code = codes.load_parity_mtx(os.path.join(ROOT, "tests", "golden", "codes", "1200_3_6_rand_ldpc_1.txt"))
+    chk = np.ascontiguousarray(code.edge_chk, dtype=np.int32)
+    var = np.ascontiguousarray(code.edge_var, dtype=np.int32)
+    info = (ctypes.c_double * 4)()
+    for alg, dtype, waves in ((0, 0, 2), (0, 1, 2), (1, 1, 2)):  # fp32 (all algorithms share it), fp64 min-sum, fp64 sum-product (fixed edge order)
+        out = tmp_path / ("plans_%d_%d" % (alg, dtype))
+        out.mkdir()
+        _lib.check(lib.ldpc_plan_layout(code.m, code.n, code.E, chk.ctypes.data, var.ctypes.data, alg, dtype, 400000, str(out).encode(), info))
+        assert info[0] == waves and info[1] == 240 and info[2] == 540  # waves per frame, conflict-free gather cycles, trivial placement
+        assert 0 < info[3] < 0.75 * info[2]
+        files = os.listdir(out)
+        assert len(files) == 1 and files[0].endswith(".plan") and os.path.getsize(out / files[0]) > 4 * (code.m + code.n + 2 * code.E)
+    # a graph no fused shape exists for: reported as such, nothing written
+    big = codes.rand_reg_ldpc(20000, 3, 6, np.random.RandomState(1))
+    _lib.check(lib.ldpc_plan_layout(big.m, big.n, big.E, np.ascontiguousarray(big.edge_chk, dtype=np.int32).ctypes.data,
+                                    np.ascontiguousarray(big.edge_var, dtype=np.int32).ctypes.data, 0, 0, 1000, None, info))
+    assert info[0] == 0
+    # a malformed edge list is refused with the graph error of ldpc_code_create
+    rc = lib.ldpc_plan_layout(2, 2, 3, np.array([0, 1, 0], dtype=np.int32).ctypes.data, np.array([0, 1, 1], dtype=np.int32).ctypes.data, 0, 0, 1000, None, info)
+    assert rc == -3 and b"row-major" in lib.ldpc_last_error()

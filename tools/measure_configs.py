@@ -15,7 +15,7 @@ import torch  # noqa: E402
 from bench import load_code  # noqa: E402
 from ldpc_decoders_amd._device import DecoderHandle  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 CASES = [  # config, code, decoder alg, channel, param, batch, steps, backend[, precision]
     ("2: n=1200 (3,6) MSA BI-AWGN, fp64 (the reference's arithmetic, bit-identical decisions)", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 1.0, 65536, 6, "auto", "f64"),
     ("2: n=1200 (3,6) MSA BI-AWGN, fp64 (the reference's arithmetic, bit-identical decisions)", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 2.0, 65536, 6, "auto", "f64"),
@@ -23,11 +23,15 @@ CASES = [  # config, code, decoder alg, channel, param, batch, steps, backend[, 
     ("2: n=1200 (3,6) MSA BI-AWGN, fp32 mode", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 2.0, 65536, 6, "auto"),
     ("3: n=1200 (3,6) SPA BSC", "1200_3_6_rand_ldpc_1", "SPA", "bsc", 0.07, 65536, 6, "auto"),
     ("3: n=1200 (3,6) SPA BSC", "1200_3_6_rand_ldpc_1", "SPA", "bsc", 0.05, 65536, 6, "auto"),
+    ("3: n=1200 (3,6) SPA BI-AWGN, fp64 (the reference's formula verbatim, LDS kernel)", "1200_3_6_rand_ldpc_1", "SPA", "biawgn", 1.5, 65536, 3, "auto", "f64"),
+    ("3: n=1200 (3,6) SPA BI-AWGN, fp64, streaming kernels", "1200_3_6_rand_ldpc_1", "SPA", "biawgn", 1.5, 16384, 1, "stream", "f64"),
     ("3: n=1200 (3,6) erasure decoder BEC", "1200_3_6_rand_ldpc_1", "BEC", "bec", 0.40, 65536, 6, "auto"),
     ("3: n=1200 (3,6) erasure decoder BEC", "1200_3_6_rand_ldpc_1", "BEC", "bec", 0.35, 65536, 6, "auto"),
     ("4: rate-1/2 irregular n=10000 MSA (2^20 frames over 8 GPUs = 131072 per GPU)", "gen:irg:10000", "MSA", "biawgn", 1.2, 131072, 2, "auto"),
     ("4: rate-1/2 irregular n=10000 MSA (2^20 frames over 8 GPUs = 131072 per GPU)", "gen:irg:10000", "MSA", "biawgn", 1.8, 131072, 2, "auto"),
     ("4: same, streaming kernels", "gen:irg:10000", "MSA", "biawgn", 1.2, 32768, 1, "stream"),
+    ("4: same, streaming kernels (frames leave after 11..50 sweeps: per-frame early termination by frame repack)", "gen:irg:10000", "MSA", "biawgn", 1.8, 32768, 1, "stream"),
+    ("4: same, fp64 (the reference's arithmetic; 327 KB per frame: streaming kernels)", "gen:irg:10000", "MSA", "biawgn", 1.8, 32768, 1, "auto", "f64"),
     ("5: (3,6) n=64800 MSA, early termination (2^18 frames over 8 GPUs = 32768 per GPU)", "gen:reg:64800:3:6", "MSA", "biawgn", 1.0, 32768, 1, "auto"),
     ("5: (3,6) n=64800 MSA, early termination (2^18 frames over 8 GPUs = 32768 per GPU)", "gen:reg:64800:3:6", "MSA", "biawgn", 2.0, 32768, 1, "auto"),
 ]
@@ -54,7 +58,7 @@ for case in CASES:
     frames, sweeps = int(c[0]), int(c[3])
     bytes_fs = (8 if prec == "f64" else 4) * (4 * g.E + g.n) if alg != "BEC" else (4 * g.E + g.n)
     rows.append(dict(config=cfg, code=code_name, n=g.n, E=g.E, decoder=alg, precision=prec, channel=ch, param=prm, max_iter=50, frames_per_step=B, steps=steps,
-                     backend=h.last_stats()[0], waves_per_frame=h.fused_info()["waves_per_frame"] if h.last_stats()[0] == "fused" else 0,
+                     backend=h.last_stats()[0], repacks=h.last_repacks(), waves_per_frame=h.fused_info()["waves_per_frame"] if h.last_stats()[0] == "fused" else 0,
                      frames_per_s=round(frames / dt, 1), ms_per_step=round(1e3 * dt / steps, 3), mean_sweeps=round(sweeps / frames, 3),
                      wer=round(int(c[1]) / frames, 6), ber=int(c[2]) / (frames * g.n),
                      algorithmic_GBps=round(sweeps * bytes_fs / dt / 1e9, 1)))
