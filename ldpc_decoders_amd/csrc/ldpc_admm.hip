@@ -83,7 +83,7 @@ __device__ void pp_project(AD v, AD s, AD c, AD bp, AI who, AI bp_who, int len) 
     int r = (int)floor(mass);
     if (r & 1) --r;
     double facet = 0;
-    for (int i = 0; i < r + 1; ++i) facet += c[i];
+    for (int i = 0; i < r + 1 && i < len; ++i) facet += c[i];  // r == len: upstream reads c[len] (projection.cpp:79-80); taken as 0 here
     for (int i = r + 1; i < len; ++i) facet -= c[i];
     if (facet <= r) {
         for (int i = 0; i < len; ++i) v[who[i]] = c[i];
@@ -154,6 +154,148 @@ __device__ void pp_project(AD v, AD s, AD c, AD bp, AI who, AI bp_who, int len) 
     else
         beta = -(r - prev_clip - 1 - prev_active) / (prev_zero - prev_clip - 1);
     for (int i = 0; i < len; ++i) v[who[i]] = clamp01(i <= r ? s[i] - beta : s[i] + beta);
+}
+
+// The same projection for a check of exactly L edges, entirely in registers: every loop is unrolled over the L positions and
+// predicated, the sort is an odd-even transposition network (adjacent compare-exchanges with a strict comparison never reorder
+// equal values, i.e. the same stable decreasing order as the insertion sort above), the two data-dependent reads of the merge
+// are select chains.  No LDS arrays -> the kernel's occupancy is set by its registers alone (k_admm_z_fixed).  Same arithmetic,
+// operation by operation, as pp_project: results are bit-identical.
+template <int L>
+__device__ __forceinline__ double dyn_get(const double (&a)[L], int idx) {
+    double r = a[0];
+#pragma unroll
+    for (int i = 1; i < L; ++i) r = (idx == i) ? a[i] : r;
+    return r;
+}
+
+template <int L>
+__device__ __forceinline__ void pp_project_fixed(double (&v)[L]) {
+    bool none_positive = true, all_above_one = true;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        if (v[i] > 0) none_positive = false;
+        if (v[i] <= 1) all_above_one = false;
+    }
+    if (none_positive) {
+#pragma unroll
+        for (int i = 0; i < L; ++i) v[i] = 0;
+        return;
+    }
+    if (L % 2 == 0 && all_above_one) {
+#pragma unroll
+        for (int i = 0; i < L; ++i) v[i] = 1;
+        return;
+    }
+    double s[L];
+    int who[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        s[i] = v[i];
+        who[i] = i;
+    }
+#pragma unroll
+    for (int round = 0; round < L; ++round) {
+#pragma unroll
+        for (int i = round & 1; i + 1 < L; i += 2) {
+            const bool sw = s[i + 1] > s[i];
+            const double hi = sw ? s[i + 1] : s[i], lo = sw ? s[i] : s[i + 1];
+            const int wh = sw ? who[i + 1] : who[i], wl = sw ? who[i] : who[i + 1];
+            s[i] = hi; s[i + 1] = lo;
+            who[i] = wh; who[i + 1] = wl;
+        }
+    }
+    double mass = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) mass += clamp01(s[i]);
+    int r = (int)floor(mass);
+    if (r & 1) --r;
+    double facet = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) facet = (i <= r) ? facet + clamp01(s[i]) : facet - clamp01(s[i]);
+    // r == L (even L, every entry clips to 1): upstream reads one element past its arrays here (projection.cpp:79-80); the
+    // all-ones point is a vertex of the polytope, and with that element taken as 0 the facet test returns it
+    if (facet <= r) {
+#pragma unroll
+        for (int i = 0; i < L; ++i) v[i] = clamp01(v[i]);  // == v[who[i]] = clamp01(s[i])
+        return;
+    }
+    // members of the first r+1 sorted positions, as a bit mask over the original positions
+    unsigned inset = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) inset |= (i <= r) ? (1u << who[i]) : 0u;
+    const double s_r = dyn_get<L>(s, r);
+    const double beta_cap = (r + 2 <= L) ? (s_r - dyn_get<L>(s, r + 1 < L ? r + 1 : L - 1)) / 2 : s_r;
+    // break points, ascending: s[i] - 1 for i = r..0 merged with -s[i] for i = r+1..L-1 (ties: the left sequence first)
+    double bp[L], bs[L];  // bs[k] = s[bp_who[k]]
+    bool bleft[L];        // bp_who[k] <= r
+    {
+        int lp = r, rp = r + 1;
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            const double sl = dyn_get<L>(s, lp < 0 ? 0 : lp), sr = dyn_get<L>(s, rp >= L ? L - 1 : rp);
+            const double a = sl - 1, b = -sr;
+            const bool take_right = lp < 0 || (rp < L && a > b);
+            bp[k] = take_right ? b : a;
+            bs[k] = take_right ? sr : sl;
+            bleft[k] = !take_right;
+            if (take_right) ++rp; else --lp;
+        }
+    }
+    const double tol = 1e-10;
+    int clip = -1, zero = 0, first = 0, last = -1;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        if (s[i] > 1) ++clip;
+        if (s[i] >= 0 - tol) ++zero;
+        if (bp[i] < 0 + tol) ++first;
+        if (bp[i] < beta_cap) ++last;
+    }
+    double active = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        if (i > clip && i <= r) active += s[i];
+        if (i > r && i < zero) active -= s[i];
+    }
+    double total = active + clip + 1;
+    int prev_clip = clip, prev_zero = zero;
+    bool fresh = true, running = true;
+    double prev_active = active, beta = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        if (running && i >= first && i <= last) {
+            if (fresh) {
+                prev_clip = clip;
+                prev_zero = zero;
+                prev_active = active;
+            }
+            fresh = false;
+            beta = bp[i];
+            if (bleft[i]) {
+                --clip;
+                active += bs[i];
+            } else {
+                ++zero;
+                active -= bs[i];
+            }
+            if (i < L - 1) {
+                if (beta != bp[i + 1 < L ? i + 1 : i]) {
+                    total = (clip + 1) + active - beta * (zero - clip - 1);
+                    fresh = true;
+                    if (total < r) running = false;
+                }
+            } else {
+                total = (clip + 1) + active - beta * (zero - clip - 1);
+                fresh = true;
+            }
+        }
+    }
+    if (total > r)
+        beta = -(r - clip - 1 - active) / (zero - clip - 1);
+    else
+        beta = -(r - prev_clip - 1 - prev_active) / (prev_zero - prev_clip - 1);
+#pragma unroll
+    for (int i = 0; i < L; ++i) v[i] = clamp01(((inset >> i) & 1u) ? v[i] - beta : v[i] + beta);
 }
 
 // gamma [B,n] -> gam[tile][n][64]; state: z = 0.5, lambda = 0 (src/admm.py:44)
@@ -254,6 +396,41 @@ __global__ __launch_bounds__(LDSARR ? 128 : 256) void k_admm_z(const int32_t* __
                 d2[o] = b * b;
                 z[o] = v[j];
             }
+        }
+    }
+}
+
+// The same for codes whose checks all have exactly L edges: register-only projection, edge k0 + j of check c at c * L + j
+template <int L>
+__global__ __launch_bounds__(256) void k_admm_z_fixed(const int32_t* __restrict__ edge_var, double* __restrict__ z, double* __restrict__ lam,
+                                                      const double* __restrict__ x, double* __restrict__ d1, double* __restrict__ d2,
+                                                      const u64* __restrict__ live, int m, int n, int64_t E, double mu) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.y;
+    const u64 lv = live[tile];
+    if (lv == 0 || !((lv >> lane) & 1ull)) return;
+    const int64_t eb = (int64_t)tile * E * 64 + lane;
+    const double* xt = x + (int64_t)tile * n * 64 + lane;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < m; c += gridDim.x * 4) {
+        const int k0 = c * L;
+        double xs[L], lm[L], zo[L], v[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            xs[j] = xt[(int64_t)edge_var[k0 + j] * 64];
+            lm[j] = lam[eb + (int64_t)(k0 + j) * 64];
+            zo[j] = z[eb + (int64_t)(k0 + j) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < L; ++j) v[j] = xs[j] + lm[j] / mu;
+        pp_project_fixed<L>(v);
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int64_t o = eb + (int64_t)(k0 + j) * 64;
+            lam[o] = lm[j] + mu * (xs[j] - v[j]);
+            const double a = xs[j] - v[j], b = zo[j] - v[j];
+            d1[o] = a * a;
+            d2[o] = b * b;
+            z[o] = v[j];
         }
     }
 }
@@ -450,7 +627,17 @@ int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, doubl
     for (int it = 0; it < cap; ++it) {
         hipLaunchKernelGGL(k_admm_x, dim3(gv, tiles), dim3(256), 0, st, c->d_col_ptr, c->d_col_edge, z, lam, gam, x, live, n, E, tiles, mu);
         static const bool lds_arrays = !(std::getenv("LDPC_ADMM_REGARR") && std::getenv("LDPC_ADMM_REGARR")[0] == '1');
-        if (c->max_dc <= 8 && lds_arrays) {
+        static const bool fixed_ok = !(std::getenv("LDPC_ADMM_FIXED") && std::getenv("LDPC_ADMM_FIXED")[0] == '0');
+        const int Lfix = (fixed_ok && c->min_dc == c->max_dc && c->max_dc >= 2 && c->max_dc <= 8) ? c->max_dc : 0;
+        if (Lfix) {  // every check has the same degree: the register-only projection
+#define LDPC_ADMM_FIXED_CASE(LL) \
+    case LL: hipLaunchKernelGGL((k_admm_z_fixed<LL>), dim3(gc, tiles), dim3(256), 0, st, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu); break;
+            switch (Lfix) {
+                LDPC_ADMM_FIXED_CASE(2) LDPC_ADMM_FIXED_CASE(3) LDPC_ADMM_FIXED_CASE(4) LDPC_ADMM_FIXED_CASE(5)
+                LDPC_ADMM_FIXED_CASE(6) LDPC_ADMM_FIXED_CASE(7) LDPC_ADMM_FIXED_CASE(8)
+            }
+#undef LDPC_ADMM_FIXED_CASE
+        } else if (c->max_dc <= 8 && lds_arrays) {
             const unsigned gcl = (unsigned)((m + 1) / 2 < 1024 ? (m + 1) / 2 : 1024);
             hipLaunchKernelGGL((k_admm_z<8, true>), dim3(gcl, tiles), dim3(128), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
         } else if (c->max_dc <= 8) {

@@ -89,7 +89,7 @@ int oracle_pp_project(int len, const double* v, double* out) {
     int r = (int)floor(mass);
     if (r & 1) --r;
     double facet = 0;
-    for (int i = 0; i < r + 1; ++i) facet += c[i];
+    for (int i = 0; i < r + 1 && i < len; ++i) facet += c[i]; /* r == len: upstream reads one element past its arrays (projection.cpp:79-80); taken as 0 */
     for (int i = r + 1; i < len; ++i) facet -= c[i];
     if (facet <= r) { /* the cube projection already satisfies the facet inequality */
         for (int i = 0; i < len; ++i) out[who[i]] = c[i];
