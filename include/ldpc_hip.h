@@ -165,6 +165,9 @@ int ldpc_admm_destroy(ldpc_admm_t admm);
 int ldpc_admm_decode(ldpc_admm_t admm, const double* gamma_dev, int64_t B, double mu, double eps, int32_t max_iter, double* x_dev,
                      int32_t* iters_dev, uint8_t* converged_dev, void* stream);
 
+/* how often the last ldpc_admm_decode gathered its live frames into dense tiles (frames leave one by one, src/admm.py:65-66) */
+int ldpc_admm_last_repacks(ldpc_admm_t admm, int* repacks);
+
 /* Profiling aid: coalesced 4-byte-per-lane device copy of a known size, used to calibrate the profiler's HBM byte
  * counters for the access width of the streaming kernels. */
 int ldpc_debug_copy4(const void* src_dev, void* dst_dev, int64_t nbytes, void* stream);

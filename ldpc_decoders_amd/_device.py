@@ -311,6 +311,12 @@ class AdmmHandle:
     # knobs of the simulate() composition below, set by admm.ADMM
     mu, eps, allow_pseudo, on_iters = 3.0, 1e-5, False, None
 
+    def last_repacks(self):
+        """How often the last decode re-formed its tiles from the live frames."""
+        r = ctypes.c_int(0)
+        _lib.check(_lib.load().ldpc_admm_last_repacks(self.h, ctypes.byref(r)))
+        return r.value
+
     def simulate(self, channel, param, codeword, seed, stream_id, frame0, B, max_iter, counters, flags=0, hist_bins=0):
         """Same call shape as DecoderHandle.simulate: device channel kernel -> LLRs -> ADMM -> pseudo_to_cw -> counters, all
         on the GPU (a composition of ldpc_channel / ldpc_admm_decode / torch element-wise ops; no host noise)."""

@@ -10,6 +10,7 @@
 // projection with the same stable decreasing sort and water-filling steps -- so estimates and iteration counts are
 // bit-identical to the reference's (golden vectors, tests/test_gpu_admm.py).  oracle/admm_oracle.c is the CPU statement.
 #include "ldpc_common.hpp"
+#include "ldpc_repack.hpp"
 
 #include <cstdlib>
 #include <new>
@@ -20,6 +21,8 @@ namespace ldpc {
 struct AdmmDecoder {
     Code* code = nullptr;
     DevBuf z, lam, d1, d2, x, gam, live, flags, part;
+    DevBuf z2, lam2, x2, gam2, live2, fmap, fmap2, rbase;  // second state set + frame maps of the repack (ldpc_repack.hpp)
+    int last_repacks = 0;
     int32_t* d_leaf_off = nullptr;  // numpy's summation blocks of a length-E vector
     int32_t* d_leaf_len = nullptr;
     int32_t* d_prog = nullptr;      // stack program folding the block sums (see k_admm_test)
@@ -478,7 +481,8 @@ __global__ __launch_bounds__(256) void k_admm_leaves(const double* __restrict__ 
 // stopping test (src/admm.py:21, 65) and the max_iter exit of the next loop head (src/admm.py:51); one wave per tile
 __global__ __launch_bounds__(64) void k_admm_test(const double* __restrict__ part, const int32_t* __restrict__ prog, int prog_len, int leaves,
                                                   u64* __restrict__ live, int32_t* __restrict__ iters, uint8_t* __restrict__ converged,
-                                                  int* __restrict__ live_tiles, int64_t B, double thresh, int it, int max_iter) {
+                                                  int* __restrict__ live_tiles, int64_t B, double thresh, int it, int max_iter,
+                                                  const int32_t* __restrict__ frame_of) {
     const int tile = blockIdx.x, lane = threadIdx.x;
     const u64 lv = live[tile];
     if (lv == 0) return;
@@ -504,8 +508,8 @@ __global__ __launch_bounds__(64) void k_admm_test(const double* __restrict__ par
         close = aa1 < thresh && aa2 < thresh;
     }
     const bool capped = max_iter > 0 && it + 1 >= max_iter;
-    const int64_t fr = (int64_t)tile * 64 + lane;
-    if (on && fr < B) {
+    const int64_t fr = frame_of ? (int64_t)frame_of[(int64_t)tile * 64 + lane] : (int64_t)tile * 64 + lane;
+    if (on && fr >= 0 && fr < B) {
         if (close) {
             iters[fr] = it;
             if (converged) converged[fr] = 1;
@@ -517,15 +521,52 @@ __global__ __launch_bounds__(64) void k_admm_test(const double* __restrict__ par
     const u64 stay = lv & ~leave;
     if (lane == 0) {
         live[tile] = stay;
-        if (stay && live_tiles) atomicAdd(live_tiles, 1);
+        if (stay && live_tiles) {
+            atomicAdd(live_tiles, 1);
+            atomicAdd(live_tiles + 1, __popcll(stay));
+        }
     }
 }
 
-__global__ void k_admm_out(const double* __restrict__ x, double* __restrict__ out, int64_t B, int n) {
+__global__ void k_admm_out(const double* __restrict__ x, double* __restrict__ out, int64_t B, int n, const int32_t* __restrict__ frame_of) {
     const int tile = blockIdx.y, lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t fr = (int64_t)tile * 64 + lane;
-    if (v < n && fr < B) out[fr * n + v] = x[((int64_t)tile * n + v) * 64 + lane];
+    const int64_t fr = frame_of ? (int64_t)frame_of[(int64_t)tile * 64 + lane] : (int64_t)tile * 64 + lane;
+    if (v < n && fr >= 0 && fr < B) out[fr * n + v] = x[((int64_t)tile * n + v) * 64 + lane];
+}
+
+// live frames -> dense tiles: z, lambda (E lines each) and x, gamma (n lines each) of the frame of rank j move to (j / 64, j % 64)
+__global__ __launch_bounds__(256) void k_admm_repack(const double* __restrict__ z_s, double* __restrict__ z_d, const double* __restrict__ l_s,
+                                                     double* __restrict__ l_d, const double* __restrict__ x_s, double* __restrict__ x_d,
+                                                     const double* __restrict__ g_s, double* __restrict__ g_d, const u64* __restrict__ live_src,
+                                                     u64* __restrict__ live_dst, const int32_t* __restrict__ base,
+                                                     const int32_t* __restrict__ frame_src, int32_t* __restrict__ frame_dst, int tiles_src, int n,
+                                                     int64_t E, int rows_per_wave) {
+    const int lane = threadIdx.x;
+    const int dt = blockIdx.y;
+    int st, sl;
+    const bool has = repack_source(base, live_src, tiles_src, dt * 64 + lane, &st, &sl);
+    const int chunk = blockIdx.x * 4 + threadIdx.y;
+    const int64_t rows = E + n;
+    const int64_t r0 = (int64_t)chunk * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
+    if (has) {
+        const int64_t es = (int64_t)st * E * 64 + sl, ed = (int64_t)dt * E * 64 + lane;
+        const int64_t vs = (int64_t)st * n * 64 + sl, vd = (int64_t)dt * n * 64 + lane;
+        for (int64_t r = r0; r < r1; ++r) {
+            if (r < E) {
+                z_d[ed + r * 64] = z_s[es + r * 64];
+                l_d[ed + r * 64] = l_s[es + r * 64];
+            } else {
+                x_d[vd + (r - E) * 64] = x_s[vs + (r - E) * 64];
+                g_d[vd + (r - E) * 64] = g_s[vs + (r - E) * 64];
+            }
+        }
+    }
+    if (chunk == 0) {
+        frame_dst[(int64_t)dt * 64 + lane] = has ? (frame_src ? frame_src[(int64_t)st * 64 + sl] : st * 64 + sl) : -1;
+        const u64 lv = __ballot(has);
+        if (lane == 0) live_dst[dt] = lv;
+    }
 }
 
 }  // namespace
@@ -575,9 +616,13 @@ int admm_create(Code* code, AdmmDecoder** out) {
     return LDPC_OK;
 }
 
+int admm_last_repacks(const AdmmDecoder* d) { return d ? d->last_repacks : 0; }
+
 void admm_destroy(AdmmDecoder* d) {
     if (!d) return;
-    for (DevBuf* b : {&d->z, &d->lam, &d->d1, &d->d2, &d->x, &d->gam, &d->live, &d->flags, &d->part}) b->release();
+    for (DevBuf* b : {&d->z, &d->lam, &d->d1, &d->d2, &d->x, &d->gam, &d->live, &d->flags, &d->part, &d->z2, &d->lam2, &d->x2, &d->gam2, &d->live2, &d->fmap, &d->fmap2,
+                      &d->rbase})
+        b->release();
     for (void* q : {(void*)d->d_leaf_off, (void*)d->d_leaf_len, (void*)d->d_prog})
         if (q) (void)hipFree(q);
     if (d->pinned) (void)hipHostFree(d->pinned);
@@ -623,15 +668,29 @@ int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, doubl
     const double thresh = (eps * eps) * (double)E;  // (eps ** 2) * parity_mtx.sum()   (src/admm.py:14)
     const int cap = max_iter > 0 ? max_iter : 100000;  // max_iter <= 0: no cap upstream (src/admm.py:51); bounded here
     const unsigned gv = (unsigned)((n + 3) / 4 < 512 ? (n + 3) / 4 : 512), gc = (unsigned)((m + 3) / 4 < 512 ? (m + 3) / 4 : 512);
+    // frame repack (ldpc_repack.hpp): frames leave one by one (src/admm.py:65-66) while the frames that never converge run into the
+    // iteration cap -- at 2.2 dB a frame needs 64 iterations on average, 4.5 % of them all 300, and nearly every tile holds one
+    bool repack_ok = true;
+    double repack_fill = 0.75;
+    if (const char* e = std::getenv("LDPC_STREAM_REPACK")) repack_ok = atoi(e) != 0;
+    if (const char* e = std::getenv("LDPC_STREAM_REPACK_FILL")) repack_fill = atof(e);
+    DevBuf* set_z[2] = {&d->z, &d->z2};
+    DevBuf* set_l[2] = {&d->lam, &d->lam2};
+    DevBuf* set_x[2] = {&d->x, &d->x2};
+    DevBuf* set_g[2] = {&d->gam, &d->gam2};
+    DevBuf* set_live[2] = {&d->live, &d->live2};
+    DevBuf* set_fmap[2] = {&d->fmap, &d->fmap2};
+    int cur = 0, cur_tiles = tiles, repacks = 0;
+    int32_t* fmap = nullptr;
     int done = 0;
     for (int it = 0; it < cap; ++it) {
-        hipLaunchKernelGGL(k_admm_x, dim3(gv, tiles), dim3(256), 0, st, c->d_col_ptr, c->d_col_edge, z, lam, gam, x, live, n, E, tiles, mu);
+        hipLaunchKernelGGL(k_admm_x, dim3(gv, cur_tiles), dim3(256), 0, st, c->d_col_ptr, c->d_col_edge, z, lam, gam, x, live, n, E, cur_tiles, mu);
         static const bool lds_arrays = !(std::getenv("LDPC_ADMM_REGARR") && std::getenv("LDPC_ADMM_REGARR")[0] == '1');
         static const bool fixed_ok = !(std::getenv("LDPC_ADMM_FIXED") && std::getenv("LDPC_ADMM_FIXED")[0] == '0');
         const int Lfix = (fixed_ok && c->min_dc == c->max_dc && c->max_dc >= 2 && c->max_dc <= 8) ? c->max_dc : 0;
         if (Lfix) {  // every check has the same degree: the register-only projection
 #define LDPC_ADMM_FIXED_CASE(LL) \
-    case LL: hipLaunchKernelGGL((k_admm_z_fixed<LL>), dim3(gc, tiles), dim3(256), 0, st, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu); break;
+    case LL: hipLaunchKernelGGL((k_admm_z_fixed<LL>), dim3(gc, cur_tiles), dim3(256), 0, st, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu); break;
             switch (Lfix) {
                 LDPC_ADMM_FIXED_CASE(2) LDPC_ADMM_FIXED_CASE(3) LDPC_ADMM_FIXED_CASE(4) LDPC_ADMM_FIXED_CASE(5)
                 LDPC_ADMM_FIXED_CASE(6) LDPC_ADMM_FIXED_CASE(7) LDPC_ADMM_FIXED_CASE(8)
@@ -639,26 +698,56 @@ int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, doubl
 #undef LDPC_ADMM_FIXED_CASE
         } else if (c->max_dc <= 8 && lds_arrays) {
             const unsigned gcl = (unsigned)((m + 1) / 2 < 1024 ? (m + 1) / 2 : 1024);
-            hipLaunchKernelGGL((k_admm_z<8, true>), dim3(gcl, tiles), dim3(128), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
+            hipLaunchKernelGGL((k_admm_z<8, true>), dim3(gcl, cur_tiles), dim3(128), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
         } else if (c->max_dc <= 8) {
-            hipLaunchKernelGGL((k_admm_z<8, false>), dim3(gc, tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
+            hipLaunchKernelGGL((k_admm_z<8, false>), dim3(gc, cur_tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
         } else {
-            hipLaunchKernelGGL((k_admm_z<16, false>), dim3(gc, tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
+            hipLaunchKernelGGL((k_admm_z<16, false>), dim3(gc, cur_tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
         }
         const bool poll = (it % 8) == 7 || it + 1 == cap;
-        if (poll) LDPC_HIP_TRY(hipMemsetAsync(live_tiles, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_admm_leaves, dim3((d->leaves + 3) / 4, tiles), dim3(256), 0, st, d1, d2, d->d_leaf_off, d->d_leaf_len, d->leaves,
+        if (poll) LDPC_HIP_TRY(hipMemsetAsync(live_tiles, 0, 2 * sizeof(int), st));
+        hipLaunchKernelGGL(k_admm_leaves, dim3((d->leaves + 3) / 4, cur_tiles), dim3(256), 0, st, d1, d2, d->d_leaf_off, d->d_leaf_len, d->leaves,
                            (double*)d->part.p, live, E);
-        hipLaunchKernelGGL(k_admm_test, dim3(tiles), dim3(64), 0, st, (const double*)d->part.p, d->d_prog, d->prog_len, d->leaves, live, iters,
-                           converged, poll ? live_tiles : nullptr, B, thresh, it, it + 1 == cap ? it + 1 : max_iter);
+        hipLaunchKernelGGL(k_admm_test, dim3(cur_tiles), dim3(64), 0, st, (const double*)d->part.p, d->d_prog, d->prog_len, d->leaves, live, iters,
+                           converged, poll ? live_tiles : nullptr, B, thresh, it, it + 1 == cap ? it + 1 : max_iter, fmap);
         done = it + 1;
         if (poll) {
-            LDPC_HIP_TRY(hipMemcpyAsync(h_poll, live_tiles, sizeof(int), hipMemcpyDeviceToHost, st));
+            LDPC_HIP_TRY(hipMemcpyAsync(h_poll, live_tiles, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
             LDPC_HIP_TRY(hipStreamSynchronize(st));
-            if (*h_poll == 0) break;
+            const int lt = h_poll[0], lf = h_poll[1];
+            if (lt == 0) break;
+            if (repack_ok && lt >= 2 && (double)lf <= repack_fill * 64.0 * lt && it + 1 < cap) {
+                const int nt = (lf + 63) / 64, nx = 1 - cur;
+                const size_t es2 = (size_t)nt * E * 64 * sizeof(double), vs2 = (size_t)nt * n * 64 * sizeof(double);
+                LDPC_TRY(set_z[nx]->reserve(es2));
+                LDPC_TRY(set_l[nx]->reserve(es2));
+                LDPC_TRY(set_x[nx]->reserve(vs2));
+                LDPC_TRY(set_g[nx]->reserve(vs2));
+                LDPC_TRY(set_live[nx]->reserve((size_t)nt * 8));
+                LDPC_TRY(set_fmap[nx]->reserve((size_t)nt * 64 * sizeof(int32_t)));
+                LDPC_TRY(d->rbase.reserve(((size_t)cur_tiles + 1) * sizeof(int32_t)));
+                // x_hat of every frame of the old tiles as it stands (frames that left keep it; the moved ones overwrite theirs at the end)
+                hipLaunchKernelGGL(k_admm_out, dim3((n + 3) / 4, cur_tiles), dim3(256), 0, st, x, x_out, B, n, fmap);
+                hipLaunchKernelGGL(k_repack_plan, dim3(1), dim3(1024), 0, st, live, cur_tiles, (int32_t*)d->rbase.p);
+                const int rows_per_wave = 128;
+                const int chunks = (int)((E + n + rows_per_wave - 1) / rows_per_wave);
+                hipLaunchKernelGGL(k_admm_repack, dim3((chunks + 3) / 4, nt), dim3(64, 4), 0, st, z, (double*)set_z[nx]->p, lam, (double*)set_l[nx]->p, x,
+                                   (double*)set_x[nx]->p, gam, (double*)set_g[nx]->p, live, (u64*)set_live[nx]->p, (const int32_t*)d->rbase.p, fmap,
+                                   (int32_t*)set_fmap[nx]->p, cur_tiles, n, E, rows_per_wave);
+                cur = nx;
+                z = (double*)set_z[cur]->p;
+                lam = (double*)set_l[cur]->p;
+                x = (double*)set_x[cur]->p;
+                gam = (double*)set_g[cur]->p;
+                live = (u64*)set_live[cur]->p;
+                fmap = (int32_t*)set_fmap[cur]->p;
+                cur_tiles = nt;
+                ++repacks;
+            }
         }
     }
-    hipLaunchKernelGGL(k_admm_out, dim3((n + 3) / 4, tiles), dim3(256), 0, st, x, x_out, B, n);
+    hipLaunchKernelGGL(k_admm_out, dim3((n + 3) / 4, cur_tiles), dim3(256), 0, st, x, x_out, B, n, fmap);
+    d->last_repacks = repacks;
     LDPC_HIP_TRY(hipGetLastError());
     d->last_iters = done;
     return LDPC_OK;

@@ -498,6 +498,12 @@ int ldpc_admm_destroy(ldpc_admm_t h) {
     return LDPC_OK;
 }
 
+int ldpc_admm_last_repacks(ldpc_admm_t h, int* repacks) {
+    if (!h || !repacks) return LDPC_E_ARG;
+    *repacks = admm_last_repacks((AdmmDecoder*)h);
+    return LDPC_OK;
+}
+
 int ldpc_admm_decode(ldpc_admm_t h, const double* gamma_dev, int64_t B, double mu, double eps, int32_t max_iter, double* x_dev,
                      int32_t* iters_dev, uint8_t* converged_dev, void* stream) {
     if (!h || !gamma_dev || !x_dev || !iters_dev || B < 0) {

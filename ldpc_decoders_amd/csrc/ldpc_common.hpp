@@ -149,6 +149,7 @@ int ml_simulate(MlDecoder* d, int channel, int dtype, double param, int codeword
 struct AdmmDecoder;
 int admm_create(Code* code, AdmmDecoder** out);
 void admm_destroy(AdmmDecoder* d);
+int admm_last_repacks(const AdmmDecoder* d);
 int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, double eps, int32_t max_iter, double* x_out, int32_t* iters,
                 uint8_t* converged, hipStream_t st);
 

@@ -18,6 +18,7 @@
 
 #include "ldpc_cn.hpp"
 #include "ldpc_common.hpp"
+#include "ldpc_repack.hpp"
 
 namespace ldpc {
 
@@ -318,41 +319,12 @@ __global__ __launch_bounds__(256) void k_syndrome(const int32_t* __restrict__ ro
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Frame repack (early termination): when many tiles hold only a few live frames, the live frames are gathered into dense
-// tiles -- the reference leaves per FRAME (src/bpa.py:28-29); a tile keeps streaming its whole message block for as long as
-// one of its 64 frames is live.  k_repack_plan ranks the live frames (prefix sums of the tiles' live counts); k_repack moves
+// Frame repack (early termination, ldpc_repack.hpp): when many tiles hold only a few live frames, the live frames are gathered
+// into dense tiles.  k_repack moves
 // message lines, priors and decision bit-planes: destination lane j reads (source tile, source lane) of the j-th live frame;
 // lanes that share a source tile share the 256-byte line, so a line of a source tile is fetched once per destination tile
 // that draws from it.  The decisions of every frame of the old tiles are written out before (k_unpack), the moved frames
 // overwrite theirs at the end.
-__global__ __launch_bounds__(1024) void k_repack_plan(const u64* __restrict__ live, int tiles, int32_t* __restrict__ base) {
-    // base[t] = number of live frames in tiles [0, t); base[tiles] = total.  One workgroup, tiles <= 65535.
-    __shared__ int part[1024];
-    const int t = threadIdx.x;
-    const int per = (tiles + 1023) / 1024;
-    int sum = 0;
-    for (int i = t * per; i < min(tiles, (t + 1) * per); ++i) sum += __popcll(live[i]);
-    part[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan
-        const int v = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    int run = t ? part[t - 1] : 0;
-    for (int i = t * per; i < min(tiles, (t + 1) * per); ++i) {
-        base[i] = run;
-        run += __popcll(live[i]);
-    }
-    if (t == 1023) base[tiles] = part[1023];
-}
-
-__device__ __forceinline__ int nth_set_bit(u64 x, int k) {  // position of the k-th (0-based) set bit of x
-    for (int i = 0; i < k; ++i) x &= x - 1;
-    return __ffsll((long long)x) - 1;
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void k_repack(const T* __restrict__ msg_src, T* __restrict__ msg_dst, const T* __restrict__ prior_src,
                                                 T* __restrict__ prior_dst, const u64* __restrict__ xb_src, u64* __restrict__ xb_dst,
@@ -361,20 +333,8 @@ __global__ __launch_bounds__(256) void k_repack(const T* __restrict__ msg_src, T
                                                 int32_t* __restrict__ frame_dst, int tiles_src, int n, int64_t E, int rows_per_wave) {
     const int lane = threadIdx.x;
     const int dt = blockIdx.y;  // destination tile
-    const int total = base[tiles_src];
-    const int j = dt * 64 + lane;
-    // source of this lane's frame: the tile whose rank interval holds j (binary search over the prefix sums)
-    int st = 0, sl = 0;
-    const bool has = j < total;
-    if (has) {
-        int lo = 0, hi = tiles_src - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (base[mid] <= j) lo = mid; else hi = mid - 1;
-        }
-        st = lo;
-        sl = nth_set_bit(live_src[st], j - base[st]);
-    }
+    int st, sl;
+    const bool has = repack_source(base, live_src, tiles_src, dt * 64 + lane, &st, &sl);
     const int chunk = blockIdx.x * 4 + threadIdx.y;
     const int64_t rows = E + n;  // message lines, then prior lines (+ one bit-plane word per prior line)
     const int64_t r0 = (int64_t)chunk * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);

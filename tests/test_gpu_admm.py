@@ -76,6 +76,38 @@ def test_admm_batches_vs_c_oracle():
         assert len(np.unique(io)) > 3
 
 
+def test_admm_frame_repack_is_bit_transparent(monkeypatch):
+    # frames leave one by one (src/admm.py:65-66) while the non-converging ones run into the cap: live frames are re-gathered into
+    # dense tiles (ldpc_repack.hpp).  Moving state must not change a bit: repack on == repack off == the C oracle.
+    import torch
+    from ldpc_decoders_amd._device import AdmmHandle
+
+    rng = np.random.RandomState(9)
+    for name, B, snr, max_iter, with_oracle in (("1200_3_6_rand_ldpc_1", 64 * 9 + 5, 2.3, 200, 96), ("1200_rho_x5_rand_ldpc_5", 64 * 6, 2.0, 120, 0),
+                                                ("7_4_hamming", 64 * 40 + 3, 2.0, 100, 64 * 40 + 3)):
+        code = _code(name)
+        gamma = -2 * (-1 + rng.normal(0, np.sqrt(10 ** (-snr / 10)), (B, code.n))) / 10 ** (-snr / 10)
+        gd = torch.from_numpy(gamma).cuda()
+        outs = {}
+        for mode, fill in (("0", None), ("1", "0.95"), ("1", None)):
+            monkeypatch.setenv("LDPC_STREAM_REPACK", mode)
+            if fill:
+                monkeypatch.setenv("LDPC_STREAM_REPACK_FILL", fill)
+            else:
+                monkeypatch.delenv("LDPC_STREAM_REPACK_FILL", raising=False)
+            h = AdmmHandle(code)
+            x, it, cv = h.decode_device(gd, 3.0, 1e-5, max_iter)
+            outs[(mode, fill)] = (x.cpu().numpy(), it.cpu().numpy(), cv.cpu().numpy(), h.last_repacks())
+        ref = outs[("0", None)]
+        assert ref[3] == 0 and outs[("1", "0.95")][3] >= 2
+        for key in (("1", "0.95"), ("1", None)):
+            assert np.array_equal(outs[key][0], ref[0], equal_nan=True) and np.array_equal(outs[key][1], ref[1]) and np.array_equal(outs[key][2], ref[2])
+        assert len(np.unique(ref[1])) > 5
+        if with_oracle:
+            xo, io, co = A.admm_decode(graph_of(name), gamma[:with_oracle], 3.0, 1e-5, max_iter)
+            assert np.array_equal(ref[1][:with_oracle], io) and np.array_equal(ref[0][:with_oracle], xo, equal_nan=True)
+
+
 def _admm_main_cases():
     with open(os.path.join(GOLDEN, "main_counters_admm.json")) as fp:
         return json.load(fp)
