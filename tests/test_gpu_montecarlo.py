@@ -37,7 +37,14 @@ def test_main_py_path_is_the_in_kernel_path(alg, prec, channel, param):
         outs[name] = sim.run_round(param, 3, 100, 4096)[:4].tolist()
         if backend == "auto":
             assert h.fused_info()["waves_per_frame"] > 0
-    assert outs["main"] == outs["bench"] == outs["composed"], outs
+    assert outs["main"] == outs["bench"], outs
+    if alg == "SPA" and prec == "f32":
+        # fp32 sum-product: the LDS kernel visits a check's edges in the order its layout plan chose, the streaming kernel in H's
+        # order; the (E, O) joins round differently in the last bit, which may flip a bit of a non-converging frame
+        a, b = np.array(outs["main"], dtype=float), np.array(outs["composed"], dtype=float)
+        assert a[0] == b[0] and np.all(np.abs(a[1:] - b[1:]) <= 0.02 * b[1:] + 2), outs
+    else:
+        assert outs["main"] == outs["composed"], outs
     assert outs["main"][0] == 4096 and outs["main"][3] > 4096
 
 
