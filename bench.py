@@ -147,8 +147,8 @@ def committed(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step")
     ap.add_argument("--snr", type=float, default=1.0)
     ap.add_argument("--max-iter", type=int, default=50)
