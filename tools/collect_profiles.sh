@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for P in f64 f32; do
   for BK in fused stream; do
     B=auto; [ $BK = stream ] && B=stream
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_${BK}_$P -o k -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --points --no-profile --precision $P --backend $B > $OUT/stats_${BK}_$P.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_${BK}_$P -o k -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --points --no-profile --precision $P --backend $B > $OUT/stats_${BK}_$P.log 2>&1
     for C in FETCH_SIZE WRITE_SIZE; do
       rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${BK}_${P}_$C -o p -- python3 $R/tools/prof_fused.py --reps 1 --precision $P --backend $B > $OUT/pmc_${BK}_${P}_$C.log 2>&1
     done
