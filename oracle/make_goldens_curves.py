@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Collect the reference's PUBLISHED result files (data/output/*.json: BER/WER curves it ships) for the codes whose H files
-are among the test fixtures, into tests/golden/published_curves.json.  Data only (counters per channel parameter)."""
+"""Collect the reference's PUBLISHED result files (data/output/*.json: BER/WER curves it ships) for every code the build can
+construct (all of its data/codes files, kept as fixtures, and the built-in toy codes) into tests/golden/published_curves.json.
+Data only (counters per channel parameter)."""
 import json
 import os
 import sys
@@ -10,7 +11,8 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 import ref_import  # noqa: E402
 
-CODES = {"1200_3_6_ldpc", "1200_3_6_rand_ldpc_1", "1200_rho_x5_rand_ldpc_5", "7_4_hamming", "margulis"}
+# every code whose H the build can construct: all 27 data/codes files (fixtures under tests/golden/codes) + the built-in toy codes
+CODES = {os.path.splitext(f)[0] for f in os.listdir(os.path.join(ROOT, "tests", "golden", "codes"))} | {"4_2_test", "6_2_3_ldpc", "7_4_hamming", "12_3_4_ldpc"}
 DECODERS = {"SPA", "MSA", "ML", "ADMM"}
 
 out = []
