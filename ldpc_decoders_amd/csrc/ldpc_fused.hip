@@ -221,9 +221,7 @@ int fused_plan_create(Decoder* d) {
     const Code* c = d->code;
     d->fused = new FusedPlan();
     FusedPlan* p = d->fused;
-    const bool full_dv = c->min_dv == c->max_dv;
     const bool short_rows = c->min_dc != c->max_dc;
-    (void)full_dv;
     const ShapeChoice ch = choose_shape(c, d->alg, d->dtype);
     const int si = ch.si;
     if (si < 0) return LDPC_OK;
