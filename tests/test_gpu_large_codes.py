@@ -153,3 +153,52 @@ def test_config4_fused_deterministic():
     for _ in range(4):
         x1, i1 = h.decode_device(pri, None, 50)
         assert torch.equal(x1, x0) and torch.equal(i1, i0)
+
+
+def test_full_size_configs_4_and_5_properties():
+    # BASELINE configs 4 and 5 at their FULL per-GPU sizes (2^20 / 8 = 131 072 frames of the rate-1/2 irregular n = 10 000 ensemble;
+    # 2^18 / 8 = 32 768 frames of the (3,6) n = 64 800 code), device noise.  The oracle cannot run these sizes, so the checks are
+    # size-independent properties: the counters of the whole batch equal the sum over two shards (frames are keyed by their global
+    # index: what makes the 8-GPU split exact), every frame that left early carries a codeword (zero syndrome), the all-zero word
+    # is recovered at this SNR, iteration counts are spread (per-frame early termination at work, with the streaming backend
+    # re-forming its tiles), and a sample of frames re-decoded by the C oracle is bit-identical.
+    import torch
+    from ldpc_decoders_amd import codes
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    for name, code, B, snr, backend in (("config 5", codes.rand_reg_ldpc(64800, 3, 6, np.random.RandomState(20261002)), 32768, 2.0, "stream"),
+                                         ("config 4", codes.rand_irregular_ldpc(10000, codes.LAMBDA_RHO_X5_HALF_RATE, 6, np.random.RandomState(20261002)), 131072, 2.1, "fused")):
+        h = DecoderHandle(code, "MSA", "f32", backend)
+
+        def counters(f0, nb):
+            c = torch.zeros(4 + 51, dtype=torch.int64, device="cuda")
+            h.simulate("biawgn", snr, 0, 99, 0, f0, nb, 50, c, hist_bins=51)
+            torch.cuda.synchronize()
+            return c.cpu().numpy()
+
+        whole = counters(0, B)
+        assert h.last_stats()[0] == backend
+        half = counters(0, B // 2 + 7) + counters(B // 2 + 7, B - B // 2 - 7)
+        assert (whole == half).all(), name
+        hist = whole[4:]
+        assert whole[0] == B and hist.sum() == B and (hist > 0).sum() >= 8, (name, hist)  # frames leave after many different sweep counts
+        assert whole[1] <= 0.4 * B, (name, whole[:4])  # most frames decode at this SNR
+        # a slice of the same frames through the decode entry: codewords where the frame left early, oracle-identical on a sample
+        nb = 1024 if backend == "stream" else 4096
+        pri, _ = h.channel_device("biawgn", snr, 0, 99, 0, 0, nb)
+        xhat, iters = h.decode_device(pri, None, 50)
+        xh, it = xhat.cpu().numpy(), iters.cpu().numpy()
+        early = it < 50
+        assert early.mean() > 0.8 and code.syndrome(xh[early][:256]).sum() == 0
+        assert (np.bincount(it, minlength=51) == counters(0, nb)[4:]).all()  # the decode entry and the Monte-Carlo path agree frame for frame
+        if backend == "stream":
+            assert h.last_repacks() >= 1
+
+        class G:
+            m, n, chk, var = code.m, code.n, code.edge_chk, code.edge_var
+
+        idx = np.r_[0:8, nb - 8:nb]
+        xo, io = C.bp_decode(G, "MSA", None, pri[idx].cpu().numpy(), 50, dtype=np.float32)
+        assert (xh[idx] == xo).all() and (it[idx] == io).all(), name
+        del h, pri, xhat, iters
+        torch.cuda.empty_cache()
