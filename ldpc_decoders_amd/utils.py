@@ -32,7 +32,7 @@ def _reference_flags(p, channel_names, code_names, decoder_names):
                    help="name of the code: a built-in, or a parity-check text file found in $%s (falls back to data/codes)" % codes.file_codes_dir_string)
     p.add_argument("decoder", choices=list(decoder_names), help="which decoder to run on the GPU")
     p.add_argument("--codeword", type=int, default=0, choices=[-1, 0, 1],
-                   help="what is sent: 0 = the all-zero word, 1 = the all-one word, -1 = a fresh random codeword per frame (short codes; host noise)")
+                   help="what is sent: 0 = the all-zero word, 1 = the all-one word, -1 = a fresh random codeword per frame (codes with a code book, i.e. short ones)")
     p.add_argument("--min-wec", type=int, default=100, help="stop a point once this many frames were decoded wrongly")
     p.add_argument("--params", type=float, nargs="+", default=[.1, .01],
                    help="one run per value: SNR in dB (biawgn), crossover probability (bsc) or erasure probability (bec)")
