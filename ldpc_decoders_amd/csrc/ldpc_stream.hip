@@ -283,36 +283,44 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
 
 // ---------------------------------------------------------------------------------------------------
 // Syndrome of the current hard decisions; frames whose syndrome is zero leave (iters = sweeps run so far).
-__global__ __launch_bounds__(256) void k_syndrome(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
-                                                  const u64* __restrict__ xbits, u64* __restrict__ live,
-                                                  int32_t* __restrict__ iters, int* __restrict__ live_tiles, int m, int n,
-                                                  int64_t B, int sweeps, const int32_t* __restrict__ frame_of) {
-    __shared__ u64 s_un;
-    const int tile = blockIdx.x, t = threadIdx.x;
-    const u64 lv = live[tile];
-    if (lv == 0) return;
-    if (t == 0) s_un = 0;
-    __syncthreads();
+// Two kernels: k_syndrome_part -- a block takes one tile and a CHUNK of the checks (a grid of tiles alone cannot fill the chip: 512
+// tiles of n = 64 800 meant 2 blocks per CU and 0.97 ms per sweep, 6 % of it), ORs the parities of its checks over the bit-planes
+// and merges the result into the tile's word -- and k_syndrome_fin, one wave per tile, which retires the frames.
+__global__ __launch_bounds__(256) void k_syndrome_part(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
+                                                       const u64* __restrict__ xbits, const u64* __restrict__ live,
+                                                       u64* __restrict__ unsat_acc, int m, int n, int checks_per_block) {
+    const int tile = blockIdx.y, t = threadIdx.x;
+    if (live[tile] == 0) return;
     const u64* xb = xbits + (int64_t)tile * n;
+    const int c0 = blockIdx.x * checks_per_block, c1 = min(m, c0 + checks_per_block);
     u64 acc = 0;
-    for (int c = t; c < m; c += 256) {
+    for (int c = c0 + t; c < c1; c += 256) {
         u64 par = 0;
         for (int k = row_ptr[c]; k < row_ptr[c + 1]; ++k) par ^= xb[edge_var[k]];
         acc |= par;
     }
     acc = wave_or(acc);
-    if ((t & 63) == 0 && acc) atomicOr(&s_un, acc);
-    __syncthreads();
-    const u64 unsat = s_un;
+    if ((t & 63) == 0 && acc) atomicOr(&unsat_acc[2 * tile], acc);
+}
+
+__global__ __launch_bounds__(64) void k_syndrome_fin(u64* __restrict__ unsat_acc, u64* __restrict__ live, int32_t* __restrict__ iters,
+                                                     int* __restrict__ live_tiles, int64_t B, int sweeps,
+                                                     const int32_t* __restrict__ frame_of) {
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const u64 lv = live[tile];
+    if (lv == 0) return;
+    const u64 unsat = unsat_acc[2 * tile];
     const u64 stay = lv & unsat, leave = lv & ~unsat;
+    __syncthreads();  // every lane has read the word before lane 0 clears it for the next sweep
     if (t == 0) {
+        unsat_acc[2 * tile] = 0;
         live[tile] = stay;
         if (stay && live_tiles) {
             atomicAdd(live_tiles, 1);                    // tiles that still hold a live frame
             atomicAdd(live_tiles + 1, __popcll(stay));   // live frames
         }
     }
-    if (t < 64 && ((leave >> t) & 1ull)) {
+    if ((leave >> t) & 1ull) {
         const int64_t fr = frame_of ? (int64_t)frame_of[(int64_t)tile * 64 + t] : (int64_t)tile * 64 + t;
         if (fr >= 0 && fr < B) iters[fr] = sweeps;
     }
@@ -582,8 +590,14 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                 hipLaunchKernelGGL(k_bec_check, dim3(cur_tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr,
                                    B, cur_tiles, sweeps);
             } else {
-                hipLaunchKernelGGL(k_syndrome, dim3(cur_tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, xbits, live, iters,
-                                   poll ? live_tiles : nullptr, m, n, B, sweeps, fmap);
+                // chunks of the checks per tile: enough blocks to fill the chip (about 4 per CU), at least 1024 checks each
+                int sblocks = (int)((1024 + cur_tiles - 1) / cur_tiles);
+                const int smax = (m + 1023) / 1024;
+                sblocks = sblocks < 1 ? 1 : (sblocks > smax ? smax : sblocks);
+                const int cpb = (m + sblocks - 1) / sblocks;
+                hipLaunchKernelGGL(k_syndrome_part, dim3(sblocks, cur_tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, xbits, live, tflags, m, n,
+                                   cpb);
+                hipLaunchKernelGGL(k_syndrome_fin, dim3(cur_tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr, B, sweeps, fmap);
             }
             if (poll) {
                 LDPC_HIP_TRY(hipMemcpyAsync(h_poll, live_tiles, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
