@@ -3,8 +3,9 @@
 // Layout per tile of 64 frames (lane == frame):
 //     msg  [tile][E][64]   T     one array, updated IN PLACE: check pass turns v2c into c2v, variable pass back
 //     prior[tile][n][64]   T
-//     xbits[tile][n]       u64   hard decision of variable v for the 64 frames (bit f == frame f)
-//     xera [tile][n]       u64   (erasure decoder only) "still erased" plane
+//     xbits[tile/8][n][8]  u64   hard decision of variable v for the 64 frames of a tile (bit f == frame f); the words of EIGHT
+//                                consecutive tiles sit in one 64-byte sector, which is what the syndrome kernel fetches per variable
+//     xera [tile/8][n][8]  u64   (erasure decoder only) "still erased" plane
 //     live [tile]          u64   frames that are still iterating
 // Every H index is wave-uniform (scalar loads); every message access is one contiguous 64-element line.
 // Algorithmic HBM traffic per frame-iteration = sizeof(T) * (4E + n)   (SURVEY.md section 8(d)).
@@ -56,6 +57,10 @@ __device__ __forceinline__ u64 wave_or(u64 x) {
     return x;
 }
 
+// index of the bit-plane word of (tile, variable): eight tiles interleaved per variable
+__host__ __device__ __forceinline__ int64_t plane_at(int tile, int64_t v, int n) { return ((int64_t)(tile >> 3) * n + v) * 8 + (tile & 7); }
+__host__ inline size_t plane_words(int tiles, int n) { return (size_t)((tiles + 7) / 8) * n * 8; }
+
 // ---------------------------------------------------------------------------------------------------
 // priors [B,n] (frame-major, as numpy hands them over) -> prior tile [n][64]; optional hard word y0 -> planes.
 // BEC: the "prior" is the ternary message {-1,+1,0}[y] (src/bec.py:76,85) and y itself seeds both planes.
@@ -93,13 +98,13 @@ __global__ __launch_bounds__(256) void k_load_tile(const T* __restrict__ priors,
             if constexpr (ALG == ALG_BEC) {
                 const u64 one = __ballot(s == 1), era = __ballot(s >= 2);
                 if (tx == 0) {
-                    xbits[(int64_t)tile * n + v] = one;
-                    xera[(int64_t)tile * n + v] = era;
+                    xbits[plane_at(tile, v, n)] = one;
+                    xera[plane_at(tile, v, n)] = era;
                 }
                 era_any |= era;
             } else if (y0) {
                 const u64 one = __ballot(s != 0);
-                if (tx == 0) xbits[(int64_t)tile * n + v] = one;
+                if (tx == 0) xbits[plane_at(tile, v, n)] = one;
             }
         }
     }
@@ -192,8 +197,8 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
     T* mt = msg + (int64_t)tile * E * 64 + lane;
     const T* pt = prior_t + (int64_t)tile * n * 64 + lane;
     T* sft = soft_t ? soft_t + (int64_t)tile * n * 64 + lane : nullptr;
-    u64* xb = xbits + (int64_t)tile * n;
-    u64* xe = (ALG == ALG_BEC) ? xera + (int64_t)tile * n : nullptr;
+    u64* xb = xbits + plane_at(tile, 0, n);  // word of variable v at xb[8 * v]
+    u64* xe = (ALG == ALG_BEC) ? xera + plane_at(tile, 0, n) : nullptr;
     u64 chg = 0, era_any = 0;
     const int v_end = min(n, (chunk + 1) * vpw);
     for (int vbase = chunk * vpw; vbase < v_end; vbase += UNR) {
@@ -258,18 +263,18 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
             const int vv = vbase + u;
             if constexpr (ALG == ALG_BEC) {
                 const u64 era = __ballot(b_era);
-                const u64 old1 = xb[vv], olde = xe[vv];
+                const u64 old1 = xb[8 * vv], olde = xe[8 * vv];
                 const u64 new1 = (old1 & ~lv) | (one & lv), newe = (olde & ~lv) | (era & lv);
                 chg |= (old1 ^ new1) | (olde ^ newe);
                 era_any |= newe & lv;
                 if (lane == 0) {
-                    xb[vv] = new1;
-                    xe[vv] = newe;
+                    xb[8 * vv] = new1;
+                    xe[8 * vv] = newe;
                 }
             } else {
                 u64 merged = one;
-                if (lv != ~0ull) merged = (xb[vv] & ~lv) | (one & lv);
-                if (lane == 0) xb[vv] = merged;
+                if (lv != ~0ull) merged = (xb[8 * vv] & ~lv) | (one & lv);
+                if (lane == 0) xb[8 * vv] = merged;
             }
         }
     }
@@ -283,24 +288,40 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
 
 // ---------------------------------------------------------------------------------------------------
 // Syndrome of the current hard decisions; frames whose syndrome is zero leave (iters = sweeps run so far).
-// Two kernels: k_syndrome_part -- a block takes one tile and a CHUNK of the checks (a grid of tiles alone cannot fill the chip: 512
-// tiles of n = 64 800 meant 2 blocks per CU and 0.97 ms per sweep, 6 % of it), ORs the parities of its checks over the bit-planes
-// and merges the result into the tile's word -- and k_syndrome_fin, one wave per tile, which retires the frames.
+// Two kernels: k_syndrome_part -- a block takes a GROUP of eight tiles and a chunk of the checks; a thread fetches, per edge of its
+// check, the one 64-byte sector that holds the decision words of the variable for all eight tiles (per-tile 8-byte gathers made this
+// kernel L2-bound: 0.92 ms per sweep at n = 64 800, 6 % of the sweep), XORs them into eight parities, and the block merges the OR of
+// its checks into the tiles' words -- and k_syndrome_fin, one wave per tile, which retires the frames.
 __global__ __launch_bounds__(256) void k_syndrome_part(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
                                                        const u64* __restrict__ xbits, const u64* __restrict__ live,
-                                                       u64* __restrict__ unsat_acc, int m, int n, int checks_per_block) {
-    const int tile = blockIdx.y, t = threadIdx.x;
-    if (live[tile] == 0) return;
-    const u64* xb = xbits + (int64_t)tile * n;
+                                                       u64* __restrict__ unsat_acc, int m, int n, int tiles, int checks_per_block) {
+    const int grp = blockIdx.y, t = threadIdx.x;
+    const int t0 = grp * 8, nt = min(8, tiles - t0);
+    u64 any_live = 0;
+    for (int i = 0; i < nt; ++i) any_live |= live[t0 + i];
+    if (any_live == 0) return;
+    const ulonglong2* xb = reinterpret_cast<const ulonglong2*>(xbits + (int64_t)grp * n * 8);  // variable v: xb[4 v .. 4 v + 3]
     const int c0 = blockIdx.x * checks_per_block, c1 = min(m, c0 + checks_per_block);
-    u64 acc = 0;
+    u64 acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int c = c0 + t; c < c1; c += 256) {
-        u64 par = 0;
-        for (int k = row_ptr[c]; k < row_ptr[c + 1]; ++k) par ^= xb[edge_var[k]];
-        acc |= par;
+        u64 par[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = row_ptr[c]; k < row_ptr[c + 1]; ++k) {
+            const ulonglong2* w = xb + (int64_t)edge_var[k] * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const ulonglong2 x = w[q];
+                par[2 * q] ^= x.x;
+                par[2 * q + 1] ^= x.y;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] |= par[i];
     }
-    acc = wave_or(acc);
-    if ((t & 63) == 0 && acc) atomicOr(&unsat_acc[2 * tile], acc);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u64 a = wave_or(acc[i]);
+        if ((t & 63) == 0 && a && i < nt) atomicOr(&unsat_acc[2 * (t0 + i)], a);
+    }
 }
 
 __global__ __launch_bounds__(64) void k_syndrome_fin(u64* __restrict__ unsat_acc, u64* __restrict__ live, int32_t* __restrict__ iters,
@@ -356,9 +377,9 @@ __global__ __launch_bounds__(256) void k_repack(const T* __restrict__ msg_src, T
         } else {
             const int64_t v = r - E;
             if (has) pd[v * 64] = ps[v * 64];
-            const u64 w = has ? xb_src[(int64_t)st * n + v] : 0ull;
+            const u64 w = has ? xb_src[plane_at(st, v, n)] : 0ull;
             const u64 plane = __ballot(has && ((w >> sl) & 1ull));
-            if (lane == 0) xb_dst[(int64_t)dt * n + v] = plane;
+            if (lane == 0) xb_dst[plane_at(dt, v, n)] = plane;
         }
     }
     if (chunk == 0) {
@@ -414,9 +435,9 @@ __global__ __launch_bounds__(256) void k_unpack(const u64* __restrict__ xbits, c
     const int tile = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= n) return;
-    const u64 one = xbits[(int64_t)tile * n + v];
+    const u64 one = xbits[plane_at(tile, v, n)];
     u64 era = 0;
-    if constexpr (ALG == ALG_BEC) era = xera[(int64_t)tile * n + v];
+    if constexpr (ALG == ALG_BEC) era = xera[plane_at(tile, v, n)];
     const int64_t f0 = (int64_t)tile * 64;
     if (frame_of) {  // repacked tiles: lane f holds frame frame_of[tile][f] (-1: none)
         for (int f = 0; f < 64; ++f) {
@@ -516,10 +537,10 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     }
     LDPC_TRY(d->msg.reserve((size_t)tiles * E * 64 * sizeof(T)));
     LDPC_TRY(d->prior.reserve((size_t)tiles * n * 64 * sizeof(T)));
-    LDPC_TRY(d->xbits.reserve((size_t)tiles * n * 8));
+    LDPC_TRY(d->xbits.reserve(plane_words(tiles, n) * 8));
     LDPC_TRY(d->live.reserve((size_t)tiles * 8));
     LDPC_TRY(d->flags.reserve((size_t)tiles * 16 + 64));
-    if (ALG == ALG_BEC) LDPC_TRY(d->xera.reserve((size_t)tiles * n * 8));
+    if (ALG == ALG_BEC) LDPC_TRY(d->xera.reserve(plane_words(tiles, n) * 8));
     T* soft_t = nullptr;
     if (soft_out && ALG != ALG_BEC) {
         LDPC_TRY(d->scratch.reserve((size_t)tiles * n * 64 * sizeof(T)));
@@ -549,7 +570,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     g.vpw = per_wave(n);
     g.vn_chunks = (n + g.vpw - 1) / g.vpw;
 
-    LDPC_HIP_TRY(hipMemsetAsync(xbits, 0, (size_t)tiles * n * 8, st));
+    LDPC_HIP_TRY(hipMemsetAsync(xbits, 0, plane_words(tiles, n) * 8, st));
     LDPC_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)tiles * 16 + 64, st));
     LDPC_HIP_TRY(hipMemsetAsync(iters, 0, (size_t)B * sizeof(int32_t), st));
     hipLaunchKernelGGL((k_load_tile<T, ALG>), dim3((n + 63) / 64, tiles), dim3(256), 0, st, (const T*)priors_v, y0, B, n,
@@ -590,13 +611,14 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                 hipLaunchKernelGGL(k_bec_check, dim3(cur_tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr,
                                    B, cur_tiles, sweeps);
             } else {
-                // chunks of the checks per tile: enough blocks to fill the chip (about 4 per CU), at least 1024 checks each
-                int sblocks = (int)((1024 + cur_tiles - 1) / cur_tiles);
+                // groups of eight tiles x chunks of the checks: enough blocks to fill the chip (about 4 per CU), at least 1024 checks each
+                const int groups = (cur_tiles + 7) / 8;
+                int sblocks = (1024 + groups - 1) / groups;
                 const int smax = (m + 1023) / 1024;
                 sblocks = sblocks < 1 ? 1 : (sblocks > smax ? smax : sblocks);
                 const int cpb = (m + sblocks - 1) / sblocks;
-                hipLaunchKernelGGL(k_syndrome_part, dim3(sblocks, cur_tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, xbits, live, tflags, m, n,
-                                   cpb);
+                hipLaunchKernelGGL(k_syndrome_part, dim3(sblocks, groups), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, xbits, live, tflags, m, n,
+                                   cur_tiles, cpb);
                 hipLaunchKernelGGL(k_syndrome_fin, dim3(cur_tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr, B, sweeps, fmap);
             }
             if (poll) {
@@ -609,7 +631,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                     const int nx = 1 - cur;
                     LDPC_TRY(set_msg[nx]->reserve((size_t)nt * E * 64 * sizeof(T)));
                     LDPC_TRY(set_prior[nx]->reserve((size_t)nt * n * 64 * sizeof(T)));
-                    LDPC_TRY(set_xbits[nx]->reserve((size_t)nt * n * 8));
+                    LDPC_TRY(set_xbits[nx]->reserve(plane_words(nt, n) * 8));
                     LDPC_TRY(set_live[nx]->reserve((size_t)nt * 8));
                     LDPC_TRY(set_fmap[nx]->reserve((size_t)nt * 64 * sizeof(int32_t)));
                     LDPC_TRY(d->rbase.reserve(((size_t)cur_tiles + 1) * sizeof(int32_t)));
