@@ -94,7 +94,8 @@ def test(args, comm=None):
             if own_hist:
                 handle.on_iters = None
             sim = DeviceSimulator(handle, args.channel, args.max_iter, args.codeword, args.seed, comm, hist_bins=bins)
-            c = sim.run_point(param, stream_id=pi, min_wec=args.min_wec, batch_per_rank=args.batch, on_progress=progress)
+            c = sim.run_point(param, stream_id=pi, min_wec=args.min_wec, batch_per_rank=args.batch, on_progress=progress,
+                              max_frames=(args.max_frames or None))
             if own_hist:
                 inner.iter[:] = 0
                 inner.iter[:bins] = c["hist"]

@@ -56,6 +56,8 @@ def setup_parser(code_names, channel_names, decoder_names):
     g.add_argument("--backend", choices=["auto", "stream", "fused"], default="auto", help="kernel family")
     g.add_argument("--batch", type=int, default=65536, help="frames per round and per GPU (device-noise mode)")
     g.add_argument("--seed", type=int, default=0x5EED1200, help="Philox seed of the device noise")
+    g.add_argument("--max-frames", type=int, default=0,
+                   help="device-noise mode: stop a parameter after this many frames even if --min-wec was not reached (0 = no cap, as upstream)")
     g.add_argument("--exact", action="store_true",
                    help="reference-exact mode: host numpy noise (np.random global stream), fp64 messages, sequential stopping rule")
     g.add_argument("--np-seed", type=int, default=None, help="np.random.seed() for --exact runs (upstream runs unseeded)")
