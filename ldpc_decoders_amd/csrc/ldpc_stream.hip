@@ -162,9 +162,10 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
             for (int u = 0; u < UNR; ++u) {
 #pragma unroll
                 for (int j = 0; j < DCMAX; ++j) {
-                    if (j < deg[u]) {
-                        v[u][j] = first ? pt[(int64_t)edge_var[k0[u] + j] * 64] : msg_ld<LDPC_CN_NTL != 0>(mt + (int64_t)(k0[u] + j) * 64);
-                    }
+                    // irregular rows: every line is fetched unconditionally (a short row re-reads its last edge): a branch per line keeps
+                    // the loads of a group of checks from being issued together
+                    const int kk = FIXED_DC > 0 ? k0[u] + j : k0[u] + (j < deg[u] ? j : (deg[u] > 0 ? deg[u] - 1 : 0));
+                    v[u][j] = first ? pt[(int64_t)edge_var[kk] * 64] : msg_ld<LDPC_CN_NTL != 0>(mt + (int64_t)kk * 64);
                 }
             }
 #pragma unroll
@@ -499,6 +500,10 @@ int dispatch_cn(const Code* c, T* msg, const T* prior, const u64* live, const Ge
     const bool regular = c->min_dc == c->max_dc;
     if (regular && c->max_dc == 6) {
         launch_cn<T, ALG, 6, 6>(c, msg, prior, live, g, first, st);
+        return 0;
+    }
+    if (c->max_dc > 4 && c->max_dc <= 6) {  // check degrees up to 6 (the rho = x^5 ensembles): no lines fetched for positions that never exist
+        launch_cn<T, ALG, 6, 0>(c, msg, prior, live, g, first, st);
         return 0;
     }
     switch (pick_pow2_ge(c->max_dc, 4, 64)) {
