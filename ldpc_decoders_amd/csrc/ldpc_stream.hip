@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
 
 // ---------------------------------------------------------------------------------------------------
 // Variable pass: marginal = prior + ordered sum of c2v ; v2c = marginal - c2v (in place) ; decision bit.
-template <typename T, int ALG, int DVMAX, int UNR>
+// FIXED_DV > 0: every variable has exactly that many edges (edge list of variable v at v * FIXED_DV): no col_ptr loads and no branch
+// per line, so the lines of a group of variables are fetched together
+template <typename T, int ALG, int DVMAX, int UNR, int FIXED_DV>
 __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ col_edge,
                                             T* __restrict__ msg, const T* __restrict__ prior_t,
                                             const u64* __restrict__ live, u64* __restrict__ xbits, u64* __restrict__ xera,
@@ -209,7 +211,10 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int vv = vbase + u;
-            if (vv < v_end) {
+            if constexpr (FIXED_DV > 0) {
+                p0[u] = (vv < v_end ? vv : v_end - 1) * FIXED_DV;  // past the end: the last variable's lines once more, result unused
+                deg[u] = vv < v_end ? FIXED_DV : -1;
+            } else if (vv < v_end) {
                 p0[u] = col_ptr[vv];
                 deg[u] = col_ptr[vv + 1] - p0[u];
             } else {
@@ -220,27 +225,34 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
         if (on) {
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                if (deg[u] >= 0) pr[u] = pt[(int64_t)(vbase + u) * 64];
+                if constexpr (FIXED_DV > 0) {
+                    pr[u] = pt[(int64_t)(vbase + u < v_end ? vbase + u : v_end - 1) * 64];
 #pragma unroll
-                for (int j = 0; j < DVMAX; ++j) {
-                    if (j < deg[u]) c[u][j] = msg_ld<LDPC_VN_NTL != 0>(mt + (int64_t)col_edge[p0[u] + j] * 64);
+                    for (int j = 0; j < FIXED_DV; ++j) c[u][j] = msg_ld<LDPC_VN_NTL != 0>(mt + (int64_t)col_edge[p0[u] + j] * 64);
+                } else {
+                    if (deg[u] >= 0) pr[u] = pt[(int64_t)(vbase + u) * 64];
+#pragma unroll
+                    for (int j = 0; j < DVMAX; ++j) {
+                        if (j < deg[u]) c[u][j] = msg_ld<LDPC_VN_NTL != 0>(mt + (int64_t)col_edge[p0[u] + j] * 64);
+                    }
                 }
             }
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             if (deg[u] < 0) continue;  // wave-uniform
+            const int du = FIXED_DV > 0 ? FIXED_DV : deg[u];
             bool b_one = false, b_era = false;
             if (on) {
                 if constexpr (ALG == ALG_BEC) {
                     int s = 0;
 #pragma unroll
                     for (int j = 0; j < DVMAX; ++j)
-                        if (j < deg[u]) s += c[u][j];
+                        if (j < du) s += c[u][j];
                     const int marg = (int)pr[u] + s;
 #pragma unroll
                     for (int j = 0; j < DVMAX; ++j) {
-                        if (j < deg[u]) {
+                        if (j < du) {
                             const int d = marg - (int)c[u][j];
                             mt[(int64_t)col_edge[p0[u] + j] * 64] = (T)((d > 0) - (d < 0));
                         }
@@ -251,11 +263,11 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
                     T s = T(0);
 #pragma unroll
                     for (int j = 0; j < DVMAX; ++j)
-                        if (j < deg[u]) s += c[u][j];
+                        if (j < du) s += c[u][j];
                     const T marg = pr[u] + s;
 #pragma unroll
                     for (int j = 0; j < DVMAX; ++j)
-                        if (j < deg[u]) msg_st<LDPC_VN_NTS != 0>(mt + (int64_t)col_edge[p0[u] + j] * 64, (T)(marg - c[u][j]));
+                        if (j < du) msg_st<LDPC_VN_NTS != 0>(mt + (int64_t)col_edge[p0[u] + j] * 64, (T)(marg - c[u][j]));
                     b_one = marg < T(0);  // NaN marginal -> 0 (src/bpa.py:38,62)
                     if (sft) sft[(int64_t)(vbase + u) * 64] = marg;
                 }
@@ -486,12 +498,12 @@ void launch_cn(const Code* c, T* msg, const T* prior, const u64* live, const Geo
                        c->d_edge_var, msg, prior, live, c->m, c->n, c->E, g.tiles, g.cn_chunks, g.cpw, first);
 }
 
-template <typename T, int ALG, int DVMAX>
+template <typename T, int ALG, int DVMAX, int FIXED_DV = 0>
 void launch_vn(const Code* c, T* msg, const T* prior, const u64* live, u64* xbits, u64* xera, u64* flags, T* soft,
                const Geometry& g, hipStream_t st) {
     constexpr int UNR = unroll_for(DVMAX * (int)sizeof(T));
     const int tasks = g.tiles * g.vn_chunks;
-    hipLaunchKernelGGL((k_vn<T, ALG, DVMAX, UNR>), dim3((tasks + 3) / 4), dim3(64, 4), 0, st, c->d_col_ptr, c->d_col_edge,
+    hipLaunchKernelGGL((k_vn<T, ALG, DVMAX, UNR, FIXED_DV>), dim3((tasks + 3) / 4), dim3(64, 4), 0, st, c->d_col_ptr, c->d_col_edge,
                        msg, prior, live, xbits, xera, flags, soft, c->n, c->E, g.tiles, g.vn_chunks, g.vpw);
 }
 
@@ -519,6 +531,14 @@ int dispatch_cn(const Code* c, T* msg, const T* prior, const u64* live, const Ge
 template <typename T, int ALG>
 int dispatch_vn(const Code* c, T* msg, const T* prior, const u64* live, u64* xbits, u64* xera, u64* flags, T* soft,
                 const Geometry& g, hipStream_t st) {
+    if (c->min_dv == c->max_dv && c->max_dv == 3) {  // (3, r)-regular codes
+        launch_vn<T, ALG, 3, 3>(c, msg, prior, live, xbits, xera, flags, soft, g, st);
+        return 0;
+    }
+    if (c->min_dv == c->max_dv && c->max_dv == 4) {
+        launch_vn<T, ALG, 4, 4>(c, msg, prior, live, xbits, xera, flags, soft, g, st);
+        return 0;
+    }
     switch (pick_pow2_ge(c->max_dv, 4, 64)) {
         case 4: launch_vn<T, ALG, 4>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
         case 8: launch_vn<T, ALG, 8>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
