@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: bench lines + rocprofv3 kernel stats of BASELINE configs 4 and 5 at their per-GPU sizes.  tools/collect_configs45.sh <tag>
-TAG=${1:-r02e}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

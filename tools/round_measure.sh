@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: everything a round's measurements are quoted from, under gpurun_out/<tag>/.   tools/round_measure.sh <tag>
-TAG=${1:-r02c}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
