@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
     const u64 lv = live[tile];
     if (lv == 0) return;
     const bool on = (lv >> lane) & 1ull;
+    const bool dense = E * 4 >= (int64_t)m * DCMAX * 3;  // average row length at least three quarters of DCMAX (wave-uniform)
     T* mt = msg + (int64_t)tile * E * 64 + lane;
     const T* pt = prior_t + (int64_t)tile * n * 64 + lane;
     const int c_end = min(m, (chunk + 1) * cpw);
@@ -158,14 +159,25 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
             }
         }
         if (on) {
+            // irregular rows, `dense` (most rows nearly DCMAX long): every line is fetched unconditionally (a short row re-reads its
+            // last edge) -- a branch per line keeps the loads of a group of checks from being issued together; with widely spread row
+            // lengths the branch stays
+            if (FIXED_DC > 0 || dense) {
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
+                for (int u = 0; u < UNR; ++u) {
 #pragma unroll
-                for (int j = 0; j < DCMAX; ++j) {
-                    // irregular rows: every line is fetched unconditionally (a short row re-reads its last edge): a branch per line keeps
-                    // the loads of a group of checks from being issued together
-                    const int kk = FIXED_DC > 0 ? k0[u] + j : k0[u] + (j < deg[u] ? j : (deg[u] > 0 ? deg[u] - 1 : 0));
-                    v[u][j] = first ? pt[(int64_t)edge_var[kk] * 64] : msg_ld<LDPC_CN_NTL != 0>(mt + (int64_t)kk * 64);
+                    for (int j = 0; j < DCMAX; ++j) {
+                        const int kk = FIXED_DC > 0 ? k0[u] + j : k0[u] + (j < deg[u] ? j : (deg[u] > 0 ? deg[u] - 1 : 0));
+                        v[u][j] = first ? pt[(int64_t)edge_var[kk] * 64] : msg_ld<LDPC_CN_NTL != 0>(mt + (int64_t)kk * 64);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+                    for (int j = 0; j < DCMAX; ++j) {
+                        if (j < deg[u]) v[u][j] = first ? pt[(int64_t)edge_var[k0[u] + j] * 64] : msg_ld<LDPC_CN_NTL != 0>(mt + (int64_t)(k0[u] + j) * 64);
+                    }
                 }
             }
 #pragma unroll
