@@ -123,3 +123,14 @@ def test_curves_overlap_the_published_reference_results(tmp_path):
                             "--out", str(tmp_path / "c.md")], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         assert "agrees" in open(str(tmp_path / "c.md")).read()
+
+
+def test_max_frames_stops_a_low_error_point(tmp_path):
+    # --max-frames (an addition): a parameter whose word-error rate is too low to collect --min-wec errors stops at the cap --
+    # the reference's tables go down to WER ~1e-9, where its own loop would run for years (src/main.py:37)
+    from ldpc_decoders_amd import main as M
+
+    res = M.main(["bec", "1200_3_6_rand_ldpc_1", "SPA", "--codeword", "0", "--min-wec", "100000", "--max-iter", "10", "--params", "0.2",
+                  "--batch", "8192", "--max-frames", "20000", "--data_dir", str(tmp_path), "--console"])
+    r = res[0.2]
+    assert r["tot"] == 3 * 8192 and r["wec"] < 100000  # whole rounds: the first total at or above the cap
