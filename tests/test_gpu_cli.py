@@ -125,11 +125,12 @@ def test_curves_overlap_the_published_reference_results(tmp_path):
         assert "agrees" in open(str(tmp_path / "c.md")).read()
 
 
-def test_max_frames_stops_a_low_error_point(tmp_path):
+def test_max_frames_stops_a_low_error_point(tmp_path, monkeypatch):
     # --max-frames (an addition): a parameter whose word-error rate is too low to collect --min-wec errors stops at the cap --
     # the reference's tables go down to WER ~1e-9, where its own loop would run for years (src/main.py:37)
-    from ldpc_decoders_amd import main as M
+    from ldpc_decoders_amd import codes, main as M
 
+    monkeypatch.setenv(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
     res = M.main(["bec", "1200_3_6_rand_ldpc_1", "SPA", "--codeword", "0", "--min-wec", "100000", "--max-iter", "10", "--params", "0.2",
                   "--batch", "8192", "--max-frames", "20000", "--data_dir", str(tmp_path), "--console"])
     r = res[0.2]
