@@ -153,3 +153,45 @@ def test_fp64_in_kernel_channel_equals_the_channel_kernel(name, alg, channel, pa
         _lib.check(_lib.load().ldpc_count_errors(xh.data_ptr(), None, cw, it.data_ptr(), B, g.n, 41, ref.data_ptr(), st))
         assert cnt.cpu().tolist() == ref.cpu().tolist()
         assert cnt[0].item() == B and cnt[3].item() > B
+
+
+def test_streaming_backend_high_degrees():
+    # the streaming kernels take node degrees up to 64 (instantiated maxima 4, 6, 8, 16, 32, 64): a (5,20)-regular code, a (3,33)-regular one
+    # (odd degree beyond 32) and a hand-made matrix with check degrees spread from 2 to 40 and variable degrees from 1 to 24, all three
+    # decoders and both arithmetics against the C oracle
+    import bp_oracle as O
+    import c_oracle as C
+    from ldpc_decoders_amd import bpa, bec, codes
+    from ldpc_decoders_amd.codes import Code
+
+    rng = np.random.RandomState(12)
+    cases = [codes.rand_reg_ldpc(2000, 5, 20, rng), codes.rand_reg_ldpc(1980, 3, 33, rng)]
+    # spread degrees: check i takes (2 + i % 39) distinct variables drawn with a skew towards low indices
+    n, m = 900, 300
+    rows = []
+    for i in range(m):
+        d = 2 + i % 39
+        p = 1.0 / (1.0 + np.arange(n) / 40.0)
+        rows.append(sorted(rng.choice(n, size=d, replace=False, p=p / p.sum()).tolist()))
+    chk = np.concatenate([[i] * len(r) for i, r in enumerate(rows)]).astype(np.int32)
+    var = np.concatenate(rows).astype(np.int32)
+    spread = Code.from_edges(m, n, chk, var)
+    assert spread.row_degrees().max() == 40 and spread.col_degrees().max() >= 20 and spread.col_degrees().min() <= 1
+    cases.append(spread)
+    for code in cases:
+        class G:
+            m, n, chk, var = code.m, code.n, code.edge_chk, code.edge_var
+
+        B = 130
+        y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(4.0)), (B, code.n))
+        pri = O.biawgn_priors(y, 4.0)
+        for prec, dt in (("f64", np.float64), ("f32", np.float32)):
+            dec = bpa.MSA(code, max_iter=12, precision=prec, backend="auto")
+            xhat, iters = dec.decode_batch(None, pri.astype(dt))
+            assert dec.handle.last_stats()[0] == "stream"
+            xo, io = C.bp_decode(G, "MSA", None, pri.astype(dt), 12, dtype=dt)
+            assert (xhat == xo).all() and (iters == io).all()
+        ys = (rng.random_sample((B, code.n)) < 0.25).astype(np.uint8) * 2  # erasures of the all-zero word
+        xb, ib = bec.SPA(0.25, code, max_iter=12).decode_batch(ys)
+        xo, io = C.bec_decode(G, ys, 12)
+        assert (xb == xo).all() and (ib == io).all()
