@@ -148,3 +148,24 @@ def test_fp64_simulate_on_the_lds_kernel_equals_streaming(channel, param):
         res[be] = cnt.cpu().numpy()
     assert (res["fused"] == res["stream"]).all() and res["fused"][0] == 3000 and 0 < res["fused"][1] < 3000
     assert res["fused"][4:].sum() == 3000
+
+
+@pytest.mark.parametrize("prec,dt", [("f64", np.float64), ("f32", np.float32)])
+def test_whole_batch_against_the_oracle(prec, dt):
+    # not a sample: EVERY frame of a 16 384-frame device-noise batch (config 2's code, min-sum, max_iter 50), at an SNR where nearly
+    # every frame fails and at one where frames leave after 5..50 sweeps, re-decoded by the C oracle on the host threads --
+    # decisions and iteration counts identical, frame for frame, on the LDS-resident backend
+    from ldpc_decoders_amd._device import DecoderHandle
+    from ldpc_decoders_amd.codes import Code
+
+    g = golden_edges("1200_3_6_rand_ldpc_1")
+    h = DecoderHandle(Code.from_edges(g.m, g.n, g.chk, g.var), "MSA", prec, "fused")
+    B = 16384
+    for snr in (1.0, 2.0):
+        pri, _ = h.channel_device("biawgn", snr, 0, 77, 3, 0, B)
+        xhat, iters = h.decode_device(pri, None, 50)
+        xo, io = C.bp_decode(g, "MSA", None, pri.cpu().numpy(), 50, dtype=dt)
+        xh, it = xhat.cpu().numpy(), iters.cpu().numpy()
+        assert h.last_stats()[0] == "fused"
+        assert (it == io).all() and (xh == xo).all(), (prec, snr, int((it != io).sum()), int((xh != xo).any(axis=1).sum()))
+        assert len(np.unique(it)) > (3 if snr == 1.0 else 20)
