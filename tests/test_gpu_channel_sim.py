@@ -169,3 +169,25 @@ def test_whole_batch_against_the_oracle(prec, dt):
         assert h.last_stats()[0] == "fused"
         assert (it == io).all() and (xh == xo).all(), (prec, snr, int((it != io).sum()), int((xh != xo).any(axis=1).sum()))
         assert len(np.unique(it)) > (3 if snr == 1.0 else 20)
+
+
+def test_whole_batch_erasure_decoder_against_the_oracle():
+    # the same for the erasure decoder (integer arithmetic: exact), device-generated erasures at eps = 0.42 where frames end in
+    # stopping sets as often as they decode: every one of 16 384 frames, symbols {0, 1, 2} and sweep counts, both backends
+    from ldpc_decoders_amd._device import DecoderHandle
+    from ldpc_decoders_amd.codes import Code
+
+    g = golden_edges("1200_3_6_rand_ldpc_1")
+    code = Code.from_edges(g.m, g.n, g.chk, g.var)
+    B = 16384
+    ref = None
+    for backend in ("fused", "stream"):
+        h = DecoderHandle(code, "BEC", "f32", backend)
+        _, y = h.channel_device("bec", 0.42, 0, 5, 1, 0, B)
+        xhat, iters = h.decode_device(None, y, 50)
+        xh, it = xhat.cpu().numpy(), iters.cpu().numpy()
+        assert h.last_stats()[0] == backend
+        if ref is None:
+            ref = C.bec_decode(g, y.cpu().numpy(), 50)
+        assert (xh == ref[0]).all() and (it == ref[1]).all(), backend
+    assert 0.05 < (ref[0] == 2).any(axis=1).mean() < 0.95  # stopping sets and complete decodes both present
