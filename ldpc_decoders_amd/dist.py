@@ -91,7 +91,10 @@ def init_from_env(prefer_gpu=True):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if not td.is_initialized():
-            td.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw = {}
+            if backend == "nccl" and use_gpu:  # bind the communicator to this rank's GPU (also what barrier() then uses)
+                kw["device_id"] = torch.device("cuda", local % max(1, torch.cuda.device_count()))
+            td.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return Comm(rank, world, local, backend, group=(world > 1 or force))
 
 
