@@ -4,8 +4,10 @@
 
 Same positional/flag grammar, same logger names, same JSON result files (see ``utils``), so the arg-lines emitted by
 the reference's ``simulations.py`` run unchanged and ``graph.py`` reads the outputs.  Differences, all additive:
-frames are decoded in batches on the GPU; ``--exact`` selects the reference-exact mode (host noise, sequential
-stopping rule); under ``torchrun`` each rank drives one GPU and the counters are all-reduced once per round.
+frames are decoded in batches on the GPU (``--batch`` per round and rank, ``--seed`` for the device noise, ``--precision`` /
+``--backend`` for the kernels, ``--max-frames`` to stop a parameter whose error rate is too low to reach ``--min-wec``); ``--exact``
+selects the reference-exact mode (host noise, sequential stopping rule, ``--np-seed``); under ``torchrun`` each rank drives one GPU
+and the counters are all-reduced once per round.
 """
 import logging
 import time
