@@ -4,7 +4,7 @@
 A "step" is one pass of the hot path over one batch of synthetic input, entirely on the GPU:
     BI-AWGN channel + LLR (Philox noise, all-zero word) -> flooding min-sum decode (syndrome early exit as in the
     reference) -> bit/word error counters.
-Workload = BASELINE.json configs[1]: code 1200_3_6_rand_ldpc_1 (the reference's own H, tests/golden/codes fixture), batch
+Workload = BASELINE.json configs[1]: code 1200_3_6_rand_ldpc_1 (the reference's own H, shipped in ldpc_decoders_amd/data/codes), batch
 65 536 frames per GPU.  Message arithmetic: fp64 by default -- the reference's own, hard decisions and iteration counts
 bit-identical to it (LDS-resident fp64 min-sum kernel) --; `--precision f32` is the throughput mode, reported beside it under
 "fp32_mode".  Default operating point 1.0 dB: every frame fails there, so every frame executes exactly 50 sweeps -- the honest
@@ -41,7 +41,7 @@ NOMINAL_CLOCK_HZ = 2.4e9  # max shader clock; the effective clock of a profiled 
 
 
 def load_code(name):
-    """A code file of tests/golden/codes (the reference's data/codes files, kept as fixtures), or a generated ensemble member:
+    """A code file of the reference (its data/codes files ship inside the package), or a generated ensemble member:
     'gen:reg:<n>:<l>:<r>' / 'gen:irg:<n>' (BASELINE configs 4-5)."""
     from ldpc_decoders_amd import codes
 
@@ -51,7 +51,7 @@ def load_code(name):
         if parts[1] == "reg":
             return codes.rand_reg_ldpc(int(parts[2]), int(parts[3]), int(parts[4]), rng)
         return codes.rand_irregular_ldpc(int(parts[2]), codes.LAMBDA_RHO_X5_HALF_RATE, 6, rng)
-    return codes.load_parity_mtx(os.path.join(ROOT, "tests", "golden", "codes", name + ".txt"))
+    return codes.load_parity_mtx(os.path.join(codes.PACKAGE_CODES_DIR, name + ".txt"))
 
 
 def cpu_baseline(code, snr, max_iter, precision="f64", budget_s=12.0):

@@ -15,9 +15,17 @@ import numpy as np
 file_codes_dir_string = "FILE_CODES_DIR"
 
 
+PACKAGE_CODES_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "codes")  # the reference's 27 data/codes files
+
+
 def _file_codes_dir():
-    # src/codes.py:68-70: env var or ./data/codes relative to the working directory
-    return os.path.abspath(os.environ.get(file_codes_dir_string, os.path.join("data", "codes")))
+    """src/codes.py:68-70: $FILE_CODES_DIR, else ./data/codes relative to the working directory -- and, where upstream would
+    find nothing (it is always run from its own checkout), the copies of its data/codes files that ship inside this package."""
+    env = os.environ.get(file_codes_dir_string)
+    if env:
+        return os.path.abspath(env)
+    cwd = os.path.abspath(os.path.join("data", "codes"))
+    return cwd if os.path.isdir(cwd) else PACKAGE_CODES_DIR
 
 
 class Code:

@@ -7,7 +7,7 @@ hard decisions, iteration counts, marginals and Monte-Carlo counters.  No refere
 source travels.  Usage:   python oracle/make_goldens.py [--quick]
 
 Fixtures written
-  tests/golden/codes/<name>.txt      copies of the H data files used by the vectors
+  ldpc_decoders_amd/data/codes/<name>.txt      copies of the H data files used by the vectors
   tests/golden/codes_edges.npz       edge lists as loaded by the reference loader (src/codes.py:93-105)
   tests/golden/kat.json              the six known-answer tests + reference outputs (src/{biawgn,bsc,bec}.py Test.test_all)
   tests/golden/decode_<tag>.npz      per case: seed, received words, x_hat (packed), iterations, marginal traces

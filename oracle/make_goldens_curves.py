@@ -11,8 +11,8 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 import ref_import  # noqa: E402
 
-# every code whose H the build can construct: all 27 data/codes files (fixtures under tests/golden/codes) + the built-in toy codes
-CODES = {os.path.splitext(f)[0] for f in os.listdir(os.path.join(ROOT, "tests", "golden", "codes"))} | {"4_2_test", "6_2_3_ldpc", "7_4_hamming", "12_3_4_ldpc"}
+# every code whose H the build can construct: all 27 data/codes files (shipped in ldpc_decoders_amd/data/codes) + the built-in toy codes
+CODES = {os.path.splitext(f)[0] for f in os.listdir(os.path.join(ROOT, "ldpc_decoders_amd", "data", "codes"))} | {"4_2_test", "6_2_3_ldpc", "7_4_hamming", "12_3_4_ldpc"}
 DECODERS = {"SPA", "MSA", "ML", "ADMM"}
 
 out = []

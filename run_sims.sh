@@ -2,7 +2,7 @@
 # Counterpart of the reference's run_sims.sh for the GPU build.
 #   ./run_sims.sh SEQL REG_ENS --data_dir=./data --console     one run after another on GPU 0
 #   ./run_sims.sh PARA REG_ENS --data_dir=./data               runs dealt round-robin over the node's GPUs, in parallel
-# FILE_CODES_DIR must point at the directory with the code files (e.g. the reference's data/codes).
+# Code names resolve against $FILE_CODES_DIR, else ./data/codes, else the reference's data/codes files shipped inside the package.
 MODE=${1:-SEQL}
 CASE=$2
 OTHER=${@:3:99}

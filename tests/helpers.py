@@ -8,6 +8,8 @@ import numpy as np
 import bp_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# the reference's data/codes files ship inside the package (ldpc_decoders_amd/data/codes)
+CODES_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ldpc_decoders_amd", "data", "codes")
 
 
 def golden_edges(name):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import admm_oracle as A
-from helpers import GOLDEN
+from helpers import CODES_DIR, GOLDEN
 from test_oracle_admm import admm_arrays, admm_cases, graph_of
 
 pytestmark = pytest.mark.gpu
@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def _code(name):
     from ldpc_decoders_amd import codes
 
-    os.environ.setdefault(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
+    os.environ.setdefault(codes.file_codes_dir_string, CODES_DIR)
     return codes.get_code(name)
 
 
@@ -25,7 +25,7 @@ def _code(name):
 def test_admm_bit_exact_vs_reference(case, monkeypatch):
     from ldpc_decoders_amd import admm, codes
 
-    monkeypatch.setenv(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
+    monkeypatch.setenv(codes.file_codes_dir_string, CODES_DIR)
     a = admm_arrays(case)
     dec = admm.ADMM(codes.get_code(case["code"]), mu=case["mu"], eps=case["eps"], max_iter=case["max_iter"],
                     allow_pseudo=case["allow_pseudo"], log_freq=5.0)  # unknown keywords are ignored, as upstream

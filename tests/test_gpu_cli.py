@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, main_counter_cases
+from helpers import CODES_DIR, GOLDEN, main_counter_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,7 @@ def _is_llr_spa(run):
 def _run_exact(run, tmp_path, monkeypatch):
     from ldpc_decoders_amd import codes, main
 
-    monkeypatch.setenv(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
+    monkeypatch.setenv(codes.file_codes_dir_string, CODES_DIR)
     argv = run["argline"].split() + ["--data_dir", str(tmp_path), "--console", "--exact", "--np-seed", str(run["seed"])]
     main.main(argv)
     with open(os.path.join(str(tmp_path), run["file_name"])) as fp:
@@ -99,7 +99,7 @@ def test_exact_mode_sum_product_lines_through_hip(run, tmp_path, monkeypatch, ca
 def test_device_mode_schema_and_rates(tmp_path, monkeypatch):
     from ldpc_decoders_amd import codes, main
 
-    monkeypatch.setenv(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
+    monkeypatch.setenv(codes.file_codes_dir_string, CODES_DIR)
     argv = "biawgn 1200_3_6_rand_ldpc_1 MSA --codeword 0 --min-wec 200 --max-iter 10 --params 2.0 2.5 --batch 8192".split()
     res = main.main(argv + ["--data_dir", str(tmp_path), "--console"])
     data = json.load(open(os.path.join(str(tmp_path), "biawgn-1200_3_6_rand_ldpc_1-MSA-0-200-10.json")))
@@ -130,7 +130,7 @@ def test_max_frames_stops_a_low_error_point(tmp_path, monkeypatch):
     # the reference's tables go down to WER ~1e-9, where its own loop would run for years (src/main.py:37)
     from ldpc_decoders_amd import codes, main as M
 
-    monkeypatch.setenv(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
+    monkeypatch.setenv(codes.file_codes_dir_string, CODES_DIR)
     res = M.main(["bec", "1200_3_6_rand_ldpc_1", "SPA", "--codeword", "0", "--min-wec", "100000", "--max-iter", "10", "--params", "0.2",
                   "--batch", "8192", "--max-frames", "20000", "--data_dir", str(tmp_path), "--console"])
     r = res[0.2]

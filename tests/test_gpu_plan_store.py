@@ -1,4 +1,4 @@
-"""The shipped LDS layout plans against the matrices they were made for: every code file of the reference (tests/golden/codes, the
+"""The shipped LDS layout plans against the matrices they were made for: every code file of the reference (ldpc_decoders_amd/data/codes, the
 reference's data/codes) constructs its decoders from a stored plan -- no annealing at construction, few bank-conflict cycles -- and
 decodes bit-identically to the C oracle in the reference's arithmetic."""
 import glob
@@ -9,10 +9,10 @@ import pytest
 
 import bp_oracle as O
 import c_oracle as C
-from helpers import GOLDEN
+from helpers import CODES_DIR, GOLDEN
 
 pytestmark = pytest.mark.gpu
-NAMES = sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(GOLDEN, "codes", "*.txt")))
+NAMES = sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(CODES_DIR, "*.txt")))
 
 
 def test_all_reference_code_files_are_fixtures():
@@ -26,7 +26,7 @@ def test_stored_plan_and_parity(name, monkeypatch, tmp_path):
     monkeypatch.setenv("LDPC_FUSED_PLAN_SAVE", "none")            # nothing may be annealed-and-kept here ...
     monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "empty"))  # ... nor found in a user cache: only the shipped plans count
     monkeypatch.setenv("LDPC_FUSED_PLAN_MOVES", "1000")            # a plan that is NOT in the store would show up with hundreds of conflict cycles
-    code = codes.load_parity_mtx(os.path.join(GOLDEN, "codes", name + ".txt"))
+    code = codes.load_parity_mtx(os.path.join(CODES_DIR, name + ".txt"))
 
     class G:
         m, n, chk, var = code.m, code.n, code.edge_chk, code.edge_var

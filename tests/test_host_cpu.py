@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, golden_edges
+from helpers import CODES_DIR, GOLDEN, golden_edges
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -67,10 +67,41 @@ def test_builtin_codes_match_reference(name):
 def test_file_loader_matches_reference(name, monkeypatch):
     from ldpc_decoders_amd import codes
 
-    monkeypatch.setenv(codes.file_codes_dir_string, os.path.join(GOLDEN, "codes"))
+    monkeypatch.setenv(codes.file_codes_dir_string, CODES_DIR)
     assert name in codes.get_code_names()
     c, g = codes.get_code(name), golden_edges(name)
     assert (c.m, c.n, c.E) == (g.m, g.n, g.E) and (c.edge_chk == g.chk).all() and (c.edge_var == g.var).all()
+
+
+def test_code_names_resolve_without_environment(tmp_path, monkeypatch):
+    """src/codes.py:68-90 resolves names against $FILE_CODES_DIR or ./data/codes; upstream is always run from its own checkout, so its
+    27 data/codes files ship inside the package and are what a bare `python -m ldpc_decoders_amd.main ...` finds."""
+    import subprocess
+    import sys
+
+    from ldpc_decoders_amd import codes, utils
+
+    monkeypatch.delenv(codes.file_codes_dir_string, raising=False)
+    monkeypatch.chdir(tmp_path)  # no ./data/codes here
+    names = codes.get_code_names()
+    assert len(names) == 4 + 27 and "1200_3_6_rand_ldpc_1" in names and "margulis" in names
+    c, g = codes.get_code("1200_3_6_rand_ldpc_1"), golden_edges("1200_3_6_rand_ldpc_1")
+    assert (c.edge_chk == g.chk).all() and (c.edge_var == g.var).all()
+    # the argparse `choices` of the CLI (src/utils.py:24-27) accept the name from a clean environment
+    parser = utils.setup_parser(codes.get_code_names(), ["biawgn", "bsc", "bec"], utils.decoder_names)
+    args = parser.parse_args(["biawgn", "1200_3_6_rand_ldpc_1", "MSA", "--max-iter", "50", "--params", "2.0", "--console"])
+    assert args.code == "1200_3_6_rand_ldpc_1"
+    env = {k: v for k, v in os.environ.items() if k != codes.file_codes_dir_string}
+    env["PYTHONPATH"] = ROOT
+    r = subprocess.run([sys.executable, "-c", "from ldpc_decoders_amd import codes; print(len(codes.get_code_names()), codes.get_code('margulis').n)"],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.split() == ["31", "2640"], r.stderr
+    # ./data/codes of the working directory still shadows the packaged files, $FILE_CODES_DIR shadows both (upstream order)
+    os.makedirs(tmp_path / "data" / "codes")
+    (tmp_path / "data" / "codes" / "tiny.txt").write_text("1 2\n2 3\n")
+    assert set(codes.get_code_names()) == {"4_2_test", "6_2_3_ldpc", "7_4_hamming", "12_3_4_ldpc", "tiny"}
+    monkeypatch.setenv(codes.file_codes_dir_string, CODES_DIR)
+    assert "margulis" in codes.get_code_names() and "tiny" not in codes.get_code_names()
 
 
 def test_loader_edge_cases(tmp_path):
@@ -253,7 +284,7 @@ def test_host_only_layout_planning_and_plan_store(tmp_path):
     from ldpc_decoders_amd import _lib, codes
 
     lib = _lib.load()
-    code = codes.load_parity_mtx(os.path.join(ROOT, "tests", "golden", "codes", "1200_3_6_rand_ldpc_1.txt"))
+    code = codes.load_parity_mtx(os.path.join(CODES_DIR, "1200_3_6_rand_ldpc_1.txt"))
     chk = np.ascontiguousarray(code.edge_chk, dtype=np.int32)
     var = np.ascontiguousarray(code.edge_var, dtype=np.int32)
     info = (ctypes.c_double * 4)()

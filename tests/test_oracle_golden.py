@@ -7,7 +7,7 @@ import pytest
 
 import bp_oracle as O
 import c_oracle as C
-from helpers import (GOLDEN, case_id, decode_cases, expected_xhat, golden_edges, kat_cases, load_case, main_counter_cases)
+from helpers import (CODES_DIR, GOLDEN, case_id, decode_cases, expected_xhat, golden_edges, kat_cases, load_case, main_counter_cases)
 
 
 @pytest.mark.parametrize("kat", kat_cases(), ids=lambda k: "%s-%s-%s" % (k["channel"], k["code"], k["decoder"]))
@@ -24,7 +24,7 @@ def test_known_answer(kat):
 @pytest.mark.parametrize("name", ["1200_3_6_rand_ldpc_1", "1200_rho_x5_rand_ldpc_5", "512_3_6_rand_ldpc_2", "margulis", "1200_3_6_ldpc"])
 def test_loader_matches_reference(name):
     # reference: codes.load_parity_mtx (src/codes.py:93-105) incl. the var-1 quirk on the 0-based margulis file
-    with open(os.path.join(GOLDEN, "codes", name + ".txt")) as fp:
+    with open(os.path.join(CODES_DIR, name + ".txt")) as fp:
         g = O.parse_parity_text(fp.read())
     ref = golden_edges(name)
     assert (g.m, g.n, g.E) == (ref.m, ref.n, ref.E)

@@ -83,7 +83,7 @@ def test_layout_planner_under_asan(tmp_path, code_name, cr, vr, vrx, nw):
         if "error:" in r.stderr and "ldpc_" in r.stderr:
             pytest.fail("planner harness does not compile: " + r.stderr[-1500:])
         pytest.skip("sanitized host build unavailable here: " + r.stderr[-300:])
-    code_file = os.path.join(ROOT, "tests", "golden", "codes", code_name + ".txt")
+    code_file = os.path.join(ROOT, "ldpc_decoders_amd", "data", "codes", code_name + ".txt")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
     plans = os.path.join(ROOT, "ldpc_decoders_amd", "plans")
     out = subprocess.run([exe, code_file, str(cr), str(vr), str(vrx), str(tmp_path), plans, str(nw)], capture_output=True, text=True,

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from ldpc_decoders_amd import codes
 from ldpc_decoders_amd._device import AdmmHandle
-os.environ.setdefault(codes.file_codes_dir_string, os.path.join(ROOT, "tests", "golden", "codes"))
+os.environ.setdefault(codes.file_codes_dir_string, os.path.join(ROOT, "ldpc_decoders_amd", "data", "codes"))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 code = codes.get_code("1200_3_6_rand_ldpc_1")
 nv = 10 ** (-2.2 / 10)

@@ -7,7 +7,7 @@ import numpy as np, torch
 import admm_oracle as A
 from ldpc_decoders_amd import codes
 from ldpc_decoders_amd._device import AdmmHandle
-os.environ.setdefault(codes.file_codes_dir_string, os.path.join(ROOT, "tests", "golden", "codes"))
+os.environ.setdefault(codes.file_codes_dir_string, os.path.join(ROOT, "ldpc_decoders_amd", "data", "codes"))
 for name, B, snr, mi in (("1200_3_6_rand_ldpc_1", 8192, 2.2, 300), ("1200_3_6_rand_ldpc_1", 8192, 3.0, 300), ("7_4_hamming", 1 << 20, 2.0, 100)):
     code = codes.get_code(name)
     rng = np.random.RandomState(1)

@@ -48,7 +48,7 @@ def main():
                          "atanh, artefacts included); f32: the throughput mode (min-sum over the BSC stays fp64: tie-dominated)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "curves_vs_reference.md"))
     a = ap.parse_args()
-    os.environ.setdefault(codes.file_codes_dir_string, os.path.join(ROOT, "tests", "golden", "codes"))
+    os.environ.setdefault(codes.file_codes_dir_string, os.path.join(ROOT, "ldpc_decoders_amd", "data", "codes"))
     with open(os.path.join(ROOT, "tests", "golden", "published_curves.json")) as fp:
         curves = json.load(fp)
     rows, bad = [], []

@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--moves", type=int, default=300000000)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "plans"))
     ap.add_argument("--codes", nargs="*", default=None, help="default: every *.txt of --codes-dir")
-    ap.add_argument("--codes-dir", default=os.path.join(ROOT, "tests", "golden", "codes"))
+    ap.add_argument("--codes-dir", default=os.path.join(ROOT, "ldpc_decoders_amd", "data", "codes"))
     ap.add_argument("--jobs", type=int, default=max(1, (os.cpu_count() or 2) - 2))
     ap.add_argument("--nw", default="", help="LDPC_FUSED_NW: plan a non-default number of waves per frame")
     a = ap.parse_args()

@@ -4,7 +4,7 @@ the LP lines are not built) through ldpc_decoders_amd.main, in one process, with
 file with the reference's name and keys; a parameter whose word-error rate is too low to collect min_wec errors within --max-frames
 (the tables go down to WER ~1e-9, where the reference itself would run for years) stops at the cap and is reported.
 
-    python tools/run_all_sim_lines.py [--cases HMG MAR ...] [--out DIR]      (codes: tests/golden/codes)"""
+    python tools/run_all_sim_lines.py [--cases HMG MAR ...] [--out DIR]      (codes: ldpc_decoders_amd/data/codes)"""
 import argparse
 import json
 import os
@@ -23,7 +23,7 @@ def run():
     ap.add_argument("--out", default=None)
     ap.add_argument("--max-frames", type=int, default=1 << 25, help="safety cap per parameter (a point that needs more is reported, not failed)")
     a = ap.parse_args()
-    os.environ.setdefault(codes.file_codes_dir_string, os.path.join(ROOT, "tests", "golden", "codes"))
+    os.environ.setdefault(codes.file_codes_dir_string, os.path.join(ROOT, "ldpc_decoders_amd", "data", "codes"))
     out = a.out or tempfile.mkdtemp(prefix="simlines_")
     os.makedirs(out, exist_ok=True)
     rows, t_all = [], time.time()
