@@ -38,6 +38,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 NOMINAL_CLOCK_HZ = 2.4e9  # max shader clock; the effective clock of a profiled run is in profiles/lds_cycles.json
+KERNEL_CLASSES = ("stream_check_pass", "stream_variable_pass", "fused_decode")  # per-kernel HIP-event classes of ldpc_decoder_profile
 
 
 def load_code(name):
@@ -224,7 +225,7 @@ def main():
         del sim3, h3
 
     def kernel_ms(r):
-        return None if not r.get("profile") else sum(v[0] for v in r["profile"].values())
+        return None if not r.get("profile") else sum(r["profile"][k][0] for k in KERNEL_CLASSES)
 
     def summarise(snr, r, steps):
         c = r["counters"]
@@ -248,7 +249,7 @@ def main():
         roof = None
         prof = res["profile"]
         if prof:
-            kind = max(prof, key=lambda k: prof[k][0])  # dominant kernel = the class with the most event time on rank 0
+            kind = max(KERNEL_CLASSES, key=lambda k: prof[k][0])  # dominant kernel = the class with the most event time on rank 0
             ms, launches = prof[kind]
             frac_bytes = {"stream_check_pass": 2 * code.E * s, "stream_variable_pass": (2 * code.E + code.n) * s,
                           "fused_decode": bytes_per_frame_iter}[kind]

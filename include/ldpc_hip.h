@@ -79,10 +79,11 @@ int ldpc_plan_layout(int32_t m, int32_t n, int64_t E, const int32_t* edge_chk, c
 
 /* Per-kernel timing for roofline reports: when enabled, decode calls bracket their dominant kernels with HIP events
  * recorded ON THE DECODE STREAM and accumulate elapsed milliseconds / launch counts per kernel class:
- * [0] streaming check pass, [1] streaming variable pass, [2] fused decode kernel.  Enabling it makes every decode
- * call end with a stream synchronise. */
+ * [0] streaming check pass, [1] streaming variable pass, [2] fused decode kernel, [3] a whole streaming decode, first to last
+ * enqueued kernel (the two passes + tile load, syndrome, repack and unpack kernels: [3] - [0] - [1] is what the side kernels cost).
+ * Enabling it makes every decode call end with a stream synchronise. */
 int ldpc_decoder_profile(ldpc_decoder_t dec, int enable);
-int ldpc_decoder_profile_read(ldpc_decoder_t dec, double* ms3, int64_t* launches3, int reset);
+int ldpc_decoder_profile_read(ldpc_decoder_t dec, double* ms4, int64_t* launches4, int reset);
 
 /* Batched BPA.decode(y, priors) (src/bpa.py:17-63) / bec.SPA.decode(y) (src/bec.py:83-122).
  *   priors_dev  [B,n] float or double per `dtype` (ignored for LDPC_ALG_BEC)

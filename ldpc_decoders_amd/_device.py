@@ -195,10 +195,10 @@ class DecoderHandle:
 
     def read_profile(self, reset=True):
         """-> {kernel class: (milliseconds, launches)} accumulated since the last reset (HIP events on the decode stream)."""
-        ms = (ctypes.c_double * 3)()
-        ln = (ctypes.c_int64 * 3)()
+        ms = (ctypes.c_double * 4)()
+        ln = (ctypes.c_int64 * 4)()
         _lib.check(_lib.load().ldpc_decoder_profile_read(self.h, ms, ln, 1 if reset else 0))
-        return {k: (ms[i], ln[i]) for i, k in enumerate(("stream_check_pass", "stream_variable_pass", "fused_decode"))}
+        return {k: (ms[i], ln[i]) for i, k in enumerate(("stream_check_pass", "stream_variable_pass", "fused_decode", "stream_decode_total"))}
 
     def last_stats(self):
         b, s = ctypes.c_int(0), ctypes.c_int(0)

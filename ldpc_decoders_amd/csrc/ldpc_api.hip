@@ -131,7 +131,7 @@ using namespace ldpc;
 extern "C" {
 
 const char* ldpc_last_error(void) { return last_error(); }
-int ldpc_abi_version(void) { return 1; }
+int ldpc_abi_version(void) { return 2; }
 
 int ldpc_device_count(int* count) {
     if (!count) return LDPC_E_ARG;
@@ -237,7 +237,7 @@ int ldpc_decoder_destroy(ldpc_decoder_t h) {
     if (!d) return LDPC_OK;
     (void)hipSetDevice(d->code->device);
     fused_plan_destroy(d);
-    for (DevBuf* b : {&d->msg, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->msg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap, &d->fmap2, &d->rbase, &d->h_in, &d->h_y0, &d->h_out,
+    for (DevBuf* b : {&d->msg, &d->marg, &d->marg2, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->msg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap, &d->fmap2, &d->rbase, &d->h_in, &d->h_y0, &d->h_out,
                       &d->h_iters})
         b->release();
     if (d->pinned) (void)hipHostFree(d->pinned);
@@ -277,7 +277,7 @@ int ldpc_decoder_profile(ldpc_decoder_t h, int enable) {
 int ldpc_decoder_profile_read(ldpc_decoder_t h, double* ms, int64_t* launches, int reset) {
     Decoder* d = (Decoder*)h;
     if (!d) return LDPC_E_ARG;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         if (ms) ms[i] = d->prof_ms[i];
         if (launches) launches[i] = d->prof_launches[i];
         if (reset) {

@@ -5,8 +5,8 @@
 //     np.where(H) used by the reference, src/bpa.py:12) + CSR row pointers + CSC lists, resident in HBM.
 //   * Frames are processed in TILES of 64: one wavefront lane <-> one frame, so every H index is
 //     wave-uniform (scalar loads) and every message access is one contiguous 64-element line.
-//   * Streaming backend: per tile, messages live in HBM as msg[tile][edge][64]; one array is updated
-//     in place by the check pass (v2c -> c2v) and the variable pass (c2v -> v2c).
+//   * Streaming backend: per tile, check -> variable messages c2v[tile][edge][64] and marginals marg[tile][n][64] live in HBM;
+//     the check pass forms v2c = marg - c2v_old on the fly, the variable pass rebuilds the marginals (ldpc_stream.hip).
 //   * Fused backend (regular codes whose state fits the LDS): one wavefront owns one frame for all
 //     iterations; messages never leave the CU.
 #pragma once
@@ -84,8 +84,8 @@ struct Decoder {
     Code* code = nullptr;
     int alg = ALG_MSA, dtype = DT_F32, backend = BK_AUTO;
     // streaming workspace
-    DevBuf msg, prior, xbits, xera, live, flags, scratch;
-    DevBuf msg2, prior2, xbits2, live2, fmap, fmap2, rbase;  // second state set + frame maps of the early-termination repack
+    DevBuf msg, marg, prior, xbits, xera, live, flags, scratch;  // msg = check -> variable messages
+    DevBuf msg2, marg2, prior2, xbits2, live2, fmap, fmap2, rbase;  // second state set + frame maps of the early-termination repack
     // fused backend
     FusedPlan* fused = nullptr;
     // staging used by the *_host entry points
@@ -94,8 +94,8 @@ struct Decoder {
     // optional per-kernel timing with HIP events recorded on the decode stream (bench.py roofline leg)
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
-    double prof_ms[3] = {0, 0, 0};        // [0] check pass, [1] variable pass, [2] fused decode kernel
-    int64_t prof_launches[3] = {0, 0, 0};
+    double prof_ms[4] = {0, 0, 0, 0};     // [0] check pass, [1] variable pass, [2] fused decode kernel, [3] whole streaming decode
+    int64_t prof_launches[4] = {0, 0, 0, 0};
     // statistics of the last decode call
     int last_sweeps = 0;
     int last_backend = BK_STREAM;

@@ -438,6 +438,11 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
     a.zero_row = p->zero_row;
     a.sys_off = p->sys_off;
     a.certain_entry = p->certain_entry;
+    {  // 32-bit partial counters of a workgroup (sim_count): bit errors <= n and sweeps <= max_iter per frame
+        const long long per_frame = a.n > a.max_iter ? a.n : a.max_iter;
+        long long fe = ((long long)1 << 31) / (per_frame > 0 ? per_frame : 1);
+        a.flush_every = (int)(fe < 1 ? 1 : (fe > 4096 ? 4096 : fe));
+    }
     void* args[] = {&a};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (d->profile) {
@@ -479,7 +484,7 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
 
 // channel -> LLR -> decode -> count in ONE kernel (BI-AWGN, all-`codeword` word): priors never touch HBM.
 bool fused_simulate_supported(const Decoder* d, int channel, double param, int hist_bins) {
-    if (!fused_supported(d) || hist_bins < 0 || hist_bins > 64) return false;  // 0 bins: counters only (what main.py asks for)
+    if (!fused_supported(d) || hist_bins < 0 || hist_bins > 60) return false;  // 0 bins: counters only (what main.py asks for); lanes 60..63 hold the four counters
     if (d->alg == ALG_BEC) return channel == CH_BEC;
     if (channel == CH_BSC && !(param > 0.0 && param < 0.5)) {
         // the in-kernel BSC needs llr > 0 (the received bit is the sign of the prior); the fp64 kernels can still count on priors

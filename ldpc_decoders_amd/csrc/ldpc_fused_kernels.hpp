@@ -144,7 +144,55 @@ struct FusedArgs {
     double sim_mean_d, sim_sigma_d, sim_k_d, bsc_llr_d;  // the same constants for the fp64 kernels (k_biawgn<double> / k_discrete<double>)
     uint32_t certain_entry;         // gather-table entry of the "certain" variable slot that pads short check rows (0xffffffff: none)
     unsigned long long* counters;   // [4 + hist_bins] tot, wec, bec, iter_sum, histogram of sweeps
+    int flush_every;                // SIM: frames a workgroup counts in 32-bit lanes before adding them to `counters`
 };
+
+// Monte-Carlo counters of a workgroup (SIM kernels) in ONE register: lanes [0, hist_bins) hold the histogram of executed sweeps,
+// lanes 60..63 tot / wec / bec / iter_sum (src/main.py:41-45) as 32-bit partial sums, added to the global 64-bit counters every
+// FusedArgs::flush_every frames and at the end.  (Five 64-bit accumulators + a histogram register were spilled around the sweep
+// loop and written back to scratch once per frame.)
+// SIM kernels: how many words of the packed gather tables are made opaque to the optimiser at the top of every sweep.  Left alone,
+// the optimiser unpacks the WHOLE 16-bit table into one address register per gather ahead of the frame loop (the decode kernels keep
+// the variable map in those registers; the SIM kernels do not) and then spills what no longer fits -- launch invariants around the
+// sweep loop, or table entries that are reloaded from scratch in every sweep.  An opaque word keeps its two unpacking instructions
+// in the sweep instead.  Counts found by compiling each shape over a grid of values (tools/kernel_resources.py; the CPU test
+// tests/test_host_cpu.py::test_simulate_kernels_do_not_spill pins the result): the smallest counts with no spilled register.
+#ifdef LDPC_SIM_OPAQUE_CN_WORDS  // experiments: one pair of values for every shape
+constexpr int sim_opaque_cn(int, int, int) { return LDPC_SIM_OPAQUE_CN_WORDS; }
+constexpr int sim_opaque_vn(int, int, int) { return LDPC_SIM_OPAQUE_VN_WORDS; }
+#else
+constexpr int sim_opaque_cn(int alg, int nw, int vrx) {
+    if (nw > 4) return alg == ALG_MSA ? 8 : 15;           // one frame per CU (16 waves): min-sum 8 + 15 -> no spill
+    if (alg == ALG_MSA && vrx == 0) return 0;             // regular min-sum (the headline shape): nothing needed
+    return 8;
+}
+constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
+    if (nw > 4) return alg == ALG_BEC ? 0 : 15;           // (the 16-wave erasure kernel streams its variable table anyway)
+    if (alg == ALG_MSA && vrx == 0) return 0;
+    return 15;
+}
+#endif
+constexpr int SIM_ACC_LANE0 = 60;  // hist_bins <= 60 (fused_simulate_supported)
+__device__ __forceinline__ void sim_count(unsigned& accv, int lane, int err, int it, int hist_bins) {
+    const int bin = it < hist_bins ? it : hist_bins - 1;  // no histogram: -1, no lane
+    unsigned add = (lane == bin) ? 1u : 0u;
+    add = lane == SIM_ACC_LANE0 ? 1u : add;
+    add = lane == SIM_ACC_LANE0 + 1 ? (err > 0 ? 1u : 0u) : add;
+    add = lane == SIM_ACC_LANE0 + 2 ? (unsigned)err : add;
+    add = lane == SIM_ACC_LANE0 + 3 ? (unsigned)it : add;
+    accv += add;
+}
+__device__ __forceinline__ void sim_flush(unsigned& accv, int lane, int hist_bins, unsigned long long* counters) {
+    // lane id taken afresh (v_mbcnt): the counter addresses are then formed here, not at kernel entry and carried through every sweep
+    unsigned zero = 0;
+    asm volatile("" : "+v"(zero));  // opaque: keeps the two instructions below from being hoisted to kernel entry
+    lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+    if (accv) {
+        if (lane >= SIM_ACC_LANE0) atomicAdd(&counters[lane - SIM_ACC_LANE0], (unsigned long long)accv);
+        else if (lane < hist_bins) atomicAdd(&counters[4 + lane], (unsigned long long)accv);
+    }
+    accv = 0;
+}
 
 template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 || DVX > 8 || (NW == 2 && DC >= 7)) ? 3 : 4)) void k_fused_bp(const FusedArgs A) {
@@ -195,6 +243,14 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             for (int i = VNW - VN_STREAM; i < VNW; ++i) vn_idx[i] = __builtin_nontemporal_load(A.vn_tab + (w * VNW + i) * 64 + lane);
         }
     };
+    auto opaque_tables = [&]() {  // see sim_opaque_cn
+        if constexpr (SIM) {
+#pragma unroll
+            for (int i = 0; i < sim_opaque_cn(ALG, NW, VRX) && i < CNW; ++i) asm volatile("" : "+v"(cn_idx[i]));
+#pragma unroll
+            for (int i = 0; i < sim_opaque_vn(ALG, NW, VRX) && i < VNW; ++i) asm volatile("" : "+v"(vn_idx[i]));
+        }
+    };
     auto vmap_of = [&](int q) -> int {
         if constexpr (VMAP_RESIDENT) return vmap_reg[q]; else return vslot[q * 64 + lane];
     };
@@ -214,8 +270,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
     const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
     // SIM: per-workgroup counters live in wave 0 (scalars + one histogram bin per lane), flushed once at the end
     unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
-    u64 acc_tot = 0, acc_wec = 0, acc_bec = 0, acc_it = 0;
-    unsigned hist_lane = 0;
+    unsigned accv = 0;  // sim_count / sim_flush
+    int acc_frames = 0;
     unsigned dummy = 0;  // bit q: slot (q, lane) is the "certain" slot that pads short check rows (var_of_slot == -2)
     if constexpr (SIM || ALG == ALG_BEC || VRX > 0) {
 #pragma unroll
@@ -223,6 +279,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             valid |= (vslot[q * 64 + lane] >= 0) ? (1u << q) : 0u;
             dummy |= (vslot[q * 64 + lane] == -2) ? (1u << q) : 0u;
         }
+        // one register each, opaque to the optimiser: otherwise it keeps the ten per-round masks of `valid` as ten separate
+        // launch-invariant values and spills them around the sweep loop
+        asm volatile("" : "+v"(valid), "+v"(dummy));
     }
 
     // verdict exchange between the NW waves of a frame: each wave publishes "my checks see an unsatisfied syndrome" in a
@@ -333,7 +392,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
         if constexpr (SIM) {
             // channel + LLR in the kernel: the workgroup draws the frame's noise block by block (one Philox block = 4
             // consecutive variables, exactly as k_biawgn does) and drops every prior into the LDS slot of its variable
-            for (int blk = threadIdx.x; blk * 4 < n; blk += 64 * NW) {
+            // (the thread index enters through an opaque copy: everything derived from it -- table addresses, the first Philox
+            // round -- would otherwise be hoisted out of the FRAME loop and spilled around the sweeps)
+            int tid0 = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid0));
+            for (int blk = tid0; blk * 4 < n; blk += 64 * NW) {
                 const Philox4 ph = philox_word_block(A.seed, A.stream, A.frame0 + fr, (uint32_t)blk);
                 const int4 sl = *reinterpret_cast<const int4*>(A.slot_of_var + blk * 4);
                 const int slots[4] = {sl.x, sl.y, sl.z, sl.w};
@@ -413,6 +476,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 if (max_iter > 0 && updates >= max_iter) break;
                 if (early && !erased_any) break;
                 lds_set_m0(m0_c2v);
+                opaque_tables();
                 float mg[2][DC];
 #pragma unroll
                 for (int j = 0; j < DC; ++j) mg[0][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, j));
@@ -550,6 +614,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             for (;;) {
                 if (max_iter > 0 && it >= max_iter) break;
                 lds_set_m0(m0_c2v);
+                opaque_tables();
                 // ---------------- check phase (+ syndrome of the decisions of the previous sweep)
                 uint32_t synd = 0;  // bit 31: some owned check is unsatisfied by the previous decisions
                 float mg[2][DC];
@@ -710,12 +775,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             for (int q = 0; q < VRW; ++q) err += __popcll(__ballot((wrong >> q) & 1u));
             err = exchange_add(err);
             err = __builtin_amdgcn_readfirstlane(err);  // wave-uniform: keep the accumulators in scalar registers
-            acc_tot += 1;
-            acc_wec += err > 0;
-            acc_bec += (u64)err;
-            acc_it += (u64)it;
-            const int bin = it < A.hist_bins ? it : A.hist_bins - 1;
-            hist_lane += (lane == bin) ? 1u : 0u;
+            sim_count(accv, lane, err, it, A.hist_bins);
+            if (++acc_frames >= A.flush_every) {
+                if (w == 0) sim_flush(accv, lane, A.hist_bins, A.counters);
+                accv = 0;
+                acc_frames = 0;
+            }
         } else {
             if (w == 0 && lane == 0) A.iters[fr] = it;
             uint8_t* xf = A.xhat + fr * n;
@@ -739,15 +804,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
         }
     }
     if constexpr (SIM) {
-        if (w == 0) {
-            if (lane == 0) {
-                atomicAdd(&A.counters[0], acc_tot);
-                atomicAdd(&A.counters[1], acc_wec);
-                atomicAdd(&A.counters[2], acc_bec);
-                atomicAdd(&A.counters[3], acc_it);
-            }
-            if (lane < A.hist_bins && hist_lane) atomicAdd(&A.counters[4 + lane], (u64)hist_lane);
-        }
+        if (w == 0) sim_flush(accv, lane, A.hist_bins, A.counters);
     }
 }
 
@@ -820,8 +877,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
     // counting mode (SIM, or A.counters != null): the Monte-Carlo counters of main.test (src/main.py:41-45) are accumulated here instead
     // of writing decisions and iteration counts out -- per-workgroup sums in wave 0, one histogram bin per lane, flushed once
     const bool counting = SIM || A.counters != nullptr;
-    u64 acc_tot = 0, acc_wec = 0, acc_bec = 0, acc_it = 0;
-    unsigned hist_lane = 0;
+    unsigned accv = 0;  // sim_count / sim_flush
+    int acc_frames = 0;
 
     auto any_unsat = [&](bool mine) -> bool {  // contains the barrier that separates the phases
         if constexpr (NW == 1) {
@@ -1107,12 +1164,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
                 err = sum;
             }
             err = __builtin_amdgcn_readfirstlane(err);
-            acc_tot += 1;
-            acc_wec += err > 0;
-            acc_bec += (u64)err;
-            acc_it += (u64)it;
-            const int bin = it < A.hist_bins ? it : A.hist_bins - 1;
-            hist_lane += (lane == bin) ? 1u : 0u;
+            sim_count(accv, lane, err, it, A.hist_bins);
+            if (++acc_frames >= A.flush_every) {
+                if (w == 0) sim_flush(accv, lane, A.hist_bins, A.counters);
+                accv = 0;
+                acc_frames = 0;
+            }
         } else {
             if (w == 0 && lane == 0) A.iters[fr] = it;
             uint8_t* xf = A.xhat + fr * n;
@@ -1127,15 +1184,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
             }
         }
     }
-    if (counting && w == 0) {
-        if (lane == 0) {
-            atomicAdd(&A.counters[0], acc_tot);
-            atomicAdd(&A.counters[1], acc_wec);
-            atomicAdd(&A.counters[2], acc_bec);
-            atomicAdd(&A.counters[3], acc_it);
-        }
-        if (lane < A.hist_bins && hist_lane) atomicAdd(&A.counters[4 + lane], (u64)hist_lane);
-    }
+    if (counting && w == 0) sim_flush(accv, lane, A.hist_bins, A.counters);
 }
 
 

@@ -1,14 +1,25 @@
-// Streaming backend: flooding BP with the message array resident in HBM.
+// Streaming backend: flooding BP with the message state resident in HBM.
 //
 // Layout per tile of 64 frames (lane == frame):
-//     msg  [tile][E][64]   T     one array, updated IN PLACE: check pass turns v2c into c2v, variable pass back
+//     c2v  [tile][E][64]   T     check -> variable messages, row-major edge order (the order of np.where(H), src/bpa.py:12)
+//     marg [tile][n][64]   T     marginals  prior + ordered sum of c2v  (src/bpa.py:35); also the soft output
 //     prior[tile][n][64]   T
 //     xbits[tile/8][n][8]  u64   hard decision of variable v for the 64 frames of a tile (bit f == frame f); the words of EIGHT
 //                                consecutive tiles sit in one 64-byte sector, which is what the syndrome kernel fetches per variable
 //     xera [tile/8][n][8]  u64   (erasure decoder only) "still erased" plane
 //     live [tile]          u64   frames that are still iterating
 // Every H index is wave-uniform (scalar loads); every message access is one contiguous 64-element line.
-// Algorithmic HBM traffic per frame-iteration = sizeof(T) * (4E + n)   (SURVEY.md section 8(d)).
+//
+// One sweep = two passes (round 3: the variable -> check messages are no longer stored):
+//   check pass     per check: stream its old c2v lines in, gather the marginal lines of its variables, v2c = marg - c2v_old
+//                  (src/bpa.py:37 -- the same subtraction on the same operands, so the same bits), apply the rule, stream c2v out.
+//                  Every store of the sweep's E-sized traffic is a contiguous stream; the only random accesses are READS of
+//                  marginal lines, each used by dv checks (re-reads are served by the L2 / Infinity Cache).
+//   variable pass  per variable: gather its c2v lines (read only), marg = prior + (((0 + c_a) + c_b) + ...), stream marg out,
+//                  decision bit-plane.
+// HBM bytes per frame-sweep: check pass reads E + n..E, writes E; variable pass reads E + n, writes n  --  3E + 3n when the marginal
+// re-reads hit on chip, against the s(4E + n) of SURVEY.md section 8(d) (v2c written and read back); bench.py prices the kernels
+// with the section-8(d) ALGORITHMIC bytes and reports the PMC traffic beside it.
 //
 // Reference semantics reproduced (file:line relative to thadikari/ldpc_decoders):
 //   flooding loop, max_iter and syndrome exits, x_hat = (marginal < 0) ...... src/bpa.py:17-63
@@ -27,9 +38,11 @@ namespace {
 
 using u64 = unsigned long long;
 
-// streaming (non-temporal) access to the message array, selectable per pass and per direction (measured)
+// streaming (non-temporal) access, selectable per pass and per direction (measured): the check pass streams
+// its c2v lines through with non-temporal loads AND stores so that they do not push the marginal lines (re-used dv times) out of
+// the caches
 #ifndef LDPC_CN_NTL
-#define LDPC_CN_NTL 0
+#define LDPC_CN_NTL 1
 #endif
 #ifndef LDPC_CN_NTS
 #define LDPC_CN_NTS 1
@@ -121,11 +134,22 @@ __global__ void k_init_live(u64* __restrict__ live, int64_t B, int tiles) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Check pass.  One wavefront = (tile, contiguous run of checks); UNR checks are in flight together so that
-// UNR*dc independent 256-byte (fp32) lines are outstanding per wave.
+// Check pass.  One wavefront = (tile, contiguous run of checks); UNR checks are in flight together: UNR*dc old-message lines (a
+// stream) and UNR*dc marginal lines (gathers) outstanding per wave.  `src` = the marginals, or the priors in the first sweep, when
+// the reference's v2c is the prior itself (src/bpa.py:19) and there is no old message to subtract.
+template <typename T, int ALG>
+__device__ __forceinline__ T v2c_of(T marg, T c_old) {
+    if constexpr (ALG == ALG_BEC) {
+        const int d = (int)marg - (int)c_old;  // src/bec.py:116-118: the sign of what the other checks say
+        return (T)((d > 0) - (d < 0));
+    } else {
+        return marg - c_old;  // src/bpa.py:37
+    }
+}
+
 template <typename T, int ALG, int DCMAX, int FIXED_DC, int UNR>
 __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
-                                            T* __restrict__ msg, const T* __restrict__ prior_t,
+                                            T* __restrict__ c2v, const T* __restrict__ src,
                                             const u64* __restrict__ live, int m, int n, int64_t E, int tiles, int chunks,
                                             int cpw, int first) {
     const int lane = threadIdx.x;
@@ -136,11 +160,11 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
     if (lv == 0) return;
     const bool on = (lv >> lane) & 1ull;
     const bool dense = E * 4 >= (int64_t)m * DCMAX * 3;  // average row length at least three quarters of DCMAX (wave-uniform)
-    T* mt = msg + (int64_t)tile * E * 64 + lane;
-    const T* pt = prior_t + (int64_t)tile * n * 64 + lane;
+    T* ct = c2v + (int64_t)tile * E * 64 + lane;
+    const T* st = src + (int64_t)tile * n * 64 + lane;
     const int c_end = min(m, (chunk + 1) * cpw);
     for (int c = chunk * cpw; c < c_end; c += UNR) {
-        T v[UNR][DCMAX];
+        T v[UNR][DCMAX], o[UNR][DCMAX];
         int k0[UNR], deg[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -160,15 +184,16 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
         }
         if (on) {
             // irregular rows, `dense` (most rows nearly DCMAX long): every line is fetched unconditionally (a short row re-reads its
-            // last edge) -- a branch per line keeps the loads of a group of checks from being issued together; with widely spread row
-            // lengths the branch stays
+            // last edge, an empty row edge 0) -- a branch per line keeps the loads of a group of checks from being issued together;
+            // with widely spread row lengths the branch stays
             if (FIXED_DC > 0 || dense) {
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
 #pragma unroll
                     for (int j = 0; j < DCMAX; ++j) {
-                        const int kk = FIXED_DC > 0 ? k0[u] + j : k0[u] + (j < deg[u] ? j : (deg[u] > 0 ? deg[u] - 1 : 0));
-                        v[u][j] = first ? pt[(int64_t)edge_var[kk] * 64] : msg_ld<LDPC_CN_NTL != 0>(mt + (int64_t)kk * 64);
+                        const int kk = FIXED_DC > 0 ? k0[u] + j : (deg[u] > 0 ? k0[u] + (j < deg[u] ? j : deg[u] - 1) : 0);
+                        v[u][j] = st[(int64_t)edge_var[kk] * 64];
+                        if (!first) o[u][j] = msg_ld<LDPC_CN_NTL != 0>(ct + (int64_t)kk * 64);
                     }
                 }
             } else {
@@ -176,16 +201,23 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
                 for (int u = 0; u < UNR; ++u) {
 #pragma unroll
                     for (int j = 0; j < DCMAX; ++j) {
-                        if (j < deg[u]) v[u][j] = first ? pt[(int64_t)edge_var[k0[u] + j] * 64] : msg_ld<LDPC_CN_NTL != 0>(mt + (int64_t)(k0[u] + j) * 64);
+                        if (j < deg[u]) {
+                            v[u][j] = st[(int64_t)edge_var[k0[u] + j] * 64];
+                            if (!first) o[u][j] = msg_ld<LDPC_CN_NTL != 0>(ct + (int64_t)(k0[u] + j) * 64);
+                        }
                     }
                 }
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
+                if (!first) {
+#pragma unroll
+                    for (int j = 0; j < DCMAX; ++j) v[u][j] = v2c_of<T, ALG>(v[u][j], o[u][j]);
+                }
                 cn_rule<T, ALG, DCMAX>(v[u], deg[u]);
 #pragma unroll
                 for (int j = 0; j < DCMAX; ++j) {
-                    if (j < deg[u]) msg_st<LDPC_CN_NTS != 0>(mt + (int64_t)(k0[u] + j) * 64, v[u][j]);
+                    if (j < deg[u]) msg_st<LDPC_CN_NTS != 0>(ct + (int64_t)(k0[u] + j) * 64, v[u][j]);
                 }
             }
         }
@@ -193,15 +225,14 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Variable pass: marginal = prior + ordered sum of c2v ; v2c = marginal - c2v (in place) ; decision bit.
+// Variable pass: marginal = prior + ordered sum of c2v (c2v is only read) ; decision bit.
 // FIXED_DV > 0: every variable has exactly that many edges (edge list of variable v at v * FIXED_DV): no col_ptr loads and no branch
 // per line, so the lines of a group of variables are fetched together
 template <typename T, int ALG, int DVMAX, int UNR, int FIXED_DV>
 __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ col_edge,
-                                            T* __restrict__ msg, const T* __restrict__ prior_t,
+                                            const T* __restrict__ c2v, const T* __restrict__ prior_t, T* __restrict__ marg_t,
                                             const u64* __restrict__ live, u64* __restrict__ xbits, u64* __restrict__ xera,
-                                            u64* __restrict__ flags, T* __restrict__ soft_t, int n, int64_t E, int tiles,
-                                            int chunks, int vpw) {
+                                            u64* __restrict__ flags, int n, int64_t E, int tiles, int chunks, int vpw) {
     const int lane = threadIdx.x;
     const int task = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + threadIdx.y));
     const int tile = task / chunks, chunk = task - tile * chunks;
@@ -209,9 +240,9 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
     const u64 lv = live[tile];
     if (lv == 0) return;
     const bool on = (lv >> lane) & 1ull;
-    T* mt = msg + (int64_t)tile * E * 64 + lane;
+    const T* ct = c2v + (int64_t)tile * E * 64 + lane;
     const T* pt = prior_t + (int64_t)tile * n * 64 + lane;
-    T* sft = soft_t ? soft_t + (int64_t)tile * n * 64 + lane : nullptr;
+    T* mt = marg_t + (int64_t)tile * n * 64 + lane;
     u64* xb = xbits + plane_at(tile, 0, n);  // word of variable v at xb[8 * v]
     u64* xe = (ALG == ALG_BEC) ? xera + plane_at(tile, 0, n) : nullptr;
     u64 chg = 0, era_any = 0;
@@ -240,12 +271,12 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
                 if constexpr (FIXED_DV > 0) {
                     pr[u] = pt[(int64_t)(vbase + u < v_end ? vbase + u : v_end - 1) * 64];
 #pragma unroll
-                    for (int j = 0; j < FIXED_DV; ++j) c[u][j] = msg_ld<LDPC_VN_NTL != 0>(mt + (int64_t)col_edge[p0[u] + j] * 64);
+                    for (int j = 0; j < FIXED_DV; ++j) c[u][j] = msg_ld<LDPC_VN_NTL != 0>(ct + (int64_t)col_edge[p0[u] + j] * 64);
                 } else {
                     if (deg[u] >= 0) pr[u] = pt[(int64_t)(vbase + u) * 64];
 #pragma unroll
                     for (int j = 0; j < DVMAX; ++j) {
-                        if (j < deg[u]) c[u][j] = msg_ld<LDPC_VN_NTL != 0>(mt + (int64_t)col_edge[p0[u] + j] * 64);
+                        if (j < deg[u]) c[u][j] = msg_ld<LDPC_VN_NTL != 0>(ct + (int64_t)col_edge[p0[u] + j] * 64);
                     }
                 }
             }
@@ -261,14 +292,8 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
 #pragma unroll
                     for (int j = 0; j < DVMAX; ++j)
                         if (j < du) s += c[u][j];
-                    const int marg = (int)pr[u] + s;
-#pragma unroll
-                    for (int j = 0; j < DVMAX; ++j) {
-                        if (j < du) {
-                            const int d = marg - (int)c[u][j];
-                            mt[(int64_t)col_edge[p0[u] + j] * 64] = (T)((d > 0) - (d < 0));
-                        }
-                    }
+                    const int marg = (int)pr[u] + s;  // |marg| <= 1 + dv <= 65: fits the int8 line
+                    mt[(int64_t)(vbase + u) * 64] = (T)marg;
                     b_one = marg > 0;
                     b_era = marg == 0;
                 } else {
@@ -277,11 +302,8 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
                     for (int j = 0; j < DVMAX; ++j)
                         if (j < du) s += c[u][j];
                     const T marg = pr[u] + s;
-#pragma unroll
-                    for (int j = 0; j < DVMAX; ++j)
-                        if (j < du) msg_st<LDPC_VN_NTS != 0>(mt + (int64_t)col_edge[p0[u] + j] * 64, (T)(marg - c[u][j]));
+                    msg_st<LDPC_VN_NTS != 0>(mt + (int64_t)(vbase + u) * 64, marg);
                     b_one = marg < T(0);  // NaN marginal -> 0 (src/bpa.py:38,62)
-                    if (sft) sft[(int64_t)(vbase + u) * 64] = marg;
                 }
             }
             const u64 one = __ballot(b_one);
@@ -375,13 +397,14 @@ __global__ __launch_bounds__(64) void k_syndrome_fin(u64* __restrict__ unsat_acc
 // ---------------------------------------------------------------------------------------------------
 // Frame repack (early termination, ldpc_repack.hpp): when many tiles hold only a few live frames, the live frames are gathered
 // into dense tiles.  k_repack moves
-// message lines, priors and decision bit-planes: destination lane j reads (source tile, source lane) of the j-th live frame;
-// lanes that share a source tile share the 256-byte line, so a line of a source tile is fetched once per destination tile
+// message lines, marginals, priors and decision bit-planes: destination lane j reads (source tile, source lane) of the j-th live
+// frame; lanes that share a source tile share the 256-byte line, so a line of a source tile is fetched once per destination tile
 // that draws from it.  The decisions of every frame of the old tiles are written out before (k_unpack), the moved frames
 // overwrite theirs at the end.
 template <typename T>
-__global__ __launch_bounds__(256) void k_repack(const T* __restrict__ msg_src, T* __restrict__ msg_dst, const T* __restrict__ prior_src,
-                                                T* __restrict__ prior_dst, const u64* __restrict__ xb_src, u64* __restrict__ xb_dst,
+__global__ __launch_bounds__(256) void k_repack(const T* __restrict__ msg_src, T* __restrict__ msg_dst, const T* __restrict__ marg_src,
+                                                T* __restrict__ marg_dst, const T* __restrict__ prior_src, T* __restrict__ prior_dst,
+                                                const u64* __restrict__ xb_src, u64* __restrict__ xb_dst,
                                                 const u64* __restrict__ live_src, u64* __restrict__ live_dst,
                                                 const int32_t* __restrict__ base, const int32_t* __restrict__ frame_src,
                                                 int32_t* __restrict__ frame_dst, int tiles_src, int n, int64_t E, int rows_per_wave) {
@@ -390,18 +413,20 @@ __global__ __launch_bounds__(256) void k_repack(const T* __restrict__ msg_src, T
     int st, sl;
     const bool has = repack_source(base, live_src, tiles_src, dt * 64 + lane, &st, &sl);
     const int chunk = blockIdx.x * 4 + threadIdx.y;
-    const int64_t rows = E + n;  // message lines, then prior lines (+ one bit-plane word per prior line)
+    const int64_t rows = E + n;  // message lines, then per variable: marginal + prior line + one bit-plane word
     const int64_t r0 = (int64_t)chunk * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
     const T* ms = msg_src + (int64_t)st * E * 64 + sl;
     T* md = msg_dst + (int64_t)dt * E * 64 + lane;
-    const T* ps = prior_src + (int64_t)st * n * 64 + sl;
-    T* pd = prior_dst + (int64_t)dt * n * 64 + lane;
+    const int64_t so = (int64_t)st * n * 64 + sl, dof = (int64_t)dt * n * 64 + lane;
     for (int64_t r = r0; r < r1; ++r) {
         if (r < E) {
             if (has) md[r * 64] = ms[r * 64];
         } else {
             const int64_t v = r - E;
-            if (has) pd[v * 64] = ps[v * 64];
+            if (has) {
+                prior_dst[dof + v * 64] = prior_src[so + v * 64];
+                marg_dst[dof + v * 64] = marg_src[so + v * 64];
+            }
             const u64 w = has ? xb_src[plane_at(st, v, n)] : 0ull;
             const u64 plane = __ballot(has && ((w >> sl) & 1ull));
             if (lane == 0) xb_dst[plane_at(dt, v, n)] = plane;
@@ -503,63 +528,77 @@ struct Geometry {
 };
 
 template <typename T, int ALG, int DCMAX, int FIXED_DC>
-void launch_cn(const Code* c, T* msg, const T* prior, const u64* live, const Geometry& g, int first, hipStream_t st) {
-    constexpr int UNR = unroll_for(DCMAX * (int)sizeof(T));
+void launch_cn(const Code* c, T* c2v, const T* src, const u64* live, const Geometry& g, int first, hipStream_t st) {
+    constexpr int UNR = unroll_for(2 * DCMAX * (int)sizeof(T));  // old message + marginal line per edge
     const int tasks = g.tiles * g.cn_chunks;
     hipLaunchKernelGGL((k_cn<T, ALG, DCMAX, FIXED_DC, UNR>), dim3((tasks + 3) / 4), dim3(64, 4), 0, st, c->d_row_ptr,
-                       c->d_edge_var, msg, prior, live, c->m, c->n, c->E, g.tiles, g.cn_chunks, g.cpw, first);
+                       c->d_edge_var, c2v, src, live, c->m, c->n, c->E, g.tiles, g.cn_chunks, g.cpw, first);
 }
 
 template <typename T, int ALG, int DVMAX, int FIXED_DV = 0>
-void launch_vn(const Code* c, T* msg, const T* prior, const u64* live, u64* xbits, u64* xera, u64* flags, T* soft,
+void launch_vn(const Code* c, const T* c2v, const T* prior, T* marg, const u64* live, u64* xbits, u64* xera, u64* flags,
                const Geometry& g, hipStream_t st) {
-    constexpr int UNR = unroll_for(DVMAX * (int)sizeof(T));
+    constexpr int UNR = unroll_for((DVMAX + 1) * (int)sizeof(T));
     const int tasks = g.tiles * g.vn_chunks;
     hipLaunchKernelGGL((k_vn<T, ALG, DVMAX, UNR, FIXED_DV>), dim3((tasks + 3) / 4), dim3(64, 4), 0, st, c->d_col_ptr, c->d_col_edge,
-                       msg, prior, live, xbits, xera, flags, soft, c->n, c->E, g.tiles, g.vn_chunks, g.vpw);
+                       c2v, prior, marg, live, xbits, xera, flags, c->n, c->E, g.tiles, g.vn_chunks, g.vpw);
 }
 
 template <typename T, int ALG>
-int dispatch_cn(const Code* c, T* msg, const T* prior, const u64* live, const Geometry& g, int first, hipStream_t st) {
+int dispatch_cn(const Code* c, T* c2v, const T* src, const u64* live, const Geometry& g, int first, hipStream_t st) {
     const bool regular = c->min_dc == c->max_dc;
     if (regular && c->max_dc == 6) {
-        launch_cn<T, ALG, 6, 6>(c, msg, prior, live, g, first, st);
+        launch_cn<T, ALG, 6, 6>(c, c2v, src, live, g, first, st);
         return 0;
     }
     if (c->max_dc > 4 && c->max_dc <= 6) {  // check degrees up to 6 (the rho = x^5 ensembles): no lines fetched for positions that never exist
-        launch_cn<T, ALG, 6, 0>(c, msg, prior, live, g, first, st);
+        launch_cn<T, ALG, 6, 0>(c, c2v, src, live, g, first, st);
         return 0;
     }
     switch (pick_pow2_ge(c->max_dc, 4, 64)) {
-        case 4: launch_cn<T, ALG, 4, 0>(c, msg, prior, live, g, first, st); break;
-        case 8: launch_cn<T, ALG, 8, 0>(c, msg, prior, live, g, first, st); break;
-        case 16: launch_cn<T, ALG, 16, 0>(c, msg, prior, live, g, first, st); break;
-        case 32: launch_cn<T, ALG, 32, 0>(c, msg, prior, live, g, first, st); break;
-        default: launch_cn<T, ALG, 64, 0>(c, msg, prior, live, g, first, st); break;
+        case 4: launch_cn<T, ALG, 4, 0>(c, c2v, src, live, g, first, st); break;
+        case 8: launch_cn<T, ALG, 8, 0>(c, c2v, src, live, g, first, st); break;
+        case 16: launch_cn<T, ALG, 16, 0>(c, c2v, src, live, g, first, st); break;
+        case 32: launch_cn<T, ALG, 32, 0>(c, c2v, src, live, g, first, st); break;
+        default: launch_cn<T, ALG, 64, 0>(c, c2v, src, live, g, first, st); break;
     }
     return 0;
 }
 
 template <typename T, int ALG>
-int dispatch_vn(const Code* c, T* msg, const T* prior, const u64* live, u64* xbits, u64* xera, u64* flags, T* soft,
+int dispatch_vn(const Code* c, const T* c2v, const T* prior, T* marg, const u64* live, u64* xbits, u64* xera, u64* flags,
                 const Geometry& g, hipStream_t st) {
     if (c->min_dv == c->max_dv && c->max_dv == 3) {  // (3, r)-regular codes
-        launch_vn<T, ALG, 3, 3>(c, msg, prior, live, xbits, xera, flags, soft, g, st);
+        launch_vn<T, ALG, 3, 3>(c, c2v, prior, marg, live, xbits, xera, flags, g, st);
         return 0;
     }
     if (c->min_dv == c->max_dv && c->max_dv == 4) {
-        launch_vn<T, ALG, 4, 4>(c, msg, prior, live, xbits, xera, flags, soft, g, st);
+        launch_vn<T, ALG, 4, 4>(c, c2v, prior, marg, live, xbits, xera, flags, g, st);
         return 0;
     }
     switch (pick_pow2_ge(c->max_dv, 4, 64)) {
-        case 4: launch_vn<T, ALG, 4>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
-        case 8: launch_vn<T, ALG, 8>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
-        case 16: launch_vn<T, ALG, 16>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
-        case 32: launch_vn<T, ALG, 32>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
-        default: launch_vn<T, ALG, 64>(c, msg, prior, live, xbits, xera, flags, soft, g, st); break;
+        case 4: launch_vn<T, ALG, 4>(c, c2v, prior, marg, live, xbits, xera, flags, g, st); break;
+        case 8: launch_vn<T, ALG, 8>(c, c2v, prior, marg, live, xbits, xera, flags, g, st); break;
+        case 16: launch_vn<T, ALG, 16>(c, c2v, prior, marg, live, xbits, xera, flags, g, st); break;
+        case 32: launch_vn<T, ALG, 32>(c, c2v, prior, marg, live, xbits, xera, flags, g, st); break;
+        default: launch_vn<T, ALG, 64>(c, c2v, prior, marg, live, xbits, xera, flags, g, st); break;
     }
     return 0;
 }
+
+int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
+// One poll of the live counters, in flight: the syndrome kernels of a check point add the live tiles / frames into `slot` of the
+// device ring, a copy brings them to the pinned ring, an event marks it.  The host reads poll k only after it has enqueued the work
+// up to poll k + 1, so the GPU never waits for the host inside the sweep loop.
+struct PendingPoll {
+    int slot, it, sweeps, tiles;
+    bool tiling_current;  // false once a repack has been enqueued after this poll: its tile count no longer describes the state
+};
+constexpr int POLL_RING = 4;
 
 template <typename T, int ALG>
 int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags_in, uint8_t* xhat,
@@ -572,62 +611,84 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
         set_error("streaming backend supports node degrees up to 64 (max_dc=%d, max_dv=%d)", c->max_dc, c->max_dv);
         return LDPC_E_UNSUPPORTED;
     }
+    const bool early = !(flags_in & FLAG_NO_EARLY_EXIT);
+    // Frame repack (see k_repack): LLR decoders without soft output.  Policy: at a poll, when the live frames would fill less than
+    // `fill` of the tiles that still hold one, gather them into dense tiles -- a repack moves (E + 2n) lines per tile once, a sweep
+    // moves about (3E + 3n), so it pays as soon as about one more sweep follows.
+    bool repack_ok = early && ALG != ALG_BEC && soft_out == nullptr && tiles >= 2;
+    double repack_fill = 0.75;
+    if (const char* e = std::getenv("LDPC_STREAM_REPACK")) repack_ok = repack_ok && atoi(e) != 0;
+    if (const char* e = std::getenv("LDPC_STREAM_REPACK_FILL")) repack_fill = atof(e);
+    if (repack_fill > 0.95) repack_fill = 0.95;
+
+    // every buffer of the decode is reserved here, before the first sweep (no allocation -- a device synchronisation -- in the loop)
     LDPC_TRY(d->msg.reserve((size_t)tiles * E * 64 * sizeof(T)));
+    LDPC_TRY(d->marg.reserve((size_t)tiles * n * 64 * sizeof(T)));
     LDPC_TRY(d->prior.reserve((size_t)tiles * n * 64 * sizeof(T)));
     LDPC_TRY(d->xbits.reserve(plane_words(tiles, n) * 8));
     LDPC_TRY(d->live.reserve((size_t)tiles * 8));
-    LDPC_TRY(d->flags.reserve((size_t)tiles * 16 + 64));
+    LDPC_TRY(d->flags.reserve((size_t)tiles * 16 + 64 + POLL_RING * 16));
     if (ALG == ALG_BEC) LDPC_TRY(d->xera.reserve(plane_words(tiles, n) * 8));
-    T* soft_t = nullptr;
-    if (soft_out && ALG != ALG_BEC) {
-        LDPC_TRY(d->scratch.reserve((size_t)tiles * n * 64 * sizeof(T)));
-        soft_t = (T*)d->scratch.p;
-        LDPC_HIP_TRY(hipMemsetAsync(soft_t, 0, (size_t)tiles * n * 64 * sizeof(T), st));
+    if (repack_ok) {
+        // second state set: the first repack fires at <= fill * 64 live frames per tile, later ones only shrink
+        const size_t nt = (size_t)(repack_fill * tiles) + 2;
+        if (d->msg2.reserve(nt * E * 64 * sizeof(T)) || d->marg2.reserve(nt * n * 64 * sizeof(T)) ||
+            d->prior2.reserve(nt * n * 64 * sizeof(T)) || d->xbits2.reserve(plane_words((int)nt, n) * 8) || d->live2.reserve(nt * 8) ||
+            d->fmap2.reserve(nt * 64 * sizeof(int32_t)) || d->fmap.reserve(nt * 64 * sizeof(int32_t)) ||
+            d->rbase.reserve(((size_t)tiles + 1) * sizeof(int32_t)))
+            repack_ok = false;  // no room for a second set: decode without repacking
     }
     T* msg = (T*)d->msg.p;
+    T* marg = (T*)d->marg.p;
     T* prior = (T*)d->prior.p;
     u64* xbits = (u64*)d->xbits.p;
     u64* xera = (u64*)d->xera.p;
     u64* live = (u64*)d->live.p;
-    u64* tflags = (u64*)d->flags.p;                         // [tiles][2]
-    int* live_tiles = (int*)((char*)d->flags.p + (size_t)tiles * 16);  // one polling counter
-    int* h_poll = (int*)d->pinned;
+    u64* tflags = (u64*)d->flags.p;                                        // [tiles][2]
+    int* poll_dev = (int*)((char*)d->flags.p + (size_t)tiles * 16 + 64);  // [POLL_RING][4] ints: live tiles, live frames
+    volatile int* poll_host = (volatile int*)d->pinned;                    // [POLL_RING][4] page-locked
+    hipEvent_t poll_ev[POLL_RING];
+    for (int i = 0; i < POLL_RING; ++i) LDPC_TRY(prof_event(d, i, &poll_ev[i]));
+    size_t ev_next = POLL_RING;
 
     Geometry g;
     g.tiles = tiles;
-    // aim for >= ~16k wave tasks per launch when the batch allows it, 4..64 nodes per wave otherwise
-    auto per_wave = [&](int nodes) {
-        long want = ((long)nodes * tiles + 16383) / 16384;
-        long v = want < 4 ? 4 : (want > 64 ? 64 : want);
-        v = (v + 3) / 4 * 4;
+    // Nodes per wave.  The marginal lines a check pass gathers are re-used dv times; the fewer tiles are in flight at once, the
+    // more of those re-reads hit on chip -- so a tile is cut into MANY short wave tasks (tile-major task order).  Measured on one
+    // MI355X (sweep of 32 768 frames of the (3,6) n = 64 800 shape, profiles/r03_stream_chunking.txt): 64 checks per wave 20.9 ms,
+    // 16: 19.9, 8: 19.4, 2-4 with 16 variables per wave: 19.1-19.3 ms; n = 1200 and the n = 10 000 ensemble agree.  Longer runs only
+    // beyond 2^22 tasks per launch.
+    auto per_wave = [&](int nodes, int base) {
+        long v = base < 1 ? 1 : base;
+        while ((long)((nodes + v - 1) / v) * tiles > (1L << 22) && v < 256) v *= 2;
         return (int)(v > nodes ? ((nodes + 3) / 4 * 4) : v);
     };
-    g.cpw = per_wave(m);
+    g.cpw = per_wave(m, env_int("LDPC_STREAM_CPW", 4));
     g.cn_chunks = (m + g.cpw - 1) / g.cpw;
-    g.vpw = per_wave(n);
+    g.vpw = per_wave(n, env_int("LDPC_STREAM_VPW", 16));
     g.vn_chunks = (n + g.vpw - 1) / g.vpw;
 
+    hipEvent_t e_begin = nullptr, e_end = nullptr;
+    if (d->profile) {
+        LDPC_TRY(prof_event(d, ev_next++, &e_begin));
+        LDPC_TRY(prof_event(d, ev_next++, &e_end));
+        LDPC_HIP_TRY(hipEventRecord(e_begin, st));
+    }
     LDPC_HIP_TRY(hipMemsetAsync(xbits, 0, plane_words(tiles, n) * 8, st));
-    LDPC_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)tiles * 16 + 64, st));
+    LDPC_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)tiles * 16 + 64 + POLL_RING * 16, st));
     LDPC_HIP_TRY(hipMemsetAsync(iters, 0, (size_t)B * sizeof(int32_t), st));
+    if (soft_out) LDPC_HIP_TRY(hipMemsetAsync(marg, 0, (size_t)tiles * n * 64 * sizeof(T), st));  // frames that never sweep report 0
     hipLaunchKernelGGL((k_load_tile<T, ALG>), dim3((n + 63) / 64, tiles), dim3(256), 0, st, (const T*)priors_v, y0, B, n,
                        prior, xbits, xera, tflags);
     hipLaunchKernelGGL(k_init_live, dim3((tiles + 255) / 256), dim3(256), 0, st, live, B, tiles);
 
-    const bool early = !(flags_in & FLAG_NO_EARLY_EXIT);
     const int cap = max_iter > 0 ? max_iter : 100000;  // max_iter <= 0 == unlimited upstream (src/bpa.py:28); bounded here
-    // how often the host looks at the live counters: about every 300 us of streaming work
-    const double iter_us = 15.0 + (double)tiles * 64.0 * sizeof(T) * (4.0 * E + n) / 4.0e6;
+    // how often the live counters are polled: about every 300 us of streaming work
+    const double iter_us = 15.0 + (double)tiles * 64.0 * sizeof(T) * (4.0 * E + n) / 5.0e6;
     int poll_every = (int)(300.0 / iter_us);
     poll_every = poll_every < 1 ? 1 : (poll_every > 16 ? 16 : poll_every);
-    // Frame repack (see k_repack): LLR decoders without soft output.  Policy: at a poll, when the live frames would fill less than
-    // `fill` of the tiles that still hold one, gather them into dense tiles -- a repack moves (E + n) lines per tile once, a sweep
-    // moves (4E + n), so it pays as soon as about one more sweep follows.
-    bool repack_ok = early && ALG != ALG_BEC && soft_t == nullptr;
-    double repack_fill = 0.75;
-    if (const char* e = std::getenv("LDPC_STREAM_REPACK")) repack_ok = repack_ok && atoi(e) != 0;
-    if (const char* e = std::getenv("LDPC_STREAM_REPACK_FILL")) repack_fill = atof(e);
     DevBuf* set_msg[2] = {&d->msg, &d->msg2};
+    DevBuf* set_marg[2] = {&d->marg, &d->marg2};
     DevBuf* set_prior[2] = {&d->prior, &d->prior2};
     DevBuf* set_xbits[2] = {&d->xbits, &d->xbits2};
     DevBuf* set_live[2] = {&d->live, &d->live2};
@@ -637,16 +698,23 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     int cur_tiles = tiles;
     int repacks = 0;
     int sweeps = 0;
+    int polls = 0;
+    std::vector<PendingPoll> pending;
     std::vector<ProfSpan> spans;
-    size_t ev_next = 0;
-    for (int it = 0; it < cap; ++it) {
+    bool all_left = false;
+    for (int it = 0; it < cap && !all_left; ++it) {
         const bool check = early && (ALG == ALG_BEC || it > 0 || y0 != nullptr);
         if (check) {
             const bool poll = (it % poll_every) == 0 || max_iter <= 0;
-            if (poll) LDPC_HIP_TRY(hipMemsetAsync(live_tiles, 0, 2 * sizeof(int), st));
+            int* slot_dev = nullptr;
+            int slot = 0;
+            if (poll) {
+                slot = polls % POLL_RING;
+                slot_dev = poll_dev + 4 * slot;
+                LDPC_HIP_TRY(hipMemsetAsync(slot_dev, 0, 2 * sizeof(int), st));
+            }
             if (ALG == ALG_BEC) {
-                hipLaunchKernelGGL(k_bec_check, dim3(cur_tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr,
-                                   B, cur_tiles, sweeps);
+                hipLaunchKernelGGL(k_bec_check, dim3(cur_tiles), dim3(64), 0, st, tflags, live, iters, slot_dev, B, cur_tiles, sweeps);
             } else {
                 // groups of eight tiles x chunks of the checks: enough blocks to fill the chip (about 4 per CU), at least 1024 checks each
                 const int groups = (cur_tiles + 7) / 8;
@@ -656,40 +724,52 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                 const int cpb = (m + sblocks - 1) / sblocks;
                 hipLaunchKernelGGL(k_syndrome_part, dim3(sblocks, groups), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, xbits, live, tflags, m, n,
                                    cur_tiles, cpb);
-                hipLaunchKernelGGL(k_syndrome_fin, dim3(cur_tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr, B, sweeps, fmap);
+                hipLaunchKernelGGL(k_syndrome_fin, dim3(cur_tiles), dim3(64), 0, st, tflags, live, iters, slot_dev, B, sweeps, fmap);
             }
             if (poll) {
-                LDPC_HIP_TRY(hipMemcpyAsync(h_poll, live_tiles, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-                LDPC_HIP_TRY(hipStreamSynchronize(st));
-                const int lt = h_poll[0], lf = h_poll[1];
-                if (lt == 0) break;
-                if (repack_ok && it > 0 && lt >= 2 && (double)lf <= repack_fill * 64.0 * lt && it + 1 < cap) {
-                    const int nt = (lf + 63) / 64;
-                    const int nx = 1 - cur;
-                    LDPC_TRY(set_msg[nx]->reserve((size_t)nt * E * 64 * sizeof(T)));
-                    LDPC_TRY(set_prior[nx]->reserve((size_t)nt * n * 64 * sizeof(T)));
-                    LDPC_TRY(set_xbits[nx]->reserve(plane_words(nt, n) * 8));
-                    LDPC_TRY(set_live[nx]->reserve((size_t)nt * 8));
-                    LDPC_TRY(set_fmap[nx]->reserve((size_t)nt * 64 * sizeof(int32_t)));
-                    LDPC_TRY(d->rbase.reserve(((size_t)cur_tiles + 1) * sizeof(int32_t)));
-                    // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs later)
-                    hipLaunchKernelGGL((k_unpack<ALG>), dim3((n + 255) / 256, cur_tiles), dim3(256), 0, st, xbits, xera, xhat, B, n, fmap);
-                    hipLaunchKernelGGL(k_repack_plan, dim3(1), dim3(1024), 0, st, live, cur_tiles, (int32_t*)d->rbase.p);
-                    const int rows_per_wave = 128;
-                    const int chunks = (int)((E + n + rows_per_wave - 1) / rows_per_wave);
-                    hipLaunchKernelGGL((k_repack<T>), dim3((chunks + 3) / 4, nt), dim3(64, 4), 0, st, msg, (T*)set_msg[nx]->p, prior,
-                                       (T*)set_prior[nx]->p, xbits, (u64*)set_xbits[nx]->p, live, (u64*)set_live[nx]->p,
-                                       (const int32_t*)d->rbase.p, fmap, (int32_t*)set_fmap[nx]->p, cur_tiles, n, E, rows_per_wave);
-                    cur = nx;
-                    msg = (T*)set_msg[cur]->p;
-                    prior = (T*)set_prior[cur]->p;
-                    xbits = (u64*)set_xbits[cur]->p;
-                    live = (u64*)set_live[cur]->p;
-                    fmap = (int32_t*)set_fmap[cur]->p;
-                    cur_tiles = nt;
-                    g.tiles = nt;
-                    ++repacks;
+                LDPC_HIP_TRY(hipMemcpyAsync((void*)(poll_host + 4 * slot), slot_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+                LDPC_HIP_TRY(hipEventRecord(poll_ev[slot], st));
+                pending.push_back({slot, it, sweeps, cur_tiles, true});
+                ++polls;
+                // Read the OLDEST poll once a newer one is enqueued behind it (its event has long fired: a block of sweeps lies in
+                // between); with a single-tile batch, or an unbounded run, there is nothing to overlap and the newest is read at once.
+                const bool eager = max_iter <= 0 || cur_tiles < 2;
+                while (!pending.empty() && (pending.size() >= 2 || eager)) {
+                    const PendingPoll pp = pending.front();
+                    pending.erase(pending.begin());
+                    LDPC_HIP_TRY(hipEventSynchronize(poll_ev[pp.slot]));
+                    const int lt = poll_host[4 * pp.slot], lf = poll_host[4 * pp.slot + 1];
+                    if (lt == 0) {  // every frame had left at that check point; what was enqueued since found no live tile
+                        all_left = true;
+                        sweeps = pp.sweeps;
+                        break;
+                    }
+                    if (repack_ok && pp.tiling_current && pp.it > 0 && lt >= 2 && (double)lf <= repack_fill * 64.0 * lt && it + 1 < cap) {
+                        const int nt = (lf + 63) / 64;
+                        const int nx = 1 - cur;
+                        // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs later)
+                        hipLaunchKernelGGL((k_unpack<ALG>), dim3((n + 255) / 256, cur_tiles), dim3(256), 0, st, xbits, xera, xhat, B, n, fmap);
+                        hipLaunchKernelGGL(k_repack_plan, dim3(1), dim3(1024), 0, st, live, cur_tiles, (int32_t*)d->rbase.p);
+                        const int rows_per_wave = 128;
+                        const int chunks = (int)((E + n + rows_per_wave - 1) / rows_per_wave);
+                        hipLaunchKernelGGL((k_repack<T>), dim3((chunks + 3) / 4, nt), dim3(64, 4), 0, st, msg, (T*)set_msg[nx]->p, marg,
+                                           (T*)set_marg[nx]->p, prior, (T*)set_prior[nx]->p, xbits, (u64*)set_xbits[nx]->p, live,
+                                           (u64*)set_live[nx]->p, (const int32_t*)d->rbase.p, fmap, (int32_t*)set_fmap[nx]->p, cur_tiles, n, E,
+                                           rows_per_wave);
+                        cur = nx;
+                        msg = (T*)set_msg[cur]->p;
+                        marg = (T*)set_marg[cur]->p;
+                        prior = (T*)set_prior[cur]->p;
+                        xbits = (u64*)set_xbits[cur]->p;
+                        live = (u64*)set_live[cur]->p;
+                        fmap = (int32_t*)set_fmap[cur]->p;
+                        cur_tiles = nt;
+                        g.tiles = nt;
+                        ++repacks;
+                        for (PendingPoll& q : pending) q.tiling_current = false;
+                    }
                 }
+                if (all_left) break;
             }
         }
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -699,9 +779,9 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
             LDPC_TRY(prof_event(d, ev_next++, &e2));
             LDPC_HIP_TRY(hipEventRecord(e0, st));
         }
-        dispatch_cn<T, ALG>(c, msg, prior, live, g, it == 0 ? 1 : 0, st);
+        dispatch_cn<T, ALG>(c, msg, it == 0 ? prior : marg, live, g, it == 0 ? 1 : 0, st);
         if (d->profile) LDPC_HIP_TRY(hipEventRecord(e1, st));
-        dispatch_vn<T, ALG>(c, msg, prior, live, xbits, xera, tflags, soft_t, g, st);
+        dispatch_vn<T, ALG>(c, msg, prior, marg, live, xbits, xera, tflags, g, st);
         if (d->profile) {
             LDPC_HIP_TRY(hipEventRecord(e2, st));
             spans.push_back({0, e0, e1});
@@ -711,12 +791,17 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     }
     hipLaunchKernelGGL(k_finish_iters, dim3(cur_tiles), dim3(64), 0, st, live, iters, B, sweeps, fmap);
     hipLaunchKernelGGL((k_unpack<ALG>), dim3((n + 255) / 256, cur_tiles), dim3(256), 0, st, xbits, xera, xhat, B, n, fmap);
-    if (soft_t)
-        hipLaunchKernelGGL(k_soft_out<T>, dim3((n + 3) / 4, tiles), dim3(256), 0, st, soft_t, (T*)soft_out, B, n);
+    if (soft_out && ALG != ALG_BEC)
+        hipLaunchKernelGGL(k_soft_out<T>, dim3((n + 3) / 4, tiles), dim3(256), 0, st, marg, (T*)soft_out, B, n);
     LDPC_HIP_TRY(hipGetLastError());
     if (d->profile) {
+        LDPC_HIP_TRY(hipEventRecord(e_end, st));
         LDPC_HIP_TRY(hipStreamSynchronize(st));
         LDPC_TRY(prof_collect(d, spans));
+        float total = 0.f;
+        LDPC_HIP_TRY(hipEventElapsedTime(&total, e_begin, e_end));
+        d->prof_ms[3] += total;  // everything the decode enqueued: the two passes + load, syndrome, repack, unpack kernels
+        d->prof_launches[3] += 1;
     }
     d->last_repacks = repacks;
     d->last_sweeps = sweeps;

@@ -32,7 +32,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), "symbol %s declared in include/ldpc_hip.h but not exported" % name
     # the ctypes binding covers the same set
     assert set(_lib.SIGNATURES) == set(names)
-    assert _lib.load().ldpc_abi_version() == 1
+    assert _lib.load().ldpc_abi_version() == 2
 
 
 def test_argument_errors_are_reported_not_thrown():
@@ -304,3 +304,38 @@ def test_host_only_layout_planning_and_plan_store(tmp_path):
     # a malformed edge list is refused with the graph error of ldpc_code_create
     rc = lib.ldpc_plan_layout(2, 2, 3, np.array([0, 1, 0], dtype=np.int32).ctypes.data, np.array([0, 1, 1], dtype=np.int32).ctypes.data, 0, 0, 1000, None, info)
     assert rc == -3 and b"row-major" in lib.ldpc_last_error()
+
+
+# The Monte-Carlo (SIM) kernels behind `ldpc_simulate` for BASELINE configs 2-4 (+ the sum-product / irregular siblings main.py runs
+# by default): template arguments <ALG, DC, DV, CRW, VRW, NW, SIM, VRX, DVX> of csrc/ldpc_fused_kernels.hpp
+SIM_KERNELS_WITHOUT_SPILLS = [
+    "k_fused_bp<0, 6, 3, 5, 10, 2, true, 0, 3>",    # config 2, fp32 min-sum, n = 1200 (3,6): the kernel `bench.py --precision f32` times
+    "k_fused_f64<0, 6, 3, 5, 10, 2, true, 0, 3>",   # config 2, fp64 min-sum: the kernel `bench.py` times by default
+    "k_fused_bp<2, 6, 3, 5, 10, 2, true, 0, 3>",    # config 3, erasure decoder
+    "k_fused_bp<1, 6, 3, 5, 10, 2, true, 0, 3>",    # config 3, fp32 sum-product (BSC / BI-AWGN)
+    "k_fused_bp<0, 6, 3, 5, 10, 16, true, 3, 8>",   # config 4, one frame per CU (rate-1/2 irregular n = 10 000)
+    "k_fused_bp<0, 6, 3, 5, 10, 2, true, 2, 8>",    # irregular n = 1200 ensembles (1200_rho_x5_*), min-sum
+    "k_fused_bp<2, 6, 3, 5, 10, 2, true, 2, 8>",    # ... erasure decoder
+    "k_fused_bp<0, 6, 3, 4, 8, 1, true, 0, 3>",     # n <= 512
+    "k_fused_bp<0, 6, 3, 6, 11, 4, true, 0, 3>",    # Margulis n = 2640
+]
+
+
+def test_simulate_kernels_do_not_spill():
+    """Code-object metadata of the BUILT library (llvm-readelf --notes through tools/kernel_resources.py, no GPU needed): the named
+    Monte-Carlo kernels keep everything in registers -- no spilled VGPR, no scratch segment.  (Round 2 shipped them with 24-37 spilled
+    registers: 86 MB of scratch traffic per launch of a kernel whose only output is 55 counters.)"""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+
+    ks = kernel_resources.kernels_of()
+    assert len(ks) > 100, "code objects of libldpc_hip.so not found"
+    by_name = {k.split("(")[0]: v for k, v in ks.items()}
+    for name in SIM_KERNELS_WITHOUT_SPILLS:
+        assert name in by_name, "kernel %s not in the library" % name
+        r = by_name[name]
+        assert r["spill"] == 0 and r["scratch"] == 0, "%s: %d spilled VGPRs, %d B of scratch per lane" % (name, r["spill"], r["scratch"])
+        if name.startswith("k_fused_bp") and (", 2, true" in name or ", 16, true" in name):
+            assert r["vgpr"] <= 128  # four waves per SIMD: the occupancy the fp32 multi-wave shapes are built for

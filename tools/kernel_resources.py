@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Register / scratch / LDS budget of every kernel in the built libldpc_hip.so, read from the code-object metadata
+(`llvm-readelf --notes` of each gfx950 code object embedded in the library's clang offload bundles).
+
+    python tools/kernel_resources.py [--lib PATH] [--match SUBSTR] [--json]
+
+Used by tests/test_host_cpu.py::test_simulate_kernels_do_not_spill (no GPU needed)."""
+import argparse
+import json
+import os
+import re
+import struct
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT_LIB = os.path.join(ROOT, "ldpc_decoders_amd", "csrc", "libldpc_hip.so")
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+CXXFILT = "c++filt"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def code_objects(blob):
+    """Yield the device code objects (bytes) of every uncompressed clang offload bundle found in `blob`."""
+    pos = 0
+    while True:
+        at = blob.find(MAGIC, pos)
+        if at < 0:
+            return
+        pos = at + len(MAGIC)
+        (count,) = struct.unpack_from("<Q", blob, pos)
+        p = pos + 8
+        if count > 64:
+            continue
+        for _ in range(count):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, p)
+            triple = blob[p + 24:p + 24 + tlen].decode(errors="replace")
+            p += 24 + tlen
+            if "amdgcn" in triple and size:
+                yield triple, blob[at + off:at + off + size]
+
+
+def kernels_of(lib=DEFAULT_LIB):
+    """-> {demangled kernel name: dict(vgpr, sgpr, spill, scratch, lds, agpr)}"""
+    blob = open(lib, "rb").read()
+    out = {}
+    for _, co in code_objects(blob):
+        with tempfile.NamedTemporaryFile(suffix=".co") as fp:
+            fp.write(co)
+            fp.flush()
+            txt = subprocess.run([READELF, "--notes", fp.name], capture_output=True, text=True).stdout
+        for block in re.split(r"\n\s*- \.agpr_count:", txt)[1:]:
+            block = ".agpr_count:" + block
+
+            def field(name, cast=int, b=block):
+                m = re.search(r"\.%s:\s*(\S+)" % re.escape(name), b)
+                return cast(m.group(1)) if m else None
+
+            name = field("name", str)
+            if not name:
+                continue
+            out[name.strip("'\"")] = dict(vgpr=field("vgpr_count"), sgpr=field("sgpr_count"), agpr=field("agpr_count"), spill=field("vgpr_spill_count"),
+                                          sgpr_spill=field("sgpr_spill_count"), scratch=field("private_segment_fixed_size"),
+                                          lds=field("group_segment_fixed_size"))
+    names = list(out)
+    if names:
+        dem = subprocess.run([CXXFILT], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+        out = {d.replace("ldpc::(anonymous namespace)::", "").replace("void ", ""): out[m] for d, m in zip(dem, names)}
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=DEFAULT_LIB)
+    ap.add_argument("--match", default="")
+    ap.add_argument("--json", action="store_true")
+    a = ap.parse_args()
+    ks = {k: v for k, v in kernels_of(a.lib).items() if a.match in k}
+    if a.json:
+        print(json.dumps(ks, indent=1))
+    else:
+        for k, v in sorted(ks.items()):
+            print("%-110s vgpr %3s agpr %3s sgpr %3s spill %3s scratch %4s B lds %6s B" % (k.split("(")[0][:110], v["vgpr"], v["agpr"], v["sgpr"], v["spill"], v["scratch"], v["lds"]))
