@@ -10,23 +10,30 @@ bit-identical to it (LDS-resident fp64 min-sum kernel) --; `--precision f32` is 
 "fp32_mode".  Default operating point 1.0 dB: every frame fails there, so every frame executes exactly 50 sweeps -- the honest
 "50-iteration" number (no early-exit benefit).  `--snr` selects others; `--points` adds 2.0/3.0 dB lines under "points".
 
-Timing.  `value` comes from a region with NO per-kernel instrumentation: K steps enqueued through the pipelined driver
-(montecarlo.DeviceSimulator: two rounds in flight, counters all-reduced on the stream, no host sync between kernels), bracketed
-by barrier + torch.cuda.synchronize() on both sides, MAX over ranks.  The per-kernel durations behind `roofline` are measured
-in a SEPARATE pass of the same steps with the library's HIP events on the decode stream (`ldpc_decoder_profile`).
+Timing.  W warm-up steps, then the timed block -- EXACTLY K steps enqueued through the pipelined driver (montecarlo.DeviceSimulator: two
+rounds in flight, counters all-reduced on the stream, no host sync between kernels), bracketed by barrier + torch.cuda.synchronize() on
+both sides, MAX over ranks -- is repeated `--repeats` times (default 5): `ms_per_step` / `value` are the MEDIAN block, the spread is
+reported beside them (`ms_per_step_min` / `_max`, `blocks_ms_per_step`).  No per-kernel instrumentation runs inside a timed block; the
+per-kernel durations behind `roofline` come from a SEPARATE pass of the same steps with the library's HIP events on the decode stream
+(`ldpc_decoder_profile`).
 
-Roofline.  `roofline.bound` names the resource that binds the dominant kernel: "lds" for the LDS-resident (fused) kernels --
-frac = LDS-array busy cycles / available cycles, numerator from the committed SQ_LDS_IDX_ACTIVE counters (profiles/lds_cycles.json,
-written by tools/summarize_profile.py) x the frame-sweeps/s measured live -- and "hbm" for the streaming kernels (algorithmic
-bytes of SURVEY.md 8(d) / HIP-event time / 8 TB/s).  The 8(d) HBM-model figure of the fused kernel is kept as `hbm_model`
-(flagged: the messages never leave the CU, so it exceeds the HBM peak and bounds nothing).
+Roofline.  `roofline.bound` names the resource that binds the dominant kernel:
+  "lds" / "valu"  the LDS-resident (fused) kernels: frac = busy LDS-array (VALU) cycles / available cycles at 2.4 GHz.  Cycles per
+                  frame-sweep are MEASURED counters of the very kernel that is timed (rocprofv3 --pmc on tools/sim_driver.py, committed as
+                  profiles/roofline_counters.json keyed by the kernel's name, which the library reports) x the frame-sweeps/s of this run.
+  "hbm"           the streaming kernels: bytes / HIP-event time / 8 TB/s, with the SURVEY.md 8(d) algorithmic bytes s(4E+n) for the sweep and
+                  each pass's own compulsory bytes (check pass s(2E+n), variable pass s(E+2n)); PMC traffic beside it.
+The 8(d) HBM-model figure of a fused kernel is kept as `hbm_model` (flagged: the messages never leave the CU, it bounds nothing).
 
 Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run, one rank per GPU
 (RCCL); frames sharded by global frame index, ONE all-reduce of the counters per step; rank 0 prints ONE JSON line.
+`run_bench(args, comm, make_handle, device)` is the whole driver layer with the decoder handle injected -- tests/test_dist_cpu.py runs
+it on 8 gloo ranks with a CPU stand-in for the handle; `main()` always passes the HIP handle.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -37,7 +44,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-NOMINAL_CLOCK_HZ = 2.4e9  # max shader clock; the effective clock of a profiled run is in profiles/lds_cycles.json
+NOMINAL_CLOCK_HZ = 2.4e9  # max shader clock; the effective clock of a profiled run is in profiles/roofline_counters.json
 KERNEL_CLASSES = ("stream_check_pass", "stream_variable_pass", "fused_decode")  # per-kernel HIP-event classes of ldpc_decoder_profile
 
 
@@ -52,13 +59,20 @@ def load_code(name):
         if parts[1] == "reg":
             return codes.rand_reg_ldpc(int(parts[2]), int(parts[3]), int(parts[4]), rng)
         return codes.rand_irregular_ldpc(int(parts[2]), codes.LAMBDA_RHO_X5_HALF_RATE, 6, rng)
+    if name in ("4_2_test", "6_2_3_ldpc", "7_4_hamming", "12_3_4_ldpc"):
+        return codes.get_code(name)
     return codes.load_parity_mtx(os.path.join(codes.PACKAGE_CODES_DIR, name + ".txt"))
 
 
-def cpu_baseline(code, snr, max_iter, precision="f64", budget_s=12.0):
-    """The CPU oracle (oracle/bp_oracle.c, a plain-C port of the reference algorithm, OpenMP over frames) timed on this
-    host on a bounded sample of the same workload.  The only leg of this file that touches oracle/."""
+def cpu_baseline(code, snr, max_iter, precision="f64", budget_s=10.0):
+    """CPU baselines on THIS host, on a bounded sample of the same workload (the only leg of this file that touches oracle/):
+      "port"   oracle/bp_oracle.c -- a plain-C port of the reference algorithm, OpenMP over frames, every host thread;
+      "scipy"  oracle/scipy_baseline.py -- per-frame scipy.sparse decoding, the reference's class of implementation, one
+               process per host core; with the calibration measured where the true reference can run (tests/golden/reference_timing.json:
+               reference frames/s / scipy-baseline frames/s on identical frames) it estimates the reference's own rate on this host."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import multiprocessing as mp
+
     import bp_oracle as O
     import c_oracle as C
 
@@ -81,49 +95,94 @@ def cpu_baseline(code, snr, max_iter, precision="f64", budget_s=12.0):
     t0 = time.time()
     _, it = C.bp_decode(g, "MSA", None, pri, max_iter, dtype=dt_np, nthreads=cores)
     dt = time.time() - t0
-    ref = {}
-    try:
-        with open(os.path.join(ROOT, "tests", "golden", "reference_timing.json")) as fp:
-            tj = json.load(fp)
-        for pt in tj["points"]:
-            if pt["decoder"] == "MSA" and abs(pt["snr_db"] - snr) < 1e-9:
-                ref = {"reference_python_frames_per_s_per_core": round(pt["frames_per_s"], 2),
-                       "reference_python_measured_on": tj["host"]}
-    except Exception:
-        pass
     out = {"value": round(nf / dt, 1), "unit": "frames/s", "cores": cores, "kind": "port",
            "sample": "%d frames, same H / SNR %.1f dB / max_iter %d, %s C port of the reference algorithm (oracle/bp_oracle.c), "
                      "%d OpenMP threads, %.1f s, mean %.1f sweeps/frame" % (nf, snr, max_iter, "fp64" if precision == "f64" else "fp32", cores, dt,
                                                                              float(it.mean()))}
-    out.update(ref)
+    # per-frame scipy.sparse baseline, one process per core, each decoding its own frame stream for about budget_s seconds
+    try:
+        procs = min(cores, 64)
+        per = _scipy_probe((code.m, code.n, code.edge_chk, code.edge_var, snr, max_iter, 2, 1))["frames_per_s"]
+        frames_each = max(2, int(per * budget_s))
+        with mp.get_context("fork").Pool(procs) as pool:
+            t0 = time.time()
+            res = pool.map(_scipy_probe, [(code.m, code.n, code.edge_chk, code.edge_var, snr, max_iter, frames_each, 100 + i) for i in range(procs)])
+            wall = time.time() - t0
+        frames = sum(r["frames"] for r in res)
+        sc = {"value": round(frames / wall, 2), "unit": "frames/s", "cores": procs, "kind": "scipy",
+              "per_core_frames_per_s": round(frames / wall / procs, 3),
+              "sample": "%d frames (%d per process), same H / SNR %.1f dB / max_iter %d, fp64 per-frame scipy.sparse decoder "
+                        "(oracle/scipy_baseline.py), %d single-thread processes, %.1f s, mean %.1f sweeps/frame" % (
+                            frames, frames_each, snr, max_iter, procs, wall, sum(r["iters"] for r in res) / max(frames, 1))}
+        with open(os.path.join(ROOT, "tests", "golden", "reference_timing.json")) as fp:
+            tj = json.load(fp)
+        for pt in tj["points"]:
+            if pt["decoder"] == "MSA" and abs(pt["snr_db"] - snr) < 1e-9:
+                sc.update(calibration_reference_over_scipy=round(pt["calibration"], 4),
+                          calibration_measured_on="%s, %d frames: reference %.2f frames/s, scipy baseline %.2f frames/s" % (
+                              tj["host"], pt["frames"], pt["frames_per_s"], pt["baseline_frames_per_s"]),
+                          reference_estimate_frames_per_s=round(frames / wall * pt["calibration"], 2),
+                          reference_estimate_note="scipy-baseline rate on this host x calibration: what the reference's own Python would "
+                                                  "reach here with one process per core (it is single-threaded)")
+        out["scipy"] = sc
+    except Exception as e:  # the baseline is a report, never a reason to lose the benchmark line
+        out["scipy"] = {"error": repr(e)}
     return out
 
 
-def run_point(sim, handle, comm, snr, steps, warmup, batch, stream_id, torch, kernel_pass=True):
-    """Times `steps` steps at one SNR (uninstrumented, pipelined), then -- separately -- repeats them with the library's
-    HIP-event kernel timing switched on.  Returns dict(seconds, counters, profile)."""
+def _scipy_probe(task):
+    m, n, chk, var_idx, snr, max_iter, frames, seed = task
+    os.environ["OMP_NUM_THREADS"] = "1"
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from scipy_baseline import ScipyBP
+
+    dec = ScipyBP(m, n, chk, var_idx, "MSA", max_iter)
+    rng = np.random.RandomState(seed)
+    var = 10 ** (-snr / 10)
+    t0 = time.time()
+    iters = 0
+    for _ in range(frames):
+        y = -1 + rng.normal(0, np.sqrt(var), n)
+        dec.decode(y, -2 * y / var)
+        iters += dec.iterations
+    dt = time.time() - t0
+    return {"frames": frames, "iters": iters, "frames_per_s": frames / max(dt, 1e-9)}
+
+
+def _sync(device, torch):
+    if device == "cuda":
+        torch.cuda.synchronize()
+
+
+def run_point(sim, handle, comm, snr, steps, warmup, batch, stream_id, torch, kernel_pass=True, repeats=1, device="cuda"):
+    """`repeats` timed blocks of `steps` steps at one SNR (uninstrumented, pipelined), then -- separately -- the steps of one block again
+    with the library's HIP-event kernel timing switched on.  Returns dict(seconds (median block), blocks, counters (one block), profile)."""
     per_round = batch * comm.world
     frame0 = 0
-    handle.set_profiling(False)
+    if kernel_pass:
+        handle.set_profiling(False)
     for _ in range(warmup):
         sim.run_round(snr, stream_id, frame0, per_round)
         frame0 += per_round
-    tot = np.zeros(4 + sim.hist_bins, dtype=np.int64)
     first = frame0
-    comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    inflight = []
-    for _ in range(steps):
-        if len(inflight) == sim.DEPTH:
+    blocks, tot = [], None
+    for _rep in range(max(1, repeats)):
+        frame0 = first  # every block decodes the same frames: identical work, identical counters
+        tot = np.zeros(4 + sim.hist_bins, dtype=np.int64)
+        comm.barrier()
+        _sync(device, torch)
+        t0 = time.perf_counter()
+        inflight = []
+        for _ in range(steps):
+            if len(inflight) == sim.DEPTH:
+                tot += sim.finish_round(inflight.pop(0))
+            inflight.append(sim.launch_round(snr, stream_id, frame0, per_round))
+            frame0 += per_round
+        while inflight:
             tot += sim.finish_round(inflight.pop(0))
-        inflight.append(sim.launch_round(snr, stream_id, frame0, per_round))
-        frame0 += per_round
-    while inflight:
-        tot += sim.finish_round(inflight.pop(0))
-    torch.cuda.synchronize()
-    comm.barrier()
-    dt = comm.max_float(time.perf_counter() - t0)
+        _sync(device, torch)
+        comm.barrier()
+        blocks.append(comm.max_float(time.perf_counter() - t0))
     prof = None
     if kernel_pass:  # same frames again, one step at a time, with HIP events around the dominant kernels (rank-local)
         handle.set_profiling(True)
@@ -134,7 +193,7 @@ def run_point(sim, handle, comm, snr, steps, warmup, batch, stream_id, torch, ke
             f += per_round
         prof = handle.read_profile(reset=True)
         handle.set_profiling(False)
-    return dict(seconds=dt, counters=tot, profile=prof)
+    return dict(seconds=statistics.median(blocks), blocks=blocks, counters=tot, profile=prof)
 
 
 def committed(name):
@@ -145,50 +204,57 @@ def committed(name):
         return {}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step")
-    ap.add_argument("--snr", type=float, default=1.0)
-    ap.add_argument("--max-iter", type=int, default=50)
-    ap.add_argument("--code", default="1200_3_6_rand_ldpc_1")
-    ap.add_argument("--precision", default="f64", choices=["f32", "f64"],
-                    help="message arithmetic; f64 is the reference's own (hard decisions bit-identical to it), f32 the throughput mode")
-    ap.add_argument("--backend", default="auto", choices=["auto", "stream", "fused"])
-    ap.add_argument("--points", type=float, nargs="*", default=[2.0, 3.0], help="extra SNR points reported under 'points'")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="headline only: skip the HIP-event kernel pass and the side legs")
-    args = ap.parse_args()
+def fused_roofline(kernel_name, frame_sweeps_per_s, cus, counters=None):
+    """LDS / VALU roofline of an LDS-resident kernel from its committed PMC counters (profiles/roofline_counters.json, keyed by kernel
+    name): busy cycles per frame-sweep x frame-sweeps/s / (CUs x [4 SIMDs x] 2.4 GHz).  None when the kernel has no committed counters."""
+    counters = committed("roofline_counters.json") if counters is None else counters
+    e = counters.get(kernel_name)
+    if not e:
+        return None
+    lds = frame_sweeps_per_s * e["lds_idx_active_per_frame_sweep"] / (cus * NOMINAL_CLOCK_HZ)
+    valu = frame_sweeps_per_s * e["valu_active_cycles_per_frame_sweep"] / (cus * 4 * NOMINAL_CLOCK_HZ)
+    bound = "lds" if lds >= valu else "valu"
+    peak = NOMINAL_CLOCK_HZ * cus * 256 / 1e9  # the LDS array is 64 banks x 4 B wide per clock and CU
+    return dict(bound=bound, frac=round(max(lds, valu), 4), lds_frac=round(lds, 4), valu_frac=round(valu, 4),
+                achieved=round(lds * peak, 1) if bound == "lds" else round(valu * 100, 2), peak=round(peak, 1) if bound == "lds" else 100.0,
+                unit="GB/s" if bound == "lds" else "% of VALU issue cycles",
+                lds_cycles_per_frame_sweep=e["lds_idx_active_per_frame_sweep"], bank_conflict_cycles_per_frame_sweep=e["bank_conflict_per_frame_sweep"],
+                valu_busy_cycles_per_frame_sweep=e["valu_active_cycles_per_frame_sweep"], valu_insts_per_frame_sweep=e["insts_valu_per_frame_sweep"],
+                lds_insts_per_frame_sweep=e["insts_lds_per_frame_sweep"], frame_sweeps_per_s=round(frame_sweeps_per_s, 1),
+                peak_clock_hz=NOMINAL_CLOCK_HZ, effective_clock_hz_in_pmc_pass=e.get("effective_clock_hz_in_pmc_pass"),
+                lds_busy_frac_in_pmc_pass=e.get("lds_busy_frac_in_pmc_pass"), valu_busy_frac_in_pmc_pass=e.get("valu_busy_frac_in_pmc_pass"),
+                wave_time_shares=dict(waiting=e.get("wait_any_share"), issue_stall=e.get("wait_inst_any_share"), issuing=e.get("active_inst_any_share")),
+                counters_kernel=kernel_name, counters_workload=e.get("workload"), counters_from=e.get("counters_from"))
 
+
+def run_bench(args, comm, make_handle=None, device="cuda"):
+    """The benchmark driver: returns the result dict on rank 0 (None elsewhere).  `make_handle(code, alg, precision, backend)` builds
+    the decoder handle (default: the HIP DecoderHandle -- no CPU path exists in the product)."""
     import torch
 
-    from ldpc_decoders_amd import dist
-    from ldpc_decoders_amd._device import DecoderHandle
     from ldpc_decoders_amd.montecarlo import DeviceSimulator
 
-    comm = dist.init_from_env()
-    if comm.world != args.gpus and comm.is_root:
-        print("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, comm.world), file=sys.stderr)
+    if make_handle is None:
+        from ldpc_decoders_amd._device import DecoderHandle as make_handle  # noqa: N813
     code = load_code(args.code)
-    handle = DecoderHandle(code, "MSA", args.precision, args.backend)
-    sim = DeviceSimulator(handle, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=args.max_iter + 1)
+    handle = make_handle(code, "MSA", args.precision, args.backend)
+    sim = DeviceSimulator(handle, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=args.max_iter + 1, device=device)
     s = 8 if args.precision == "f64" else 4
     bytes_per_frame_iter = s * (4 * code.E + code.n)  # SURVEY.md 8(d)
-    default_workload = args.batch == 65536 and args.code == "1200_3_6_rand_ldpc_1" and abs(args.snr - 1.0) < 1e-9 and args.max_iter == 50
+    side_legs = not args.no_profile and comm.world == 1 and device == "cuda"
+    kernel_pass = not args.no_profile and device == "cuda"
 
-    res = run_point(sim, handle, comm, args.snr, args.steps, args.warmup, args.batch, 0, torch, not args.no_profile)
+    res = run_point(sim, handle, comm, args.snr, args.steps, args.warmup, args.batch, 0, torch, kernel_pass, args.repeats, device)
     backend_used, _ = handle.last_stats()
     extra = []
     for i, snr in enumerate(args.points):
-        r = run_point(sim, handle, comm, snr, max(4, args.steps), 1, args.batch, 1 + i, torch, not args.no_profile)
+        r = run_point(sim, handle, comm, snr, max(4, args.steps), 1, args.batch, 1 + i, torch, kernel_pass, 1, device)
         extra.append((snr, r))
 
-    # HBM-bound reading of the same workload: the streaming backend (messages in HBM, [tile, edge, 64] layout), N = 1
+    # HBM-bound reading of the same workload: the streaming backend (state resident in HBM, [tile, edge, 64] layout), N = 1
     stream_res = None
-    if backend_used == "fused" and comm.world == 1 and not args.no_profile:
-        h2 = DecoderHandle(code, "MSA", args.precision, "stream")
+    if backend_used == "fused" and side_legs:
+        h2 = make_handle(code, "MSA", args.precision, "stream")
         sim2 = DeviceSimulator(h2, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=args.max_iter + 1)
         stream_res = run_point(sim2, h2, comm, args.snr, 2, 1, args.batch, 0, torch)
         del sim2, h2
@@ -196,7 +262,7 @@ def main():
     # Same frames with the priors RESIDENT IN HBM when the timed region starts (channel kernel run beforehand): decode + count
     # only, rank 0's shard.  Reported beside `value` (which times the whole hot path: channel + decode + count).
     hbm_leg = None
-    if comm.world == 1 and not args.no_profile:
+    if side_legs:
         from ldpc_decoders_amd import _lib
 
         pri, _y = handle.channel_device("biawgn", args.snr, 0, 0x5EED1200, 0, 0, args.batch)
@@ -217,11 +283,12 @@ def main():
 
     # the fp32 throughput mode of the same workload (statistically identical curves, not bit-identical frame by frame), N = 1
     f32_res = None
-    if args.precision == "f64" and comm.world == 1 and not args.no_profile:
-        h3 = DecoderHandle(code, "MSA", "f32", args.backend)
+    if args.precision == "f64" and side_legs:
+        h3 = make_handle(code, "MSA", "f32", args.backend)
         sim3 = DeviceSimulator(h3, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=args.max_iter + 1)
-        f32_res = run_point(sim3, h3, comm, args.snr, args.steps, 1, args.batch, 0, torch, False)
+        f32_res = run_point(sim3, h3, comm, args.snr, args.steps, 1, args.batch, 0, torch, True, 3)
         f32_res["backend"] = h3.last_stats()[0]
+        f32_res["kernel"] = h3.kernel_name(True) if f32_res["backend"] == "fused" else ""
         del sim3, h3
 
     def kernel_ms(r):
@@ -231,135 +298,171 @@ def main():
         c = r["counters"]
         frames, iter_sum = int(c[0]), int(c[3])
         fps = frames / r["seconds"]
-        out = {"snr_db": snr, "frames_per_s": round(fps, 1), "ms_per_step": round(1e3 * r["seconds"] / steps, 3),
+        per_step = [1e3 * b / steps for b in r["blocks"]]
+        out = {"snr_db": snr, "frames_per_s": round(fps, 1), "ms_per_step": round(1e3 * r["seconds"] / steps, 4),
+               "ms_per_step_min": round(min(per_step), 4), "ms_per_step_max": round(max(per_step), 4), "timed_blocks": len(per_step),
                "mean_sweeps": round(iter_sum / max(frames, 1), 3), "wer": round(int(c[1]) / max(frames, 1), 6),
                "ber": float(c[2]) / max(frames * code.n, 1),
                "algorithmic_GBps": round(iter_sum * bytes_per_frame_iter / r["seconds"] / 1e9, 1)}
         km = kernel_ms(r)
         if km is not None:
-            # step time of the uninstrumented pipelined region minus the HIP-event time of the dominant kernels of the same steps
+            # step time of the uninstrumented pipelined region minus the HIP-event time of the kernels of the same steps
             out["kernel_ms_per_step"] = round(km / steps, 4)
-            out["host_overhead_ms_per_step"] = round(1e3 * r["seconds"] / steps - km / steps, 4)
+            total = r["profile"].get("stream_decode_total", (0, 0))[0]
+            if total > 0:  # streaming backend: the whole decode, side kernels (tile load, syndrome, repack, unpack) included
+                out["decode_ms_per_step"] = round(total / steps, 4)
+                out["side_kernels_ms_per_step"] = round((total - km) / steps, 4)
+                out["host_overhead_ms_per_step"] = round(1e3 * r["seconds"] / steps - total / steps, 4)
+                out["host_overhead_note"] = "step - HIP-event time of the whole decode; what is left is the channel and counting kernels of the step + host gaps"
+            else:
+                out["host_overhead_ms_per_step"] = round(1e3 * r["seconds"] / steps - km / steps, 4)
         return out
 
-    if comm.is_root:
-        head = summarise(args.snr, res, args.steps)
-        c = res["counters"]
-        iter_sum_rank0_share = int(c[3]) / comm.world  # the profile is rank 0's; counters are whole-job
-        roof = None
-        prof = res["profile"]
-        if prof:
-            kind = max(KERNEL_CLASSES, key=lambda k: prof[k][0])  # dominant kernel = the class with the most event time on rank 0
-            ms, launches = prof[kind]
-            frac_bytes = {"stream_check_pass": 2 * code.E * s, "stream_variable_pass": (2 * code.E + code.n) * s,
-                          "fused_decode": bytes_per_frame_iter}[kind]
-            # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, calibrated and
-            # corrected as MI355X_MICROARCH.md prescribes): collected by tools/collect_profiles.sh, committed under profiles/
-            traffic = None
-            if default_workload:
-                key = {"stream_check_pass": "stream:%s:k_cn" % args.precision, "stream_variable_pass": "stream:%s:k_vn" % args.precision,
-                       "fused_decode": "sim:%s:k_fused" % args.precision}[kind]
-                for k, v in committed("hbm_traffic.json").items():
-                    if k.startswith(key):
-                        traffic = int(v)
-            if launches > 0 and ms > 0:
-                bytes_total = iter_sum_rank0_share * frac_bytes
-                hbm_gbs = bytes_total / (ms * 1e-3) / 1e9
-                common = {"kernel": kind, "avg_launch_ms": round(ms / launches, 4), "launches": int(launches), "traffic": traffic,
-                          "all_kernels_ms": {k: round(v[0], 3) for k, v in prof.items()}}
+    if not comm.is_root:
+        return None
+    head = summarise(args.snr, res, args.steps)
+    c = res["counters"]
+    iter_sum_rank0_share = int(c[3]) / comm.world  # the profile is rank 0's; counters are whole-job
+    roof = None
+    prof = res["profile"]
+    cus = torch.cuda.get_device_properties(0).multi_processor_count if device == "cuda" else 256
+    if prof:
+        kind = max(KERNEL_CLASSES, key=lambda k: prof[k][0])  # dominant kernel = the class with the most event time on rank 0
+        ms, launches = prof[kind]
+        if launches > 0 and ms > 0:
+            common = {"kernel_class": kind, "avg_launch_ms": round(ms / launches, 4), "launches": int(launches),
+                      "all_kernels_ms": {k: round(v[0], 3) for k, v in prof.items()}}
+            if kind == "fused_decode":
+                kname = handle.kernel_name(True)
+                fsps = iter_sum_rank0_share / (ms * 1e-3)
+                hbm_gbs = iter_sum_rank0_share * bytes_per_frame_iter / (ms * 1e-3) / 1e9
                 hbm_model = {"achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "hbm_model_frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
-                             "algorithmic_bytes_per_launch": int(bytes_total / launches),
-                             "note": "SURVEY 8(d) model: sum over frames of sweeps executed x %d B (%s share of s(4E+n)) / HIP-event time" % (frac_bytes, kind)}
-                if kind != "fused_decode":
-                    roof = dict(bound="hbm", achieved=hbm_model["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_model["hbm_model_frac"],
-                                algorithmic_bytes_per_launch=hbm_model["algorithmic_bytes_per_launch"], note=hbm_model["note"], **common)
-                else:
-                    # The on-chip kernel is bound by the LDS pipe.  LDS-array cycles per frame-sweep are MEASURED (SQ_LDS_IDX_ACTIVE of
-                    # this kernel on this workload / frame-sweeps of the profiled launches; profiles/lds_cycles.json); here they are
-                    # multiplied by the frame-sweeps/s of the live HIP-event timing.
-                    lc = next((v for k, v in committed("lds_cycles.json").items() if k.startswith("%s:k_fused" % args.precision)), None)
-                    cus = torch.cuda.get_device_properties(0).multi_processor_count
-                    fsps = iter_sum_rank0_share / (ms * 1e-3)
-                    if lc is not None and default_workload:
-                        cyc = fsps * lc["lds_idx_active_per_frame_sweep"]  # LDS-array busy cycles per second, all CUs
-                        # expressed as bytes: the LDS array is 64 banks x 4 B = 256 B wide per clock and CU (MI355X_MICROARCH.md, LDS);
-                        # peak at the chip's maximum clock (2.4 GHz) -- the clock the profiled launches really ran at is stated beside it
-                        ach, peak = cyc * 256 / 1e9, NOMINAL_CLOCK_HZ * cus * 256 / 1e9
-                        # two model figures beside the measured one (per frame-sweep, MI355X_MICROARCH.md LDS table): the conflict-free
-                        # instruction minimum of the LDS array (2 cycles per gather; a stored row of 64 elements 2 cycles (4 B) / 4 (8 B)),
-                        # and the same with what a store really occupies -- its address/data transfer (ds_write_addtid_b32 2 cycles per
-                        # row, ds_write2st64_b64 13 per two rows) -- plus the measured conflict cycles
-                        fi = handle.fused_info()
-                        rows = int(fi["check_rounds"]) * int(code.row_degrees().max()) + int(fi["variable_rounds"])
-                        gath = fi["lds_gather_cycles_min"]
-                        arr_min = gath + rows * (4 if s == 8 else 2)
-                        path = gath + rows * (6.5 if s == 8 else 2) + (lc.get("bank_conflict_per_frame_sweep") or 0)
-                        avail = NOMINAL_CLOCK_HZ * cus
-                        model = dict(rows_stored_per_frame_sweep=rows, gather_cycles=gath, array_cycles_conflict_free=arr_min,
-                                     frac_conflict_free_minimum=round(fsps * arr_min / avail, 4),
-                                     cycles_incl_store_transfer_and_conflicts=round(path, 1),
-                                     frac_incl_store_transfer=round(fsps * path / avail, 4), planner_conflict_cycles=fi["conflict_cycles_planned"])
-                        roof = dict(bound="lds", achieved=round(ach, 1), peak=round(peak, 1), unit="GB/s", frac=round(ach / peak, 4),
-                                    instruction_model=model,
-                                    lds_cycles_per_frame_sweep=lc["lds_idx_active_per_frame_sweep"],
-                                    bank_conflict_cycles_per_frame_sweep=lc.get("bank_conflict_per_frame_sweep"),
-                                    frame_sweeps_per_s=round(fsps, 1), peak_clock_hz=NOMINAL_CLOCK_HZ,
-                                    effective_clock_hz_in_pmc_pass=lc.get("effective_clock_hz"),
-                                    frac_in_pmc_pass_at_its_effective_clock=lc.get("lds_pipe_busy_in_pmc_pass"),
-                                    counters_from="profiles/lds_cycles.json: " + lc.get("kernel", ""),
-                                    note="LDS-array roofline: frac = busy LDS-array cycles / (CUs x 2.4 GHz), GB/s = cycles x 256 B (array width). "
-                                         "Cycles per frame-sweep = SQ_LDS_IDX_ACTIVE of this kernel on this workload / frame-sweeps of the profiled "
-                                         "launches (committed rocprofv3 --pmc pass), x frame-sweeps/s from the HIP events of this run; the messages "
-                                         "never leave the CU, so HBM does not bound this kernel (hbm_model is informational)",
-                                    hbm_model=dict(hbm_model, flag="exceeds the HBM peak: on-chip kernel, not a bound"), **common)
-                    else:
-                        fi = handle.fused_info()
-                        roof = dict(bound="lds", achieved=None, peak=round(NOMINAL_CLOCK_HZ * cus * 256 / 1e9, 1), unit="GB/s", frac=None,
-                                    frame_sweeps_per_s=round(fsps, 1), planner=fi,
-                                    note="no committed SQ_LDS_IDX_ACTIVE counters for this (code, batch, SNR): run tools/collect_profiles.sh",
-                                    hbm_model=dict(hbm_model, flag="on-chip kernel, not a bound"), **common)
-        out = {
-            "metric": ("decoded frames/s, n=1200 (3,6) min-sum max_iter=50 (+ roofline of the dominant kernel)"
-                       if args.code == "1200_3_6_rand_ldpc_1" and args.max_iter == 50 else
-                       "decoded frames/s, %s min-sum max_iter=%d (+ roofline of the dominant kernel)" % (args.code, args.max_iter)),
-            "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "%s MSA over BI-AWGN, max_iter=%d, batch=%d frames/GPU, %.1f dB (mean %.2f sweeps/frame), "
-                                   "all-zero word + Philox noise on device" % (args.code, args.max_iter, args.batch, args.snr, head["mean_sweeps"]),
-                       "code": args.code, "n": code.n, "m": code.m, "E": code.E, "decoder": "MSA", "channel": "biawgn", "snr_db": args.snr,
-                       "max_iter": args.max_iter, "batch_per_gpu": args.batch, "backend": backend_used,
-                       "parallelism": "frames sharded over %d GPU(s), 1 all-reduce of counters per step, %d steps in flight" % (comm.world, sim.DEPTH)},
-            "mean_sweeps": head["mean_sweeps"], "wer": head["wer"], "ber": head["ber"],
-            "kernel_ms_per_step": head.get("kernel_ms_per_step"), "host_overhead_ms_per_step": head.get("host_overhead_ms_per_step"),
-            "algorithmic_GBps": head["algorithmic_GBps"], "bytes_per_frame_sweep": bytes_per_frame_iter,
-            "roofline": roof,
-            "decode_from_hbm": hbm_leg,
-            "fp32_mode": None if f32_res is None else dict(summarise(args.snr, f32_res, args.steps), backend=f32_res["backend"],
-                                                           note="same workload with fp32 message arithmetic (bench.py --precision f32)"),
-            "points": [summarise(snr, r, max(4, args.steps)) for snr, r in extra],
-        }
-        if stream_res is not None:
-            sp, sc = stream_res["profile"], stream_res["counters"]
-            it_sum = int(sc[3])
-            legs = {}
-            for kname, share in (("stream_check_pass", 2 * code.E * s), ("stream_variable_pass", (2 * code.E + code.n) * s)):
-                kms, kl = sp[kname]
-                if kl:
-                    gbs = it_sum * share / (kms * 1e-3) / 1e9
-                    legs[kname] = {"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(kms / kl, 4),
-                                   "launches": int(kl), "algorithmic_bytes_per_launch": int(it_sum * share / kl)}
-            out["roofline_streaming_backend"] = {
-                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": legs,
-                "frames_per_s": round(int(sc[0]) / stream_res["seconds"], 1),
-                "note": "same workload with --backend stream (messages resident in HBM): the HBM-bound path used for codes that do "
-                        "not fit the LDS; PMC traffic per launch in profiles/hbm_traffic.json equals the algorithmic bytes"}
-        if comm.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(code, args.snr, args.max_iter, args.precision)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
-    dist.finalize()
+                             "flag": "exceeds the HBM peak: on-chip kernel, not a bound",
+                             "note": "SURVEY 8(d) model: sum over frames of sweeps executed x %d B / HIP-event time" % bytes_per_frame_iter}
+                roof = fused_roofline(kname, fsps, cus)
+                traffic = None
+                for k, v in committed("roofline_counters.json").items():
+                    if k.startswith("hbm:") and k.endswith(":" + kname):
+                        traffic = v["hbm_bytes_per_launch"]
+                if roof is None:
+                    roof = dict(bound="lds", frac=None, achieved=None, peak=round(NOMINAL_CLOCK_HZ * cus * 256 / 1e9, 1), unit="GB/s",
+                                frame_sweeps_per_s=round(fsps, 1), note="no committed PMC counters for %s: run tools/collect_rooflines.sh" % kname)
+                roof.update(kernel=kname, traffic=traffic, hbm_model=hbm_model,
+                            note="LDS-resident kernel: frac = busy cycles of the binding unit / available cycles at 2.4 GHz.  Cycles per frame-sweep are "
+                                 "PMC counters (SQ_LDS_IDX_ACTIVE, 4 x SQ_ACTIVE_INST_VALU) of THIS kernel (the simulate variant that is timed), "
+                                 "committed under profiles/, x the frame-sweeps/s of the HIP-event timing of this run; `traffic` = PMC HBM bytes per launch",
+                            **common)
+            else:
+                # streaming kernels: each pass priced with its own compulsory bytes; the sweep with the section-8(d) model
+                share = {"stream_check_pass": (2 * code.E + code.n) * s, "stream_variable_pass": (code.E + 2 * code.n) * s}
+                legs = {}
+                for kname in ("stream_check_pass", "stream_variable_pass"):
+                    kms, kl = prof[kname]
+                    if kl:
+                        gbs = iter_sum_rank0_share * share[kname] / (kms * 1e-3) / 1e9
+                        legs[kname] = {"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(kms / kl, 4),
+                                       "launches": int(kl), "compulsory_bytes_per_frame_sweep": share[kname]}
+                pair_ms = prof["stream_check_pass"][0] + prof["stream_variable_pass"][0]
+                sweep_gbs = iter_sum_rank0_share * bytes_per_frame_iter / (pair_ms * 1e-3) / 1e9
+                traffic = None
+                pref = "k_cn<" if kind == "stream_check_pass" else "k_vn<"
+                for k, v in committed("roofline_counters.json").items():
+                    if k.startswith("hbm:") and (":" + pref + ("double" if s == 8 else "float")) in k and v.get("workload", "").startswith(args.code + " "):
+                        traffic = v["hbm_bytes_per_launch"]
+                roof = dict(bound="hbm", achieved=round(sweep_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(sweep_gbs / HBM_PEAK_GBS, 4),
+                            algorithmic_bytes_per_frame_sweep=bytes_per_frame_iter, kernel="k_cn + k_vn (one sweep)", passes=legs, traffic=traffic,
+                            note="streaming backend: achieved = executed frame-sweeps x s(4E+n) (SURVEY 8(d)) / HIP-event time of the two passes; "
+                                 "`passes` prices each kernel with its own compulsory bytes (check pass: c2v in + out + each marginal once = s(2E+n); "
+                                 "variable pass: c2v in + prior in + marginal out = s(E+2n)); `traffic` = PMC HBM bytes per launch of the dominant "
+                                 "pass on this code (profiles/roofline_counters.json)", **common)
+    out = {
+        "metric": ("decoded frames/s, n=1200 (3,6) min-sum max_iter=50 (+ roofline of the dominant kernel)"
+                   if args.code == "1200_3_6_rand_ldpc_1" and args.max_iter == 50 else
+                   "decoded frames/s, %s min-sum max_iter=%d (+ roofline of the dominant kernel)" % (args.code, args.max_iter)),
+        "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "ms_per_step_min": head["ms_per_step_min"], "ms_per_step_max": head["ms_per_step_max"],
+        "timed_blocks": head["timed_blocks"], "blocks_ms_per_step": [round(1e3 * b / args.steps, 4) for b in res["blocks"]],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "%s MSA over BI-AWGN, max_iter=%d, batch=%d frames/GPU, %.1f dB (mean %.2f sweeps/frame), "
+                               "all-zero word + Philox noise on device" % (args.code, args.max_iter, args.batch, args.snr, head["mean_sweeps"]),
+                   "code": args.code, "n": code.n, "m": code.m, "E": code.E, "decoder": "MSA", "channel": "biawgn", "snr_db": args.snr,
+                   "max_iter": args.max_iter, "batch_per_gpu": args.batch, "backend": backend_used,
+                   "parallelism": "frames sharded over %d GPU(s), 1 all-reduce of counters per step, %d steps in flight" % (comm.world, sim.DEPTH)},
+        "mean_sweeps": head["mean_sweeps"], "wer": head["wer"], "ber": head["ber"],
+        "frames_counted": int(c[0]), "word_errors": int(c[1]), "bit_errors": int(c[2]),
+        "kernel_ms_per_step": head.get("kernel_ms_per_step"), "host_overhead_ms_per_step": head.get("host_overhead_ms_per_step"),
+        "side_kernels_ms_per_step": head.get("side_kernels_ms_per_step"),
+        "algorithmic_GBps": head["algorithmic_GBps"], "bytes_per_frame_sweep": bytes_per_frame_iter,
+        "roofline": roof,
+        "decode_from_hbm": hbm_leg,
+        "fp32_mode": None,
+        "points": [summarise(snr, r, max(4, args.steps)) for snr, r in extra],
+    }
+    if f32_res is not None:
+        f32 = dict(summarise(args.snr, f32_res, args.steps), backend=f32_res["backend"], kernel=f32_res["kernel"],
+                   note="same workload with fp32 message arithmetic (bench.py --precision f32)")
+        fp = f32_res["profile"]
+        if fp and fp["fused_decode"][1] > 0:
+            f32["roofline"] = fused_roofline(f32_res["kernel"], int(f32_res["counters"][3]) / (fp["fused_decode"][0] * 1e-3), cus)
+        out["fp32_mode"] = f32
+    if stream_res is not None:
+        sp, sc = stream_res["profile"], stream_res["counters"]
+        it_sum = int(sc[3])
+        legs = {}
+        for kname, share in (("stream_check_pass", (2 * code.E + code.n) * s), ("stream_variable_pass", (code.E + 2 * code.n) * s)):
+            kms, kl = sp[kname]
+            if kl:
+                gbs = it_sum * share / (kms * 1e-3) / 1e9
+                legs[kname] = {"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(kms / kl, 4),
+                               "launches": int(kl), "compulsory_bytes_per_frame_sweep": share}
+        pair_ms = sp["stream_check_pass"][0] + sp["stream_variable_pass"][0]
+        out["roofline_streaming_backend"] = {
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": legs,
+            "sweep_achieved": round(it_sum * bytes_per_frame_iter / (pair_ms * 1e-3) / 1e9, 1),
+            "sweep_frac": round(it_sum * bytes_per_frame_iter / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "frames_per_s": round(int(sc[0]) / stream_res["seconds"], 1),
+            "note": "same workload with --backend stream (state resident in HBM): the HBM-bound path used for codes that do not fit the LDS; "
+                    "sweep_* = executed frame-sweeps x s(4E+n) / time of the two passes; per kernel: its own compulsory bytes"}
+    if comm.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(code, args.snr, args.max_iter, args.precision)
+    else:
+        out["cpu_baseline"] = None
+    return out
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; ms_per_step is the median block")
+    ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step")
+    ap.add_argument("--snr", type=float, default=1.0)
+    ap.add_argument("--max-iter", type=int, default=50)
+    ap.add_argument("--code", default="1200_3_6_rand_ldpc_1")
+    ap.add_argument("--precision", default="f64", choices=["f32", "f64"],
+                    help="message arithmetic; f64 is the reference's own (hard decisions bit-identical to it), f32 the throughput mode")
+    ap.add_argument("--backend", default="auto", choices=["auto", "stream", "fused"])
+    ap.add_argument("--points", type=float, nargs="*", default=[2.0, 3.0], help="extra SNR points reported under 'points'")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="headline only: skip the HIP-event kernel pass and the side legs")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    from ldpc_decoders_amd import dist
+
+    comm = dist.init_from_env()
+    if comm.world != args.gpus and comm.is_root:
+        print("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, comm.world), file=sys.stderr)
+    try:
+        out = run_bench(args, comm)
+        if comm.is_root:
+            print(json.dumps(out))
+    finally:
+        dist.finalize()
 
 
 if __name__ == "__main__":

@@ -69,13 +69,20 @@ int ldpc_decoder_fused_info(ldpc_decoder_t dec, double* out8);
 
 /* Host-only (no GPU needed): the LDS layout plan the fused backend would use for this (graph, algorithm, arithmetic) -- chosen
  * kernel shape, bank-conflict-minimising placement of checks / variables / edge positions (csrc/ldpc_layout.hpp) -- annealed with
- * `moves` moves (<= 0: the default short run) and stored as <key>.plan in out_dir (NULL: not stored).  Decoders find such files in
+ * `moves` moves (0: the default short run) and stored as <key>.plan in out_dir (NULL: not stored).  moves < 0: what decoder
+ * construction does -- a stored plan is used if there is one (info4[0] is then negated), otherwise ONE process per node anneals the
+ * default run (lock file next to the plan; the others wait for the file) and keeps it in out_dir / the per-user cache.  Decoders find such files in
  * $LDPC_FUSED_PLAN_DIR, in <package>/plans and in the per-user cache.  No upstream counterpart (the placement is a property of this
  * implementation; the graph arguments are those of ldpc_code_create, i.e. BPA.__init__'s edge lists, src/bpa.py:9-15).
  * info4 = {wavefronts per frame (0: no fused shape for this graph), conflict-free LDS gather cycles per sweep, extra bank-conflict
  * cycles of the trivial placement, extra cycles of the plan}. */
 int ldpc_plan_layout(int32_t m, int32_t n, int64_t E, const int32_t* edge_chk, const int32_t* edge_var, int alg, int dtype,
                      int64_t moves, const char* out_dir, double* info4);
+
+/* Name of the LDS-resident kernel this decoder launches (simulate != 0: the Monte-Carlo variant behind ldpc_simulate), exactly as
+ * rocprofv3 prints it, e.g. "k_fused_bp<0, 6, 3, 5, 10, 2, true, 0, 3>" -- the key under which its committed PMC counters are filed
+ * (profiles/roofline_counters.json).  Empty string: the decoder runs on the streaming kernels.  No upstream counterpart. */
+int ldpc_decoder_kernel_name(ldpc_decoder_t dec, int simulate, char* buf, int64_t len);
 
 /* Per-kernel timing for roofline reports: when enabled, decode calls bracket their dominant kernels with HIP events
  * recorded ON THE DECODE STREAM and accumulate elapsed milliseconds / launch counts per kernel class:

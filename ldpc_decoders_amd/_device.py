@@ -190,6 +190,12 @@ class DecoderHandle:
                 "lds_bytes_per_frame", "check_rounds", "variable_rounds")
         return dict(zip(keys, list(out)))
 
+    def kernel_name(self, simulate=False):
+        """Name of the LDS-resident kernel (as rocprofv3 prints it) this decoder launches; '' on the streaming kernels."""
+        buf = ctypes.create_string_buffer(160)
+        _lib.check(_lib.load().ldpc_decoder_kernel_name(self.h, 1 if simulate else 0, buf, 160))
+        return buf.value.decode()
+
     def set_profiling(self, on):
         _lib.check(_lib.load().ldpc_decoder_profile(self.h, 1 if on else 0))
 

@@ -38,6 +38,7 @@ SIGNATURES = {
                                     _c.POINTER(_c.c_double)]),
     "ldpc_decoder_profile": (_c.c_int, [_P, _c.c_int]),
     "ldpc_decoder_profile_read": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.c_int]),
+    "ldpc_decoder_kernel_name": (_c.c_int, [_P, _c.c_int, _c.c_char_p, _c.c_int64]),
     "ldpc_decode": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P, _P]),
     "ldpc_decode_soft": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P, _P, _P]),
     "ldpc_decode_host": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P]),
@@ -81,7 +82,10 @@ def load():
         import torch  # noqa: F401
 
         lib = ctypes.CDLL(LIB_PATH)
+        older_build = os.environ.get("LDPC_LIB_ALLOW_OLDER_ABI") == "1"  # A/B runs against a library of an earlier round (tools/ab_sim.sh)
         for name, (res, args) in SIGNATURES.items():
+            if older_build and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)  # AttributeError here == ABI mismatch with include/ldpc_hip.h
             fn.restype, fn.argtypes = res, args
         _lib = lib

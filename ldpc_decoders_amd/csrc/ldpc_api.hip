@@ -267,6 +267,12 @@ int ldpc_decoder_fused_info(ldpc_decoder_t h, double* out8) {
     return fused_info(d, out8);
 }
 
+int ldpc_decoder_kernel_name(ldpc_decoder_t h, int simulate, char* buf, int64_t len) {
+    Decoder* d = (Decoder*)h;
+    if (!d || !buf || len <= 0) return LDPC_E_ARG;
+    return fused_kernel_name(d, simulate != 0, buf, (size_t)len);
+}
+
 int ldpc_decoder_profile(ldpc_decoder_t h, int enable) {
     Decoder* d = (Decoder*)h;
     if (!d) return LDPC_E_ARG;

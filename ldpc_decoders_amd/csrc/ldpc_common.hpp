@@ -122,6 +122,7 @@ bool fused_simulate_supported(const Decoder* d, int channel, double param, int h
 int fused_simulate(Decoder* d, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
                    int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st);
 int fused_info(const Decoder* d, double* out8);
+int fused_kernel_name(const Decoder* d, bool sim, char* buf, size_t len);
 int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
                  uint8_t* xhat, int32_t* iters, void* soft_out, hipStream_t st);
 

@@ -1,8 +1,12 @@
 // Fused on-chip backend, host side: chooses a kernel shape for a (code, algorithm, arithmetic), plans the LDS layout, builds the
 // gather tables and launches.  The kernels are in ldpc_fused_kernels.hpp, instantiated by the ldpc_fused_shapes_*.hip units.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+
+#include <cerrno>
+#include <ctime>
 
 #include <algorithm>
 #include <cstdlib>
@@ -78,11 +82,13 @@ static std::string plan_save_dir() {
 }
 
 static void make_dirs(const std::string& path) {
+    // directories this library creates are private to the user (plans are later LOADED from here); existing ones are left as they are
     for (size_t i = 1; i <= path.size(); ++i)
-        if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0777);
+        if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0700);
 }
 
-// directories searched for stored layout plans: $LDPC_FUSED_PLAN_DIR (colon-separated), the per-user cache, then <package>/plans next to csrc/
+// directories searched for stored layout plans, in this order: $LDPC_FUSED_PLAN_DIR (colon-separated), <package>/plans next to csrc/
+// (the shipped long annealing runs), then the per-user cache (short runs made at decoder construction)
 static std::vector<std::string> plan_dirs() {
     std::vector<std::string> dirs;
     if (const char* e = std::getenv("LDPC_FUSED_PLAN_DIR")) {
@@ -122,6 +128,19 @@ int fused_info(const Decoder* d, double* out8) {
     out8[5] = (double)p->lds_bytes;      // LDS bytes per frame
     out8[6] = p->CR;
     out8[7] = p->VR;
+    return LDPC_OK;
+}
+
+// "k_fused_bp<0, 6, 3, 5, 10, 2, true, 0, 3>": the demangled name rocprofv3 / the code-object metadata give the kernel this decoder
+// launches (sim: the Monte-Carlo variant) -- the key under which its PMC counters are filed in profiles/.  Empty: no fused kernel.
+int fused_kernel_name(const Decoder* d, bool sim, char* buf, size_t len) {
+    if (!buf || len == 0) return LDPC_E_ARG;
+    buf[0] = 0;
+    const FusedPlan* p = d->fused;
+    if (!p || !p->ok) return LDPC_OK;
+    const ShapeEntry& s = all_shapes()[p->shape];
+    snprintf(buf, len, "%s<%d, %d, %d, %d, %d, %d, %s, %d, %d>", s.esz == 8 ? "k_fused_f64" : "k_fused_bp", s.alg, s.DC, s.DV, s.CRW, s.VRW, s.NW,
+             sim ? "true" : "false", s.VRX, s.DVX);
     return LDPC_OK;
 }
 
@@ -190,12 +209,40 @@ bool obtain_layout(const Code* c, const ShapeChoice& ch, bool use_store, long mo
         if (const char* e = std::getenv("LDPC_FUSED_PLAN_MOVES")) moves = atol(e);
         else if (const char* ms = std::getenv("LDPC_FUSED_PLAN_MS")) moves = (long)(atof(ms) * 1700.0);
     }
+    // Plan once per node: eight ranks (or run_sims.sh PARA) constructing a decoder for the same un-planned code would each anneal the
+    // same plan (2.4 s+, a pure function of H and the shape).  The first process to create <save_dir>/.<key>.lock anneals and
+    // publishes the file with an atomic rename; the others wait for it (bounded), then load it -- or anneal themselves if it never
+    // comes (a crashed owner; a lock older than ten minutes is ignored).
+    std::string lock;
+    bool owner = true;
+    if (!save_dir.empty() && use_store) {
+        make_dirs(save_dir);
+        lock = save_dir + "/." + name + ".lock";
+        struct stat sb;
+        if (stat(lock.c_str(), &sb) == 0 && time(nullptr) - sb.st_mtime > 600) (void)unlink(lock.c_str());
+        const int fd = open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0600);
+        if (fd >= 0) {
+            (void)close(fd);
+        } else if (errno == EEXIST) {
+            owner = false;
+            const double wait_s = 30.0 + (double)moves / 1.0e6;  // the owner needs about moves / 1.7e6 seconds
+            for (double waited = 0; waited < wait_s; waited += 0.05) {
+                if (layout_load(save_dir + "/" + name, key, *c, shape.DC, CR, ch.vr, L)) return true;
+                if (stat(lock.c_str(), &sb) != 0) break;  // the owner is gone without a file: anneal here
+                usleep(50000);
+            }
+            lock.clear();  // not ours to remove
+        } else {
+            lock.clear();  // read-only or missing directory: anneal without publishing
+        }
+    }
     plan_fused_layout(*c, shape.DC, CR, ch.vr, 0x1200u, moves, L);
     if (!save_dir.empty()) {
         make_dirs(save_dir);
         const std::string tmp = save_dir + "/." + name + "." + std::to_string((long)getpid());
         if (layout_save(tmp, key, *c, *L)) (void)rename(tmp.c_str(), (save_dir + "/" + name).c_str());  // atomic: readers never see half a file
     }
+    if (owner && !lock.empty()) (void)unlink(lock.c_str());
     return false;
 }
 
@@ -209,8 +256,10 @@ int fused_plan_host(const Code* c, int alg, int dtype, long moves, const char* o
     const ShapeChoice ch = choose_shape(c, alg, dtype);
     if (ch.si < 0) return LDPC_OK;
     FusedLayout L;
-    (void)obtain_layout(c, ch, false, moves, out_dir ? std::string(out_dir) : std::string(), &L);
-    info4[0] = all_shapes()[ch.si].NW;
+    // moves < 0: exactly what ldpc_decoder_create does -- plan store first, otherwise ONE process per node anneals the default run
+    const bool found = obtain_layout(c, ch, moves < 0, moves, out_dir ? std::string(out_dir) : (moves < 0 ? plan_save_dir() : std::string()), &L);
+    if (info4) info4[0] = found ? -1.0 : 0.0;
+    info4[0] = (info4[0] < 0 ? -1.0 : 1.0) * all_shapes()[ch.si].NW;  // negative: the plan came out of the store (moves < 0 only)
     info4[1] = L.base_cycles;
     info4[2] = L.extra_cycles_identity;
     info4[3] = L.extra_cycles_planned;

@@ -164,11 +164,13 @@ constexpr int sim_opaque_vn(int, int, int) { return LDPC_SIM_OPAQUE_VN_WORDS; }
 constexpr int sim_opaque_cn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_MSA ? 8 : 15;           // one frame per CU (16 waves): min-sum 8 + 15 -> no spill
     if (alg == ALG_MSA && vrx == 0) return 0;             // regular min-sum (the headline shape): nothing needed
+    if (alg == ALG_BEC && vrx == 0) return 4;             // regular erasure decoder: 4 + 4
     return 8;
 }
 constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_BEC ? 0 : 15;           // (the 16-wave erasure kernel streams its variable table anyway)
     if (alg == ALG_MSA && vrx == 0) return 0;
+    if (alg == ALG_BEC && vrx == 0) return 4;
     return 15;
 }
 #endif

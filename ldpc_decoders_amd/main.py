@@ -59,13 +59,19 @@ def test(args, comm=None):
                 log.info(", ".join("%s:%s" % (k.upper(), v) for k, v in zip(keys, vals)))
             if hasattr(decoder, "stats"):  # e.g. the ADMM iteration histogram (src/main.py:34)
                 keys.append("dec"), vals.append(decoder.stats())
+            if c.get("capped"):  # an addition: the point was stopped by --max-frames before reaching --min-wec
+                keys.append("capped"), vals.append(True)
             if comm.is_root:
                 saver.add(param, OrderedDict(zip(keys, vals)))
             return OrderedDict(zip(keys, vals))
 
-        def progress(tot, wec, bec):
+        def progress(tot, wec, bec, hist=None):
             if time.time() - state["t"] > args.log_freq:
                 state["t"] = time.time()
+                if hist is not None and state.get("hist_into") is not None:  # the decoder's own histogram follows the reduced counters
+                    into, bins = state["hist_into"]
+                    into[:] = 0
+                    into[:bins] = hist[:bins]
                 log_status(dict(tot=tot, wec=wec, bec=bec))
 
         inner = decoder if hasattr(decoder, "handle") else getattr(decoder, "dec", None)
@@ -95,6 +101,7 @@ def test(args, comm=None):
             bins = min(len(inner.iter), args.max_iter + 1 if args.max_iter > 0 else len(inner.iter)) if own_hist else 0
             if own_hist:
                 handle.on_iters = None
+                state["hist_into"] = (inner.iter, bins)  # intermediate result files then carry a real histogram, not zeros
             sim = DeviceSimulator(handle, args.channel, args.max_iter, args.codeword, args.seed, comm, hist_bins=bins)
             c = sim.run_point(param, stream_id=pi, min_wec=args.min_wec, batch_per_rank=args.batch, on_progress=progress,
                               max_frames=(args.max_frames or None))

@@ -63,15 +63,20 @@ class DeviceSimulator:
 
     DEPTH = 2  # rounds in flight in run_point / bench.py
 
-    def __init__(self, handle, channel, max_iter, codeword=0, seed=0x5EED1200, comm=None, hist_bins=0):
+    def __init__(self, handle, channel, max_iter, codeword=0, seed=0x5EED1200, comm=None, hist_bins=0, device="cuda"):
+        """``device``: where the counters live -- "cuda" always in the product (the handle is a HIP decoder); "cpu" lets the N > 1 driver
+        layer (sharding, pipelining, collective, stopping rule) be exercised on gloo ranks with a stand-in handle (tests/test_dist_cpu.py)."""
         import torch
 
         self.torch = torch
         self.h, self.channel, self.max_iter, self.codeword = handle, channel, int(max_iter), int(codeword)
         self.seed, self.comm, self.hist_bins = int(seed), comm or Comm(), int(hist_bins)
+        self.device = device
         k = 4 + self.hist_bins
-        self._slots = [dict(dev=torch.zeros(k, dtype=torch.int64, device="cuda"), host=torch.zeros(k, dtype=torch.int64).pin_memory(),
-                            done=torch.cuda.Event(), busy=False) for _ in range(self.DEPTH + 1)]
+        on_gpu = device == "cuda"
+        self._slots = [dict(dev=torch.zeros(k, dtype=torch.int64, device=device),
+                            host=torch.zeros(k, dtype=torch.int64).pin_memory() if on_gpu else torch.zeros(k, dtype=torch.int64),
+                            done=torch.cuda.Event() if on_gpu else None, busy=False) for _ in range(self.DEPTH + 1)]
         self._next = 0
 
     def launch_round(self, param, stream_id, frame0, frames_total, flags=0):
@@ -87,13 +92,15 @@ class DeviceSimulator:
                             flags=flags, hist_bins=self.hist_bins)
         self.comm.all_reduce_sum(slot["dev"], async_on_stream=True)
         slot["host"].copy_(slot["dev"], non_blocking=True)
-        slot["done"].record()
+        if slot["done"] is not None:
+            slot["done"].record()
         slot["busy"] = True
         return slot
 
     def finish_round(self, slot):
         """Wait for one launched round; returns its whole-job counters (numpy int64)."""
-        slot["done"].synchronize()
+        if slot["done"] is not None:
+            slot["done"].synchronize()
         slot["busy"] = False
         return slot["host"].numpy().copy()
 
@@ -101,28 +108,50 @@ class DeviceSimulator:
         """Decode global frames [frame0, frame0+frames_total) split over ranks; returns the reduced counters (numpy)."""
         return self.finish_round(self.launch_round(param, stream_id, frame0, frames_total, flags))
 
+    def pipeline_depth(self):
+        """Rounds worth keeping in flight.  Only the fused in-kernel path returns from ``simulate`` without a host wait; the
+        streaming kernels, the ADMM composition and ``--codeword -1`` poll / synchronise inside ``simulate``, so a second round in
+        flight buys them nothing and would only be decoded for the bin when the stopping rule fires."""
+        h = self.h
+        if self.codeword == -1 or not hasattr(h, "last_stats"):
+            return 1
+        return self.DEPTH if h.last_stats()[0] == "fused" else 1
+
     def run_point(self, param, stream_id, min_wec, batch_per_rank, on_progress=None, max_frames=None):
-        """Rounds until ``wec >= min_wec``.  The stopping rule is evaluated when a round's counters arrive, by which time the next
-        round is already running: that round is drained and DISCARDED, so the counters are exactly those of the synchronous
-        loop (a function of the round size only, not of the pipeline depth or the number of ranks)."""
+        """Rounds until ``wec >= min_wec``.  The FIRST round runs on its own: most points of the experiment tables reach ``min_wec``
+        (or ``max_frames``) inside it, and a speculative second round would be decoded and thrown away.  From the second round on
+        (fused path) rounds are pipelined: the stopping rule is evaluated when a round's counters arrive, by which time the next
+        round is already running; that round is drained and DISCARDED, so the counters are exactly those of the synchronous loop
+        (a function of the round size only, not of the pipeline depth or the number of ranks).  ``on_progress(tot, wec, bec, hist)``
+        receives the reduced counters after every counted round (``hist`` = the histogram bins or None)."""
         tot = np.zeros(4 + self.hist_bins, dtype=np.int64)
         frame0 = 0
         per_round = int(batch_per_rank) * self.comm.world
         inflight = []
+        capped = False
 
         def more():
             return tot[_lib.CNT_WEC] < min_wec and (max_frames is None or tot[_lib.CNT_TOT] < max_frames)
 
+        def count(got):
+            nonlocal tot
+            tot += got
+            if on_progress:
+                on_progress(int(tot[0]), int(tot[1]), int(tot[2]), tot[4:].copy() if self.hist_bins else None)
+
+        count(self.run_round(param, stream_id, frame0, per_round))
+        frame0 += per_round
+        depth = self.pipeline_depth()
         while more() or inflight:
-            while more() and len(inflight) < self.DEPTH:
+            while more() and len(inflight) < depth:
                 inflight.append(self.launch_round(param, stream_id, frame0, per_round))
                 frame0 += per_round
             got = self.finish_round(inflight.pop(0))
             if more():
-                tot += got
-                if on_progress:
-                    on_progress(int(tot[0]), int(tot[1]), int(tot[2]))
-        out = dict(tot=int(tot[0]), wec=int(tot[1]), bec=int(tot[2]), iter_sum=int(tot[3]))
+                count(got)
+        if tot[_lib.CNT_WEC] < min_wec:
+            capped = True  # stopped by max_frames, not by the word-error target
+        out = dict(tot=int(tot[0]), wec=int(tot[1]), bec=int(tot[2]), iter_sum=int(tot[3]), capped=capped)
         if self.hist_bins:
             out["hist"] = tot[4:].tolist()
         return out

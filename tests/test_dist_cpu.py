@@ -73,3 +73,98 @@ def test_shard_partition_is_exact():
             for s, c in spans:
                 assert s == pos
                 pos += c
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The N > 1 DRIVER LAYER of bench.py (run_bench: DeviceSimulator rounds, frame shards, pipelining, the per-step all-reduce, the JSON
+# line) on EIGHT gloo ranks.  The decoder handle is injected: here a CPU stand-in that draws the device's Philox noise (oracle model)
+# and decodes with the C oracle -- exactly the role tests/ may give the oracle; bench.py's own main() always builds the HIP handle.
+BENCH_WORKER = r'''
+import json, os, sys
+sys.path[:0] = [%(root)r, %(root)r + "/oracle", %(root)r + "/tests"]
+import numpy as np
+import torch
+import bp_oracle as O, c_oracle as C
+import bench
+from ldpc_decoders_amd import dist
+
+
+class OracleHandle:
+    """Stand-in for _device.DecoderHandle: same simulate() contract, frames decoded by the CPU oracle."""
+    log = []
+
+    def __init__(self, code, alg, precision, backend):
+        self.code, self.alg = code, alg
+        self.g = O.Edges(code.m, code.n, code.edge_chk, code.edge_var)
+
+    def simulate(self, channel, param, codeword, seed, stream_id, frame0, B, max_iter, counters, flags=0, hist_bins=0):
+        assert channel == "biawgn" and codeword == 0
+        OracleHandle.log.append((int(stream_id), int(frame0), int(B)))
+        var = O.biawgn_noise_var(param)
+        pri = np.stack([-2 * (-1 + np.sqrt(var) * O.device_biawgn_noise(seed, stream_id, f, self.g.n)) / var for f in range(frame0, frame0 + B)])
+        xh, it = C.bp_decode(self.g, self.alg, None, pri, max_iter, nthreads=1)
+        err = (xh != 0).sum(axis=1)
+        counters[0] += B
+        counters[1] += int((err > 0).sum())
+        counters[2] += int(err.sum())
+        counters[3] += int(it.sum())
+        if hist_bins:
+            counters[4:4 + hist_bins] += torch.from_numpy(np.bincount(np.minimum(it, hist_bins - 1), minlength=hist_bins))
+
+    def last_stats(self):
+        return "oracle", 0
+
+    def kernel_name(self, simulate=False):
+        return ""
+
+
+comm = dist.init_from_env(prefer_gpu=False)
+args = bench.parse_args(["--gpus", str(comm.world), "--steps", "3", "--warmup", "1", "--repeats", "2", "--batch", str(768 // comm.world),
+                         "--code", "7_4_hamming", "--snr", "2.0", "--max-iter", "10", "--points", "--no-profile", "--no-cpu-baseline"])
+out = bench.run_bench(args, comm, make_handle=OracleHandle, device="cpu")
+if out is not None:
+    print(json.dumps(out))
+json.dump(OracleHandle.log, open(sys.argv[1] + ".rank%%d" %% comm.rank, "w"))
+dist.finalize()
+'''
+
+
+def _run_bench_layer(world, tmp_path, port):
+    code = BENCH_WORKER % {"root": ROOT}
+    base = str(tmp_path / ("bench_w%d" % world))
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", code, base], env=env, stdout=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    lines = [ln for o in outs for ln in o.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]  # gloo's own connection banner
+    logs = [json.load(open(base + ".rank%d" % r)) for r in range(world)]
+    return lines, logs
+
+
+@pytest.mark.timeout(900)
+def test_bench_driver_layer_on_eight_ranks(tmp_path):
+    lines1, logs1 = _run_bench_layer(1, tmp_path, 29621)
+    lines8, logs8 = _run_bench_layer(8, tmp_path, 29622)
+    assert len(lines1) == 1 and len(lines8) == 1                      # ONE JSON line, printed by rank 0 only
+    one, eight = json.loads(lines1[0]), json.loads(lines8[0])
+    assert one["n_gpus"] == 1 and eight["n_gpus"] == 8 and eight["scaling"] == "weak" and eight["steps"] == 3
+    assert eight["config"]["batch_per_gpu"] == 96 and one["config"]["batch_per_gpu"] == 768
+    # the same global frames were decoded: every counter of the whole job equals the single-rank run
+    for k in ("frames_counted", "word_errors", "bit_errors", "mean_sweeps", "wer", "ber"):
+        assert one[k] == eight[k], k
+    assert eight["frames_counted"] == 3 * 768 and eight["timed_blocks"] == 2 and len(eight["blocks_ms_per_step"]) == 2
+    assert eight["value"] > 0 and eight["ms_per_step_min"] <= eight["ms_per_step"] <= eight["ms_per_step_max"]
+    # shard coverage: in every round the eight shards tile the round's frame range exactly, in rank order
+    rounds = len(logs8[0])
+    assert rounds == 1 + 2 * 3 and all(len(lg) == rounds for lg in logs8)
+    for i in range(rounds):
+        pos = logs1[0][i][1]
+        assert logs1[0][i][2] == 768
+        for r in range(8):
+            stream, start, cnt = logs8[r][i]
+            assert stream == logs1[0][i][0] and start == pos and cnt == 96
+            pos += cnt
+        assert pos == logs1[0][i][1] + 768

@@ -117,3 +117,28 @@ def test_main_loop_counters(run):
         tot, wec, bec = O.run_point(g, channel, alg, prm, int(opt["--codeword"]), int(opt["--min-wec"]), int(opt["--max-iter"]), chunk=chunk)
         key = str(prm)
         assert (tot, wec, bec) == (r["tot"][key], r["wec"][key], r["bec"][key])
+
+
+@pytest.mark.parametrize("name,alg", [("1200_3_6_rand_ldpc_1", "MSA"), ("1200_3_6_rand_ldpc_1", "SPA"), ("1200_rho_x5_rand_ldpc_5", "MSA"),
+                                      ("7_4_hamming", "SPA"), ("12_3_4_ldpc", "MSA")])
+def test_scipy_baseline_equals_the_oracle(name, alg):
+    """oracle/scipy_baseline.py (bench.py's per-frame scipy.sparse CPU baseline) decodes like the oracle: same hard
+    decisions and iteration counts; against the true reference it is checked frame by frame in oracle/make_timing.py
+    (tests/golden/reference_timing.json: identical_frames == frames)."""
+    import json
+
+    from scipy_baseline import ScipyBP
+
+    g = golden_edges(name)
+    rng = np.random.RandomState(11)
+    snr = 2.0
+    y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(snr)), (12, g.n))
+    pri = O.biawgn_priors(y, snr)
+    want_x, want_it = C.bp_decode(g, alg, None, pri, 30)
+    dec = ScipyBP(g.m, g.n, g.chk, g.var, alg, 30)
+    for f in range(len(y)):
+        xh = dec.decode(y[f], pri[f])
+        assert dec.iterations == want_it[f] and (np.asarray(xh) == want_x[f]).all()
+    with open(os.path.join(GOLDEN, "reference_timing.json")) as fp:
+        tj = json.load(fp)
+    assert all(p["identical_frames"] == p["frames"] >= 200 for p in tj["points"])

@@ -12,10 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from bench import load_code  # noqa: E402
+from bench import HBM_PEAK_GBS, fused_roofline, load_code  # noqa: E402
 from ldpc_decoders_amd._device import DecoderHandle  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+try:
+    COUNTERS = json.load(open(os.path.join(ROOT, "profiles", "roofline_counters.json")))
+except Exception:
+    COUNTERS = {}
+CUS = torch.cuda.get_device_properties(0).multi_processor_count
 CASES = [  # config, code, decoder alg, channel, param, batch, steps, backend[, precision]
     ("2: n=1200 (3,6) MSA BI-AWGN, fp64 (the reference's arithmetic, bit-identical decisions)", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 1.0, 65536, 6, "auto", "f64"),
     ("2: n=1200 (3,6) MSA BI-AWGN, fp64 (the reference's arithmetic, bit-identical decisions)", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 2.0, 65536, 6, "auto", "f64"),
@@ -57,7 +62,22 @@ for case in CASES:
     c = cnt.cpu().numpy()
     frames, sweeps = int(c[0]), int(c[3])
     bytes_fs = (8 if prec == "f64" else 4) * (4 * g.E + g.n) if alg != "BEC" else (4 * g.E + g.n)
-    rows.append(dict(config=cfg, code=code_name, n=g.n, E=g.E, decoder=alg, precision=prec, channel=ch, param=prm, max_iter=50, frames_per_step=B, steps=steps,
+    # roofline of the dominant kernel: LDS-resident kernels from the committed PMC counters of that very kernel (keyed by its name) x the
+    # frame-sweeps/s measured here; streaming kernels against the HBM peak with the section-8(d) algorithmic bytes of the sweep
+    backend_used = h.last_stats()[0]
+    if backend_used == "fused":
+        kname = h.kernel_name(True)
+        roof = fused_roofline(kname, sweeps / dt, CUS, COUNTERS) or dict(bound="lds", frac=None, note="no committed counters for " + kname)
+        roof = {k: roof.get(k) for k in ("bound", "frac", "lds_frac", "valu_frac", "lds_cycles_per_frame_sweep", "valu_busy_cycles_per_frame_sweep",
+                                        "counters_workload", "counters_from", "note") if roof.get(k) is not None}
+        roof["kernel"] = kname
+        roof["note"] = "whole step (channel + decode + count are this one kernel): busy cycles per frame-sweep (PMC) x frame-sweeps/s of this run / available cycles at 2.4 GHz"
+    else:
+        gbs = sweeps * bytes_fs / dt / 1e9
+        roof = dict(bound="hbm", frac=round(gbs / HBM_PEAK_GBS, 4), achieved_GBps=round(gbs, 1), peak_GBps=HBM_PEAK_GBS, kernel="k_cn + k_vn",
+                    counters_from="HBM bytes per launch of both passes: profiles/roofline_counters.json (hbm:* entries)",
+                    note="whole step incl. channel, tile load, syndrome, repack and counting kernels: executed frame-sweeps x s(4E+n) / wall time / 8 TB/s")
+    rows.append(dict(roofline=roof, config=cfg, code=code_name, n=g.n, E=g.E, decoder=alg, precision=prec, channel=ch, param=prm, max_iter=50, frames_per_step=B, steps=steps,
                      backend=h.last_stats()[0], repacks=h.last_repacks(), waves_per_frame=h.fused_info()["waves_per_frame"] if h.last_stats()[0] == "fused" else 0,
                      frames_per_s=round(frames / dt, 1), ms_per_step=round(1e3 * dt / steps, 3), mean_sweeps=round(sweeps / frames, 3),
                      wer=round(int(c[1]) / frames, 6), ber=int(c[2]) / (frames * g.n),

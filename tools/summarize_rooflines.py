@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/<tag>/ (tools/collect_rooflines.sh) into
+
+    profiles/<tag>_roofline_counters.json   one entry per (case, kernel): counters per frame-sweep, busy fractions, HBM bytes per launch
+    profiles/roofline_counters.json         the copy bench.py and tools/measure_configs.py read (entries keyed by kernel name)
+    profiles/<tag>_roofline_counters.md     the same as a table, with the arithmetic spelled out
+    profiles/<tag>_kernel_stats_<case>.csv  rocprofv3 --kernel-trace --stats of the same command
+
+Units (MI355X_MICROARCH.md): SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT count LDS-array cycles; SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES
+count quad-cycles (x4 = cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs; FETCH_SIZE / WRITE_SIZE are KiB, calibrated here on the
+known 1 GiB -> 1 GiB copy of the same pass (on gfx950 FETCH_SIZE reads half the bytes of a coalesced stream)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+PEAK_CLOCK = 2.4e9
+
+
+def short(name):
+    name = name.replace("ldpc::(anonymous namespace)::", "").replace("ldpc::", "").replace("void ", "")
+    depth = 0
+    for i, ch in enumerate(name):  # cut the argument list: the first '(' outside template brackets
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
+def pmc(d):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def durations(d):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "*kernel_trace.csv")):
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return acc
+
+
+def info_of(case, which):
+    p = os.path.join(src, case, which + ".info.json")
+    return json.load(open(p)) if os.path.exists(p) else None
+
+
+entries, md = {}, ["# Roofline counters `%s` (MI355X; tools/collect_rooflines.sh -> tools/summarize_rooflines.py)\n" % tag]
+for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
+    case = os.path.basename(os.path.dirname(case_dir))
+    stats = glob.glob(os.path.join(case_dir, "stats", "*kernel_stats.csv"))
+    if not stats:
+        continue
+    shutil.copyfile(stats[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, case)))
+    inf = info_of(case, "stats") or {}
+    md.append("\n## %s: %s %s over %s %.3g, %s, batch %d, backend %s (mean %.2f sweeps/frame)\n" % (
+        case, inf.get("code"), inf.get("alg"), inf.get("channel"), inf.get("param", 0), inf.get("precision"), inf.get("batch", 0), inf.get("backend"),
+        inf.get("mean_sweeps", 0)))
+    md.append("`rocprofv3 --kernel-trace --stats`, un-instrumented clock:\n\n| kernel | calls | avg us | % |\n|---|---|---|---|")
+    rows = list(csv.DictReader(open(stats[0])))
+    for r in rows[:6]:
+        md.append("| %s | %s | %.1f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    avg_us = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows}
+    # ---- LDS / VALU counters of the LDS-resident kernel
+    i1 = info_of(case, "sq1")
+    if i1 and i1.get("kernel"):
+        k = i1["kernel"]
+        c1, d1 = pmc(os.path.join(case_dir, "sq1")).get(k, {}), durations(os.path.join(case_dir, "sq1")).get(k, [])
+        c2, d2 = pmc(os.path.join(case_dir, "sq2")).get(k, {}), durations(os.path.join(case_dir, "sq2")).get(k, [])
+        i2 = info_of(case, "sq2") or i1
+        if c1 and d1:
+            fs, cus = float(i1["frame_sweeps"]), i1["cus"]
+            tot = {c: sum(v) for c, v in c1.items()}
+            dur_s = sum(d1) * 1e-9
+            clk = tot["GRBM_GUI_ACTIVE"] / 8.0 / dur_s
+            e = dict(case=case, kernel=k, workload="%s %s over %s %.3g, %s, batch %d, max_iter %d" % (i1["code"], i1["alg"], i1["channel"], i1["param"],
+                                                                                                   i1["precision"], i1["batch"], i1["max_iter"]),
+                     launches=len(d1), frame_sweeps=int(fs), mean_sweeps=round(i1["mean_sweeps"], 3),
+                     lds_idx_active_per_frame_sweep=round(tot["SQ_LDS_IDX_ACTIVE"] / fs, 2),
+                     bank_conflict_per_frame_sweep=round(tot.get("SQ_LDS_BANK_CONFLICT", 0) / fs, 2),
+                     insts_lds_per_frame_sweep=round(tot.get("SQ_INSTS_LDS", 0) / fs, 2),
+                     insts_valu_per_frame_sweep=round(tot.get("SQ_INSTS_VALU", 0) / fs, 2),
+                     valu_active_cycles_per_frame_sweep=round(4.0 * tot.get("SQ_ACTIVE_INST_VALU", 0) / fs, 2),
+                     wave_cycles_per_frame_sweep=round(4.0 * tot.get("SQ_WAVE_CYCLES", 0) / fs, 1),
+                     kernel_ms_per_launch_in_pmc_pass=round(1e3 * dur_s / len(d1), 4),
+                     kernel_ms_per_launch_unprofiled=round(avg_us.get(k, 0) / 1e3, 4),
+                     effective_clock_hz_in_pmc_pass=round(clk), cus=cus,
+                     lds_busy_frac_in_pmc_pass=round(tot["SQ_LDS_IDX_ACTIVE"] / (dur_s * clk * cus), 4),
+                     valu_busy_frac_in_pmc_pass=round(4.0 * tot.get("SQ_ACTIVE_INST_VALU", 0) / (dur_s * clk * cus * 4), 4),
+                     counters_from="profiles/%s_roofline_counters.json:%s (rocprofv3 --pmc, tools/sim_driver.py: the simulate kernel itself)" % (tag, case))
+            if c2 and d2:
+                fs2 = float(i2["frame_sweeps"])
+                t2 = {c: sum(v) for c, v in c2.items()}
+                wc = t2.get("SQ_WAIT_ANY", 0) + t2.get("SQ_WAIT_INST_ANY", 0) + t2.get("SQ_ACTIVE_INST_ANY", 0)
+                e.update(wait_any_share=round(t2.get("SQ_WAIT_ANY", 0) / wc, 4) if wc else None,
+                         wait_inst_any_share=round(t2.get("SQ_WAIT_INST_ANY", 0) / wc, 4) if wc else None,
+                         active_inst_any_share=round(t2.get("SQ_ACTIVE_INST_ANY", 0) / wc, 4) if wc else None,
+                         insts_salu_per_frame_sweep=round(t2.get("SQ_INSTS_SALU", 0) / fs2, 2),
+                         lds_active_inst_cycles_per_frame_sweep=round(4.0 * t2.get("SQ_ACTIVE_INST_LDS", 0) / fs2, 2))
+            entries.setdefault(k, e)
+            entries["%s:%s" % (case, k)] = e
+            # what the un-instrumented launch makes of it: busy LDS-array cycles / (CUs x 2.4 GHz)
+            if e["kernel_ms_per_launch_unprofiled"]:
+                fsps = (fs / len(d1)) / (e["kernel_ms_per_launch_unprofiled"] * 1e-3)
+                e["lds_frac_at_peak_clock_unprofiled"] = round(fsps * e["lds_idx_active_per_frame_sweep"] / (cus * PEAK_CLOCK), 4)
+                e["valu_frac_at_peak_clock_unprofiled"] = round(fsps * e["valu_active_cycles_per_frame_sweep"] / (cus * 4 * PEAK_CLOCK), 4)
+                e["frame_sweeps_per_s_unprofiled"] = round(fsps, 1)
+            md.append("\n`%s`: %d launches, %.4g frame-sweeps.  Per frame-sweep: **%.1f LDS-array cycles** (SQ_LDS_IDX_ACTIVE; %.1f of them bank "
+                      "conflicts), %.1f DS + %.1f VALU instructions, %.1f VALU-busy cycles.  In the PMC pass (%.3f ms/launch, %.3f GHz effective): LDS "
+                      "array %.3f busy, VALU %.3f busy; un-instrumented launch %.3f ms => **LDS %.3f, VALU %.3f of peak at 2.4 GHz**." % (
+                          k, len(d1), fs, e["lds_idx_active_per_frame_sweep"], e["bank_conflict_per_frame_sweep"], e["insts_lds_per_frame_sweep"],
+                          e["insts_valu_per_frame_sweep"], e["valu_active_cycles_per_frame_sweep"], e["kernel_ms_per_launch_in_pmc_pass"], clk / 1e9,
+                          e["lds_busy_frac_in_pmc_pass"], e["valu_busy_frac_in_pmc_pass"], e["kernel_ms_per_launch_unprofiled"],
+                          e.get("lds_frac_at_peak_clock_unprofiled", 0), e.get("valu_frac_at_peak_clock_unprofiled", 0)))
+            if "wait_any_share" in e:
+                md.append("Wave time: %.0f %% waiting (s_waitcnt / barrier), %.0f %% issue stalls, %.0f %% issuing." % (
+                    100 * (e["wait_any_share"] or 0), 100 * (e["wait_inst_any_share"] or 0), 100 * (e["active_inst_any_share"] or 0)))
+    # ---- HBM bytes per launch of every kernel of the case
+    fs_, ws_ = pmc(os.path.join(case_dir, "FETCH_SIZE")), pmc(os.path.join(case_dir, "WRITE_SIZE"))
+    if fs_ and ws_:
+        gib = float(1 << 30)
+        cal_f = (fs_.get("k_copy4", {}).get("FETCH_SIZE") or [0])[-1]
+        cal_w = (ws_.get("k_copy4", {}).get("WRITE_SIZE") or [0])[-1]
+        kf = gib / (cal_f * 1024) if cal_f else 2.0
+        kw = gib / (cal_w * 1024) if cal_w else 1.0
+        md.append("\nHBM traffic (separate --pmc passes; calibration copy of 1 GiB: FETCH_SIZE %.0f KiB => x%.3f, WRITE_SIZE %.0f KiB => x%.3f):\n" % (cal_f, kf, cal_w, kw))
+        md.append("| kernel | launches | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM bytes/launch | algorithmic bytes/launch | traffic / algorithmic |\n|---|---|---|---|---|---|---|")
+        ih = info_of(case, "FETCH_SIZE") or inf
+        s = 8 if ih.get("precision") == "f64" else 4
+        E, n = ih.get("E", 0), ih.get("n", 0)
+        sweeps = None
+        for k in sorted(fs_):
+            if not k.startswith("k_") or k.startswith("k_copy4"):
+                continue
+            f_, w_ = fs_[k]["FETCH_SIZE"], ws_.get(k, {}).get("WRITE_SIZE", [0])
+            fa, wa = sum(f_) / len(f_), sum(w_) / max(len(w_), 1)
+            tot_b = fa * 1024 * kf + wa * 1024 * kw
+            alg = None
+            if k.startswith("k_cn<") or k.startswith("k_vn<"):
+                # frames live in a launch vary with early termination: use launches at full batch only when no frame leaves (1.0 dB cases)
+                frames = ih.get("batch", 0)
+                alg = frames * s * ((2 * E + n) if k.startswith("k_cn<") else (E + 2 * n))
+            ent = dict(case=case, kernel=k, launches=len(f_), fetch_kib_per_launch=round(fa, 1), write_kib_per_launch=round(wa, 1),
+                       hbm_bytes_per_launch=int(tot_b), calibration=dict(fetch=round(kf, 4), write=round(kw, 4)),
+                       compulsory_bytes_per_launch=alg, traffic_over_compulsory=round(tot_b / alg, 4) if alg else None,
+                       workload="%s %s %s batch %d" % (ih.get("code"), ih.get("alg"), ih.get("precision"), ih.get("batch", 0)))
+            entries["hbm:%s:%s" % (case, k)] = ent
+            md.append("| %s | %d | %.0f | %.0f | %.4g | %s | %s |" % (k, len(f_), fa, wa, tot_b, ("%.4g" % alg) if alg else "-", ("%.3f" % (tot_b / alg)) if alg else "-"))
+        md.append("\n(check / variable pass: compulsory bytes = batch x s x (2E + n) / batch x s x (E + 2n) -- c2v in + out + each marginal once; "
+                  "c2v in + prior in + marginal out -- valid where no frame leaves early; the section-8(d) model prices the pair at s(4E + n).)")
+
+os.makedirs(dst, exist_ok=True)
+json.dump(entries, open(os.path.join(dst, "%s_roofline_counters.json" % tag), "w"), indent=1)
+json.dump(entries, open(os.path.join(dst, "roofline_counters.json"), "w"), indent=1)
+open(os.path.join(dst, "%s_roofline_counters.md" % tag), "w").write("\n".join(md) + "\n")
+print("\n".join(md)[:8000])
