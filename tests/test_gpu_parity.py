@@ -79,18 +79,21 @@ def test_bec_exact_vs_reference(path):
     assert (one == expected_xhat(c)[0]).all()
 
 
+# Frames that MAY differ from the reference in fp64 sum-product, by (case id, backend): device libm differs from numpy's by ulps, which
+# can flip a chaotic non-converging frame.  MEASURED (every golden case x both backends, profiles/r03_spa_agreement.txt): no frame
+# differs anywhere, so the list is empty and the test demands identity; a kernel change that flips a frame must name it here.
+SPA_F64_ALLOWED_FLIPS = {}
+
+
 @pytest.mark.parametrize("backend", ["stream", "auto"])
-@pytest.mark.parametrize("path", decode_cases("*_SPA_*"), ids=case_id)
+@pytest.mark.parametrize("path", [p for p in decode_cases("*_SPA_*") if "bec_" not in os.path.basename(p)], ids=case_id)
 def test_spa_fp64_vs_reference(path, backend):
-    # fp64 SPA follows the reference formula verbatim; device libm differs from numpy's by ulps, which can flip a
-    # chaotic non-converging frame -> frames that CONVERGE upstream must agree exactly, overall agreement >= 90 %.
-    # Both backends (the LDS kernel runs the streaming kernel's own device function).  The MEASURED agreement of every case is printed
-    # (pytest -s; profiles/r02_spa_agreement.txt keeps the lines of the round).
+    # fp64 SPA follows the reference formula; held to what is measured: every frame's decisions identical to the reference (allow-list
+    # above), iteration counts of the frames that converge upstream identical too.  Both backends.  The measured agreement of every
+    # case is printed (pytest -s; profiles/r03_spa_agreement.txt keeps the lines of the round).
     from ldpc_decoders_amd import bpa
 
     c = load_case(path)
-    if c["channel"] == "bec":
-        pytest.skip("erasure decoder covered by test_bec_exact_vs_reference")
     g, code = _code(c["code"])
     dec = bpa.SPA(code, max_iter=c["max_iter"], precision="f64", backend=backend)
     y0 = None if c["channel"] == "biawgn" else c["y"]
@@ -99,14 +102,15 @@ def test_spa_fp64_vs_reference(path, backend):
     keep = np.setdiff1d(np.arange(c["nframes"]), c["raw_rows"])
     same = (xhat[keep] == want[keep]).all(axis=1)
     conv = c["iters"][keep] < c["max_iter"]
-    it_ok = np.abs(iters[keep][conv] - c["iters"][keep][conv]) <= 1
+    it_same = iters[keep][conv] == c["iters"][keep][conv]
     print("fp64 sum-product vs reference, %s backend=%s(%s): frames identical %d/%d (%.1f %%), of the %d converging upstream %d (%.1f %%), "
-          "iteration counts within 1 on %.1f %% of those" % (case_id(path), backend, dec.handle.last_stats()[0], same.sum(), len(same), 100 * same.mean(),
-                                                              conv.sum(), same[conv].sum(), 100 * same[conv].mean() if conv.any() else 100.0,
-                                                              100 * it_ok.mean() if conv.any() else 100.0))
-    assert same.mean() >= 0.9
-    assert same[conv].mean() >= 0.97
-    assert it_ok.mean() >= 0.97
+          "iteration counts identical on %.1f %% of those" % (case_id(path), backend, dec.handle.last_stats()[0], same.sum(), len(same), 100 * same.mean(),
+                                                               conv.sum(), same[conv].sum(), 100 * same[conv].mean() if conv.any() else 100.0,
+                                                               100 * it_same.mean() if conv.any() else 100.0))
+    allowed = SPA_F64_ALLOWED_FLIPS.get((case_id(path), backend), set())
+    differing = set(int(f) for f in keep[~same])
+    assert differing <= allowed, "frames %s differ from the reference (allowed: %s)" % (sorted(differing - allowed), sorted(allowed))
+    assert it_same.all() or differing, "iteration counts of converging frames differ: %s" % np.flatnonzero(~it_same)
 
 
 SPA_TRACE_CASES = [p for p in decode_cases("*_SPA_*") if "bec_" not in p]
@@ -121,8 +125,21 @@ SOFT_MODES = [("SPA", "f64", "stream", 1e-9), ("SPA", "f64", "fused", 1e-9), ("S
               ("MSA", "f64", "stream", 0.0), ("MSA", "f64", "fused", 0.0), ("MSA", "f32", "stream", 1e-5), ("MSA", "f32", "fused", 1e-5)]
 
 
-@pytest.mark.parametrize("alg,prec,backend,rtol", SOFT_MODES, ids=lambda v: str(v))
-@pytest.mark.parametrize("path", SPA_TRACE_CASES + MSA_TRACE_CASES, ids=case_id)
+def _soft_cases():
+    """(case, mode) pairs that exist: the trace was recorded for the case's own check rule; toy codes have no LDS-resident shape."""
+    out = []
+    for path in SPA_TRACE_CASES + MSA_TRACE_CASES:
+        c = load_case(path)
+        if c["sumcols_trace"].shape[0] == 0:
+            continue
+        for alg, prec, backend, rtol in SOFT_MODES:
+            if c["decoder"] != alg or (backend == "fused" and not any(k in c["code"] for k in FUSED_CODES)):
+                continue
+            out.append(pytest.param(path, alg, prec, backend, rtol, id="%s-%s-%s-%s" % (case_id(path), alg, prec, backend)))
+    return out
+
+
+@pytest.mark.parametrize("path,alg,prec,backend,rtol", _soft_cases())
 def test_soft_llr_tolerance(path, alg, prec, backend, rtol):
     # marginal LLRs after 1..3 sweeps against the reference's recorded sum_cols outputs (src/bpa.py:35), through
     # ldpc_decode_soft on the streaming AND the fused (LDS-resident) kernels.
@@ -130,13 +147,7 @@ def test_soft_llr_tolerance(path, alg, prec, backend, rtol):
     from ldpc_decoders_amd import bpa
 
     c = load_case(path)
-    if c["decoder"] != alg:
-        pytest.skip("trace recorded for the other check rule")
-    if backend == "fused" and not any(k in c["code"] for k in FUSED_CODES):
-        pytest.skip("no LDS-resident shape for this toy code (streaming backend covers it)")
     tr = c["sumcols_trace"]
-    if tr.shape[0] == 0:
-        pytest.skip("no trace")
     g, code = _code(c["code"])
     pri = _priors(c)[: tr.shape[0]]
     dt = np.float64 if prec == "f64" else np.float32
@@ -181,11 +192,15 @@ def test_soft_output_with_early_exit_matches_between_backends():
     assert len(np.unique(outs[0][1])) > 5
 
 
+SPA_F32_ALLOWED_FLIPS = {}  # case id -> frames whose fp32 decisions may differ from the fp64 phi statement (measured: none)
+
+
 @pytest.mark.parametrize("path", [p for p in decode_cases("*_SPA_*") if "1200" in p and "bec_" not in p], ids=case_id)
 def test_spa_fp32_decisions(path):
     # fp32 SPA implements the phi-domain statement of the check rule (oracle: bp_oracle.spa_phi_check_update, itself
     # tied to the reference below saturation by tests/test_oracle_golden.py::test_phi_rule_*):
-    #   - against that fp64 statement: >= 95 % of frames identical in decisions (fp32 rounding can flip chaotic frames)
+    #   - against that fp64 statement: decisions identical on every frame (measured; fp32 rounding COULD flip a chaotic frame -- such a
+    #     frame would have to be named in SPA_F32_ALLOWED_FLIPS)
     #   - against the reference: identical on frames whose messages stay below |LLR| = 30 upstream
     from ldpc_decoders_amd import bpa
 
@@ -203,10 +218,13 @@ def test_spa_fp32_decisions(path):
     calm_same = (xhat[calm] == want[calm]).all(axis=1) if len(calm) else np.ones(1, dtype=bool)
     print("fp32 sum-product, %s backend=%s: frames identical to the fp64 phi statement %d/%d (%.1f %%); to the reference on the %d frames below |LLR| 30: %.1f %%"
           % (case_id(path), dec.handle.last_stats()[0], same.sum(), len(same), 100 * same.mean(), len(calm), 100 * calm_same.mean()))
-    assert same.mean() >= 0.95
-    assert (np.abs(iters - io) <= 1)[io < c["max_iter"]].mean() >= 0.9
+    # held to what is measured (profiles/r03_spa_agreement.txt): every frame identical to the fp64 phi statement, every calm frame
+    # identical to the reference; frames allowed to differ are named here
+    allowed = SPA_F32_ALLOWED_FLIPS.get(case_id(path), set())
+    assert set(int(f) for f in np.flatnonzero(~same)) <= allowed
+    assert (np.abs(iters - io) <= 1)[io < c["max_iter"]].all()
     if len(calm):
-        assert calm_same.mean() >= 0.97
+        assert calm_same.all()
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

@@ -14,6 +14,13 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SQ1="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS GRBM_GUI_ACTIVE"
 SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES GRBM_GUI_ACTIVE"
+# VALU instruction mix (issue-cycle model of the VALU-bound kernels): only the counters this rocprofv3 knows
+SQ3=""
+LIST=$(rocprofv3 -L 2>/dev/null)
+for C3 in SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT; do
+  if echo "$LIST" | grep -q "Counter_Name *:.*\b$C3\b"; then SQ3="$SQ3 $C3"; fi
+done
+echo "VALU mix counters:$SQ3"
 # name | sim_driver arguments | passes
 CASES=(
  "c2_f64|--code 1200_3_6_rand_ldpc_1 --alg MSA --channel biawgn --param 1.0 --batch 65536 --precision f64 --launches 3|sq hbm"
@@ -32,10 +39,14 @@ for C in "${CASES[@]}"; do
   NAME=${C%%|*}; REST=${C#*|}; ARGS=${REST%%|*}; PASSES=${REST#*|}
   if [ $# -gt 0 ] && [[ ! " $* " =~ " $NAME " ]]; then continue; fi
   echo "== $NAME"
+  mkdir -p $OUT/$NAME
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$NAME/stats -o k -- python3 $R/tools/sim_driver.py $ARGS --info $OUT/$NAME/stats.info.json > $OUT/$NAME.stats.log 2>&1
   if [[ $PASSES == *sq* ]]; then
     rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $OUT/$NAME/sq1 -o p -- python3 $R/tools/sim_driver.py $ARGS --info $OUT/$NAME/sq1.info.json > $OUT/$NAME.sq1.log 2>&1
     rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $OUT/$NAME/sq2 -o p -- python3 $R/tools/sim_driver.py $ARGS --info $OUT/$NAME/sq2.info.json > $OUT/$NAME.sq2.log 2>&1
+    if [ -n "$SQ3" ]; then
+      rocprofv3 --pmc $SQ3 --kernel-trace --output-format csv -d $OUT/$NAME/sq3 -o p -- python3 $R/tools/sim_driver.py $ARGS --info $OUT/$NAME/sq3.info.json > $OUT/$NAME.sq3.log 2>&1
+    fi
   fi
   if [[ $PASSES == *hbm* ]]; then
     for CNT in FETCH_SIZE WRITE_SIZE; do

@@ -7,7 +7,7 @@
     profiles/<tag>_kernel_stats_<case>.csv  rocprofv3 --kernel-trace --stats of the same command
 
 Units (MI355X_MICROARCH.md): SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT count LDS-array cycles; SQ_ACTIVE_INST_* / SQ_WAIT_* / SQ_WAVE_CYCLES
-count quad-cycles (x4 = cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs; FETCH_SIZE / WRITE_SIZE are KiB, calibrated here on the
+count quad-cycles (x4 = cycles) -- except that SQ_ACTIVE_INST_VALU equals the instruction count here; GRBM_GUI_ACTIVE is summed over the 8 XCDs; FETCH_SIZE / WRITE_SIZE are KiB, calibrated here on the
 known 1 GiB -> 1 GiB copy of the same pass (on gfx950 FETCH_SIZE reads half the bytes of a coalesced stream)."""
 import collections
 import csv
@@ -90,13 +90,12 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
                      bank_conflict_per_frame_sweep=round(tot.get("SQ_LDS_BANK_CONFLICT", 0) / fs, 2),
                      insts_lds_per_frame_sweep=round(tot.get("SQ_INSTS_LDS", 0) / fs, 2),
                      insts_valu_per_frame_sweep=round(tot.get("SQ_INSTS_VALU", 0) / fs, 2),
-                     valu_active_cycles_per_frame_sweep=round(4.0 * tot.get("SQ_ACTIVE_INST_VALU", 0) / fs, 2),
+                     sq_active_inst_valu_per_frame_sweep=round(tot.get("SQ_ACTIVE_INST_VALU", 0) / fs, 2),
                      wave_cycles_per_frame_sweep=round(4.0 * tot.get("SQ_WAVE_CYCLES", 0) / fs, 1),
                      kernel_ms_per_launch_in_pmc_pass=round(1e3 * dur_s / len(d1), 4),
                      kernel_ms_per_launch_unprofiled=round(avg_us.get(k, 0) / 1e3, 4),
                      effective_clock_hz_in_pmc_pass=round(clk), cus=cus,
                      lds_busy_frac_in_pmc_pass=round(tot["SQ_LDS_IDX_ACTIVE"] / (dur_s * clk * cus), 4),
-                     valu_busy_frac_in_pmc_pass=round(4.0 * tot.get("SQ_ACTIVE_INST_VALU", 0) / (dur_s * clk * cus * 4), 4),
                      counters_from="profiles/%s_roofline_counters.json:%s (rocprofv3 --pmc, tools/sim_driver.py: the simulate kernel itself)" % (tag, case))
             if c2 and d2:
                 fs2 = float(i2["frame_sweeps"])
@@ -107,6 +106,24 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
                          active_inst_any_share=round(t2.get("SQ_ACTIVE_INST_ANY", 0) / wc, 4) if wc else None,
                          insts_salu_per_frame_sweep=round(t2.get("SQ_INSTS_SALU", 0) / fs2, 2),
                          lds_active_inst_cycles_per_frame_sweep=round(4.0 * t2.get("SQ_ACTIVE_INST_LDS", 0) / fs2, 2))
+            # VALU issue cycles.  SQ_ACTIVE_INST_VALU turns out to count one unit per instruction on gfx950 (== SQ_INSTS_VALU), so it is no
+            # busy-cycle measure; the fraction below is an ISSUE MODEL on measured instruction counts: 2 cycles per wave64 instruction
+            # (v_fma_f32: 2 cycles on a SIMD-32, MI355X_MICROARCH.md), 4 for fp64 add / mul / fma (half rate: 78.6 vs 157.3 TFLOP/s), 8 for
+            # transcendentals (quarter rate) -- instruction-mix counters from the sq3 pass where this rocprofv3 has them
+            c3 = pmc(os.path.join(case_dir, "sq3")).get(k, {})
+            i3 = info_of(case, "sq3") or i1
+            mix = {}
+            if c3:
+                fs3 = float(i3["frame_sweeps"])
+                mix = {c: sum(v) / fs3 for c, v in c3.items()}
+            n_all = mix.get("SQ_INSTS_VALU", e["insts_valu_per_frame_sweep"])
+            n_f64 = sum(mix.get(c, 0.0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+            n_tr = mix.get("SQ_INSTS_VALU_TRANS_F32", 0.0) + mix.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+            e["valu_mix_per_frame_sweep"] = {c: round(v, 2) for c, v in mix.items()} or None
+            e["valu_issue_cycles_per_frame_sweep"] = round(2.0 * (n_all - n_f64 - n_tr) + 4.0 * n_f64 + 8.0 * n_tr, 1)
+            e["valu_issue_model"] = "2 cycles per wave64 VALU instruction, 4 per fp64 add/mul/fma, 8 per transcendental; counts: SQ_INSTS_VALU*"
+            e["valu_active_cycles_per_frame_sweep"] = e["valu_issue_cycles_per_frame_sweep"]  # the name bench.py reads
+            e["valu_busy_frac_in_pmc_pass"] = round(e["valu_issue_cycles_per_frame_sweep"] * fs / (dur_s * clk * cus * 4), 4)
             entries.setdefault(k, e)
             entries["%s:%s" % (case, k)] = e
             # what the un-instrumented launch makes of it: busy LDS-array cycles / (CUs x 2.4 GHz)
