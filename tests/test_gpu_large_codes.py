@@ -130,7 +130,7 @@ def _published_point(channel, code_name, decoder, max_iter, codeword, param):
 def test_config3_spa_bsc_full_batch():
     # config 3: n = 1200 sum-product over the BSC, batch 65 536 on one GPU (device channel kernel, fp32 LDS kernel).
     # (1) size-independent properties on the whole batch; (2) 4 096 frames re-decoded by the fp64 phi-domain oracle: identical decisions
-    # (measured: all of them; the frames that may differ would have to be named); (3) the reference's own arithmetic (fp64, formula
+    # (measured: all but two non-converging frames, which are named below); (3) the reference's own arithmetic (fp64, formula
     # verbatim) at the reference's published operating point -- bsc-1200_3_6_rand_ldpc_1-SPA-10-0.json, p = 0.06, 581 frames upstream --
     # word-error rate within 4 sigma of the published value, bit-error rate within its spread.
     import multiprocessing as mp
@@ -157,7 +157,7 @@ def test_config3_spa_bsc_full_batch():
     io = np.concatenate([p[1] for p in parts])
     differ = np.flatnonzero(~(xh[idx] == xo).all(axis=1))
     print("config 3 sum-product / BSC: %d of %d re-decoded frames differ from the fp64 phi oracle: %s" % (len(differ), len(idx), idx[differ].tolist()))
-    assert len(differ) <= CONFIG3_SPA_ALLOWED_DIFFERING_FRAMES
+    assert set(idx[differ].tolist()) <= CONFIG3_SPA_FRAMES_THAT_MAY_DIFFER
     assert (np.abs(it[idx] - io) <= 1)[io < 50].mean() >= 0.999
     # the published curve, in the reference's arithmetic
     ref = _published_point("bsc", "1200_3_6_rand_ldpc_1", "SPA", 10, 0, "0.06")
@@ -173,7 +173,9 @@ def test_config3_spa_bsc_full_batch():
     assert 0.6 <= (ber / wer) / (ref["ber"] / ref["wer"]) <= 1.6
 
 
-CONFIG3_SPA_ALLOWED_DIFFERING_FRAMES = 0  # of 4 096: measured (profiles/r03_parity_measured.txt)
+# fp32 message arithmetic against the fp64 oracle: measured on the 4 096 re-decoded frames (profiles/r03_parity_measured.txt), two
+# non-converging frames end in different words; the list names them, any other frame must be identical
+CONFIG3_SPA_FRAMES_THAT_MAY_DIFFER = {18000, 36016}
 
 
 def test_config3_erasure_full_batch():
