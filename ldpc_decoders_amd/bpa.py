@@ -37,6 +37,8 @@ class BPA:
         real-valued BI-AWGN observation it passes only if every check sum is an even integer, which requires an
         integer-valued y -- handled here on the host only in that (measure-zero) case."""
         y = np.asarray(y)
+        if y.dtype.kind == "f" and y.size and y.flat[0] != np.floor(y.flat[0]):
+            return None, None  # a real-valued observation (every BI-AWGN frame): decided on the first entry, not on a pass over the frame
         if y.dtype.kind in "biu" or np.all(y == np.floor(y)):
             yi = np.asarray(y, dtype=np.int64)
             if ((yi == 0) | (yi == 1)).all():

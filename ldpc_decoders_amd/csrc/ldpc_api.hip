@@ -241,6 +241,9 @@ int ldpc_decoder_destroy(ldpc_decoder_t h) {
                       &d->h_iters})
         b->release();
     if (d->pinned) (void)hipHostFree(d->pinned);
+    if (d->lat_pin) (void)hipHostFree(d->lat_pin);
+    if (d->lat_event) (void)hipEventDestroy(d->lat_event);
+    if (d->lat_stream) (void)hipStreamDestroy(d->lat_stream);
     for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
     delete d;
     return LDPC_OK;
@@ -348,11 +351,47 @@ int ldpc_decode_host(ldpc_decoder_t h, const void* priors, const uint8_t* y0, in
     const size_t n = (size_t)d->code->n, esz = d->dtype == DT_F64 ? 8 : 4;
     void* dp = nullptr;
     uint8_t* dy = nullptr;
-    if (d->alg != ALG_BEC) {
-        if (!priors) {
-            set_error("ldpc_decode_host: priors is null");
-            return LDPC_E_ARG;
+    if (d->alg != ALG_BEC && !priors) {
+        set_error("ldpc_decode_host: priors is null");
+        return LDPC_E_ARG;
+    }
+    if (d->alg == ALG_BEC && !y0) {
+        set_error("erasure decoder needs the received symbols (y0)");
+        return LDPC_E_ARG;
+    }
+    // A few frames on the LDS-resident kernels: ONE kernel launch and one event wait.  The kernel reads the priors from, and writes
+    // the decisions to, page-locked host memory mapped into the device (a frame is 5-10 KB: a few microseconds over PCIe, less than
+    // starting a copy engine twice); no allocation, no memset in front of the launch, no device-wide synchronisation.
+    const size_t in_bytes = (size_t)B * n * esz, y_bytes = (size_t)B * n;
+    if (B <= 64 && in_bytes <= ((size_t)256 << 10) && pick_backend(d) == BK_FUSED && !d->profile) {
+        const size_t off_y = (in_bytes + 255) & ~(size_t)255, off_out = off_y + ((y_bytes + 255) & ~(size_t)255);
+        const size_t off_it = off_out + ((y_bytes + 255) & ~(size_t)255), need = off_it + 64 * sizeof(int32_t);
+        if (d->lat_bytes < need) {
+            if (d->lat_pin) (void)hipHostFree(d->lat_pin);
+            d->lat_pin = nullptr;
+            d->lat_bytes = 0;
+            LDPC_HIP_TRY(hipHostMalloc(&d->lat_pin, need, hipHostMallocMapped));
+            d->lat_bytes = need;
         }
+        if (!d->lat_stream) LDPC_HIP_TRY(hipStreamCreateWithFlags(&d->lat_stream, hipStreamNonBlocking));
+        if (!d->lat_event) LDPC_HIP_TRY(hipEventCreateWithFlags(&d->lat_event, hipEventDisableTiming));
+        char* hp = (char*)d->lat_pin;
+        void* devp = nullptr;
+        LDPC_HIP_TRY(hipHostGetDevicePointer(&devp, d->lat_pin, 0));
+        char* gp = (char*)devp;
+        if (d->alg != ALG_BEC) memcpy(hp, priors, in_bytes);
+        if (y0) memcpy(hp + off_y, y0, y_bytes);
+        d->after_kernel_event = d->lat_event;
+        const int rc = fused_decode(d, d->alg == ALG_BEC ? nullptr : gp, y0 ? (const uint8_t*)(gp + off_y) : nullptr, B, max_iter, flags,
+                                    (uint8_t*)(gp + off_out), (int32_t*)(gp + off_it), nullptr, d->lat_stream);
+        d->after_kernel_event = nullptr;
+        if (rc) return rc;
+        LDPC_HIP_TRY(hipEventSynchronize(d->lat_event));
+        memcpy(xhat, hp + off_out, y_bytes);
+        memcpy(iters, hp + off_it, (size_t)B * sizeof(int32_t));
+        return LDPC_OK;
+    }
+    if (d->alg != ALG_BEC) {
         LDPC_TRY(d->h_in.reserve((size_t)B * n * esz));
         dp = d->h_in.p;
         LDPC_HIP_TRY(hipMemcpyAsync(dp, priors, (size_t)B * n * esz, hipMemcpyHostToDevice, nullptr));

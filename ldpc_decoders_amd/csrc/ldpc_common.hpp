@@ -91,6 +91,14 @@ struct Decoder {
     // staging used by the *_host entry points
     DevBuf h_in, h_y0, h_out, h_iters;
     void* pinned = nullptr;  // small page-locked host block (polling word, counters)
+    // low-latency host path (ldpc_decode_host, a few frames per call -- the reference's one-frame-per-call loop, src/main.py:37-48):
+    // page-locked, device-mapped staging the decode kernel reads priors from and writes decisions to DIRECTLY (no copy engine in the
+    // path), a private stream and one event recorded right behind the kernel
+    void* lat_pin = nullptr;
+    size_t lat_bytes = 0;
+    hipStream_t lat_stream = nullptr;
+    hipEvent_t lat_event = nullptr;
+    hipEvent_t after_kernel_event = nullptr;  // set for the duration of a low-latency call
     // optional per-kernel timing with HIP events recorded on the decode stream (bench.py roofline leg)
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;

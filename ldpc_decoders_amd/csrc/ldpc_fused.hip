@@ -27,7 +27,11 @@ struct FusedPlan {
     int32_t* d_var_of_slot = nullptr;  // [VR*64] variable index of a slot, -1 for padding
     int32_t* d_slot_of_var = nullptr;  // [n rounded up to 4] slot (LDS dword index) of a variable
     unsigned long long* d_cn_active = nullptr;  // [CR] lanes holding a real check in round R
-    unsigned long long* d_next = nullptr;       // frame dispenser
+    unsigned long long* d_next = nullptr;       // frame dispenser: TWO sets of 8 counters (64 B apart); a launch uses one while the other is
+                                                // zeroed behind it on the same stream, so no memset sits in front of the next launch
+    int next_sel = 0;                           // set the next launch uses
+    bool next_clean = false;                    // set `next_sel` was zeroed by a memset enqueued on `next_stream` behind the last launch
+    hipStream_t next_stream = nullptr;
     int sync_off[4] = {0, 0, 0, 0};    // NW > 1: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
     int msync_off[4] = {0, 0, 0, 0};   // NW > 1: byte offset of a padded marginal slot owned by wave w (end-of-sweep hand-off)
     int zero_row = 0;                  // 1: the c2v area ends with an always-zero row
@@ -434,7 +438,7 @@ int fused_plan_create(Decoder* d) {
         LDPC_TRY(upload_vec(sov, &p->d_slot_of_var));
     }
     LDPC_TRY(upload_vec(cn_active, &p->d_cn_active));
-    LDPC_HIP_TRY(hipMalloc((void**)&p->d_next, 8 * 64));  // 8 frame counters, one cache line apart
+    LDPC_HIP_TRY(hipMalloc((void**)&p->d_next, 2 * 8 * 64));  // 2 x 8 frame counters, one cache line apart
     hipDeviceProp_t prop;
     LDPC_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     p->num_cu = prop.multiProcessorCount;
@@ -467,7 +471,8 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
     }
     const ShapeEntry& shape = all_shapes()[p->shape];
     const Code* c = d->code;
-    LDPC_HIP_TRY(hipMemsetAsync(p->d_next, 0, 8 * 64, st));
+    unsigned long long* next_set = p->d_next + (size_t)p->next_sel * 64;
+    if (!(p->next_clean && p->next_stream == st)) LDPC_HIP_TRY(hipMemsetAsync(next_set, 0, 8 * 64, st));
     long long groups = (long long)p->num_cu * p->groups_per_cu;
     if (groups > B) groups = B;
     a.B = B;
@@ -479,7 +484,7 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
     a.var_of_slot = p->d_var_of_slot;
     a.slot_of_var = p->d_slot_of_var;
     a.cn_active = p->d_cn_active;
-    a.next_frame = p->d_next;
+    a.next_frame = next_set;
     for (int i = 0; i < 4; ++i) {
         a.sync_off[i] = p->sync_off[i];
         a.msync_off[i] = p->msync_off[i];
@@ -500,6 +505,11 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
         LDPC_HIP_TRY(hipEventRecord(e0, st));
     }
     LDPC_HIP_TRY(hipLaunchKernel(sim ? shape.kernel_sim : shape.kernel, dim3((unsigned)groups), dim3(64 * shape.NW), args, p->lds_bytes, st));
+    if (d->after_kernel_event) LDPC_HIP_TRY(hipEventRecord(d->after_kernel_event, st));  // low-latency host path: wait for the kernel only
+    // the other counter set for the next launch, zeroed behind this kernel (off the critical path of both launches)
+    p->next_sel ^= 1;
+    p->next_clean = hipMemsetAsync(p->d_next + (size_t)p->next_sel * 64, 0, 8 * 64, st) == hipSuccess;
+    p->next_stream = st;
     if (d->profile) {
         LDPC_HIP_TRY(hipEventRecord(e1, st));
         LDPC_HIP_TRY(hipStreamSynchronize(st));

@@ -122,7 +122,7 @@ def _published_point(channel, code_name, decoder, max_iter, codeword, param):
 
     with open(os.path.join(GOLDEN, "published_curves.json")) as fp:
         for e in json.load(fp):
-            if (e["channel"], e["code"], e["decoder"], str(e["max_iter"]), str(e["codeword"])) == (channel, code_name, decoder, str(max_iter), str(codeword)):
+            if (e["channel"], e["code"], e["decoder"], str(e.get("max_iter")), str(e.get("codeword"))) == (channel, code_name, decoder, str(max_iter), str(codeword)):
                 return e["points"][param]
     raise KeyError((channel, code_name, decoder, max_iter, codeword, param))
 

@@ -339,3 +339,19 @@ def test_simulate_kernels_do_not_spill():
         assert r["spill"] == 0 and r["scratch"] == 0, "%s: %d spilled VGPRs, %d B of scratch per lane" % (name, r["spill"], r["scratch"])
         if name.startswith("k_fused_bp") and (", 2, true" in name or ", 16, true" in name):
             assert r["vgpr"] <= 128  # four waves per SIMD: the occupancy the fp32 multi-wave shapes are built for
+
+
+def test_compiler_never_touches_m0_in_the_fused_kernels():
+    """The fused kernels set M0 with inline asm for their ds_write_addtid_b32 row stores (csrc/ldpc_fused_kernels.hpp: lds_set_m0 /
+    lds_st_tid); the compiler does not know.  Sound only while the compiler has no M0 use of its own in those kernels -- checked on the
+    disassembly of the BUILT library: every M0 reference is one of ours, and nothing that consumes M0 implicitly (movrel, sendmsg,
+    LDS-DMA, GWS) was generated.  A compiler upgrade that breaks the assumption fails here instead of corrupting LDS rows."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+
+    stores, foreign, consumers = kernel_resources.m0_report()
+    assert stores > 1000, "ds_write_addtid_b32 stores not found in the library"
+    assert not foreign, "M0 used outside lds_set_m0: %s" % foreign[:5]
+    assert not consumers, "instructions that read M0 implicitly: %s" % consumers[:5]

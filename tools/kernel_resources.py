@@ -69,6 +69,34 @@ def kernels_of(lib=DEFAULT_LIB):
     return out
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def m0_report(lib=DEFAULT_LIB):
+    """The LDS stores of the fused kernels address through M0 (ds_write_addtid_b32) and set it with inline asm, which the compiler cannot
+    see.  That is sound as long as the compiler itself never uses M0 in those kernels.  Disassembles every code object that contains
+    such stores and returns (number of addtid stores, M0 references that are NOT one of our `s_mov_b32 m0, sN`, instructions that would
+    consume M0 behind our back: movrel / sendmsg / LDS-DMA / GWS)."""
+    blob = open(lib, "rb").read()
+    stores, foreign, consumers = 0, [], []
+    for _, co in code_objects(blob):
+        with tempfile.NamedTemporaryFile(suffix=".co") as fp:
+            fp.write(co)
+            fp.flush()
+            txt = subprocess.run([OBJDUMP, "-d", fp.name], capture_output=True, text=True).stdout
+        if "ds_write_addtid_b32" not in txt:
+            continue
+        for line in txt.splitlines():
+            ins = line.split("//")[0].strip()
+            if "ds_write_addtid_b32" in ins:
+                stores += 1
+            elif re.search(r"\bm0\b", ins) and not re.match(r"s_mov_b32 m0, s\d+$", ins):
+                foreign.append(ins)
+            if re.search(r"movrel|s_sendmsg|_lds_|ds_gws|buffer_load.* lds|global_load_lds", ins):
+                consumers.append(ins)
+    return stores, foreign, consumers
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=DEFAULT_LIB)
