@@ -195,3 +195,43 @@ def test_streaming_backend_high_degrees():
         xb, ib = bec.SPA(0.25, code, max_iter=12).decode_batch(ys)
         xo, io = C.bec_decode(G, ys, 12)
         assert (xb == xo).all() and (ib == io).all()
+
+
+def test_empty_check_rows_including_trailing_ones():
+    # the branch-free ("dense") line fetch of the check pass computed an edge index for EVERY row; an empty row at the end of
+    # H has row_ptr == E, one past the edge list.  (3,4)-, rho = x^5-like and (3,6)-shaped toy matrices with empty rows in the middle and
+    # at the end, all three decoders, both arithmetics, against the C oracle; a frame is a codeword exactly when the non-empty checks hold.
+    import bp_oracle as O
+    import c_oracle as C
+    from ldpc_decoders_amd import bec, bpa, codes
+    from ldpc_decoders_amd.codes import Code
+
+    rng = np.random.RandomState(21)
+    for base, extra in ((codes.rand_reg_ldpc(240, 3, 4, rng), 3), (codes.rand_reg_ldpc(600, 3, 6, rng), 2), (codes.get_code("12_3_4_ldpc"), 5)):
+        # two empty rows spliced into the middle, `extra` at the end
+        mid = base.m // 2
+        chk = np.where(base.edge_chk >= mid, base.edge_chk + 2, base.edge_chk)
+        code = Code.from_edges(base.m + 2 + extra, base.n, chk, base.edge_var)
+        assert code.row_degrees()[-extra:].sum() == 0 and code.row_degrees()[mid:mid + 2].sum() == 0
+
+        class G:
+            m, n, chk, var = code.m, code.n, code.edge_chk, code.edge_var
+
+        B = 200
+        y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(3.0)), (B, code.n))
+        pri = O.biawgn_priors(y, 3.0)
+        for prec, dt in (("f64", np.float64), ("f32", np.float32)):
+            dec = bpa.MSA(code, max_iter=15, precision=prec, backend="stream")
+            xhat, iters = dec.decode_batch(None, pri.astype(dt))
+            xo, io = C.bp_decode(G, "MSA", None, pri.astype(dt), 15, dtype=dt)
+            assert (xhat == xo).all() and (iters == io).all()
+            assert len(np.unique(iters)) > 1 and code.syndrome(xhat[iters < 15]).sum() == 0
+        dec = bpa.SPA(code, max_iter=15, precision="f64", backend="stream")
+        xhat, iters = dec.decode_batch(None, pri)
+        xo, io = C.bp_decode(G, "SPA", None, pri, 15)
+        assert (xhat == xo).mean() > 0.999 and (np.abs(iters - io) <= 1).all()
+        ye = (rng.random_sample((B, code.n)) < 0.3).astype(np.uint8) * 2
+        de = bec.SPA(0.3, code, max_iter=15, backend="stream")
+        xe, ie = de.decode_batch(ye)
+        xo, io = C.bec_decode(G, ye, 15)
+        assert (xe == xo).all() and (ie == io).all()

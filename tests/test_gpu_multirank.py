@@ -31,4 +31,6 @@ def test_two_ranks_equal_one_rank():
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
     for key in ("mean_sweeps", "wer", "ber"):
         assert one[key] == two[key], key
-    assert two["value"] > 0 and two["roofline"]["kernel"] == "fused_decode"
+    assert two["value"] > 0 and two["roofline"]["kernel_class"] == "fused_decode" and two["roofline"]["kernel"].startswith("k_fused_f64<")
+    assert two["timed_blocks"] == 5 and two["ms_per_step_min"] <= two["ms_per_step"] <= two["ms_per_step_max"]
+    assert one["frames_counted"] == two["frames_counted"] == 2 * 8192 and one["bit_errors"] == two["bit_errors"]
