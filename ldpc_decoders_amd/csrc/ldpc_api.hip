@@ -476,12 +476,20 @@ int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uin
     // bounded staging: priors for at most 2^17 frames at a time
     const int64_t step = (int64_t)1 << 17;
     const int64_t cap = B < step ? B : step;
-    if (channel != CH_BEC) LDPC_TRY(d->h_in.reserve((size_t)cap * n * esz));
-    LDPC_TRY(d->h_y0.reserve((size_t)cap * n));
+    // BI-AWGN on the streaming kernels: the noise is generated straight into the tile layout (no [B,n] prior array, no transposing load)
+    const bool tiled_noise = channel == CH_BIAWGN && d->alg != ALG_BEC && pick_backend(d) == BK_STREAM;
+    if (channel != CH_BEC && !tiled_noise) LDPC_TRY(d->h_in.reserve((size_t)cap * n * esz));
+    if (channel != CH_BIAWGN) LDPC_TRY(d->h_y0.reserve((size_t)cap * n));
     LDPC_TRY(d->h_out.reserve((size_t)cap * n));
     LDPC_TRY(d->h_iters.reserve((size_t)cap * sizeof(int32_t)));
     for (int64_t b0 = 0; b0 < B; b0 += step) {
         const int64_t nb = (B - b0) < step ? (B - b0) : step;
+        if (tiled_noise) {
+            LDPC_TRY(stream_simulate_biawgn(d, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, max_iter, flags, (uint8_t*)d->h_out.p,
+                                            (int32_t*)d->h_iters.p, st));
+            LDPC_TRY(count_errors((uint8_t*)d->h_out.p, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters, st));
+            continue;
+        }
         void* pri = channel == CH_BEC ? nullptr : d->h_in.p;
         uint8_t* y = channel == CH_BIAWGN ? nullptr : (uint8_t*)d->h_y0.p;
         LDPC_TRY(channel_generate(channel, d->dtype, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, (int32_t)n, pri,

@@ -122,6 +122,9 @@ int prof_collect(Decoder* d, const std::vector<ProfSpan>& spans);
 int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
                   uint8_t* xhat, int32_t* iters, void* soft_out, hipStream_t st);
 
+int stream_simulate_biawgn(Decoder* d, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
+                           int32_t max_iter, uint32_t flags, uint8_t* xhat, int32_t* iters, hipStream_t st);
+
 int fused_plan_create(Decoder* d);
 int fused_plan_host(const Code* c, int alg, int dtype, long moves, const char* out_dir, double* info4);  // host only, no device
 void fused_plan_destroy(Decoder* d);

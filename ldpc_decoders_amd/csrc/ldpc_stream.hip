@@ -31,6 +31,7 @@
 #include "ldpc_cn.hpp"
 #include "ldpc_common.hpp"
 #include "ldpc_repack.hpp"
+#include "ldpc_rng.hpp"
 
 namespace ldpc {
 
@@ -145,6 +146,36 @@ __global__ __launch_bounds__(256) void k_load_tile(const T* __restrict__ priors,
     }
     if constexpr (ALG == ALG_BEC) {
         if (tx == 0 && era_any) atomicOr(&flags[2 * tile + 1], era_any);
+    }
+}
+
+// BI-AWGN channel + LLR written STRAIGHT into the prior tiles (ldpc_simulate on the streaming kernels): the Philox block, Box-Muller and
+// LLR expressions of k_biawgn (ldpc_channel.hip; src/biawgn.py:10-28) -- bit-identical priors -- without the [B,n] staging array and the
+// transposing tile load.  Lane == frame: one Philox block (4 consecutive variables) per lane and step, four coalesced lines per wave.
+struct SimSource {
+    double sigma, inv_var2;
+    int codeword;
+    uint64_t seed, frame0;
+    uint32_t stream;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_biawgn_tile(SimSource s, int64_t B, int n, int bpf, int blocks_per_wave, T* __restrict__ prior_t) {
+    const int lane = threadIdx.x, tile = blockIdx.y;
+    const int64_t fr = (int64_t)tile * 64 + lane;
+    if (fr >= B) return;
+    const int j0 = (blockIdx.x * 4 + threadIdx.y) * blocks_per_wave;
+    const T sg = (T)s.sigma, k = (T)s.inv_var2, mean = (T)(2 * s.codeword - 1);
+    T* pt = prior_t + (int64_t)tile * n * 64 + lane;
+    for (int j = j0; j < min(bpf, j0 + blocks_per_wave); ++j) {
+        const Philox4 p = philox_word_block(s.seed, s.stream, s.frame0 + (uint64_t)fr, (uint32_t)j);
+        T z[4];
+        box_muller<T>(p.w[0], p.w[1], z[0], z[1]);
+        box_muller<T>(p.w[2], p.w[3], z[2], z[3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T y = mean + sg * z[q];
+            if (4 * j + q < n) pt[(int64_t)(4 * j + q) * 64] = -(k * y);  // -2y/sigma^2 with k = 2/sigma^2
+        }
     }
 }
 
@@ -620,7 +651,7 @@ constexpr int POLL_RING = 4;
 
 template <typename T, int ALG>
 int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags_in, uint8_t* xhat,
-        int32_t* iters, void* soft_out, hipStream_t st) {
+        int32_t* iters, void* soft_out, hipStream_t st, const SimSource* sim = nullptr) {
     const Code* c = d->code;
     const int n = c->n, m = c->m;
     const int64_t E = c->E;
@@ -701,8 +732,15 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     LDPC_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)tiles * 16 + 64 + POLL_RING * 16, st));
     LDPC_HIP_TRY(hipMemsetAsync(iters, 0, (size_t)B * sizeof(int32_t), st));
     if (soft_out) LDPC_HIP_TRY(hipMemsetAsync(marg, 0, (size_t)tiles * n * 64 * sizeof(T), st));  // frames that never sweep report 0
-    hipLaunchKernelGGL((k_load_tile<T, ALG>), dim3((n + 63) / 64, tiles), dim3(256), 0, st, (const T*)priors_v, y0, B, n,
-                       prior, xbits, xera, tflags);
+    if constexpr (ALG != ALG_BEC) {
+        if (sim) {  // device Monte-Carlo over BI-AWGN: the noise goes straight into the tile layout
+            const int bpf = (n + 3) / 4, bpw = 16;
+            hipLaunchKernelGGL((k_biawgn_tile<T>), dim3(((bpf + bpw - 1) / bpw + 3) / 4, tiles), dim3(64, 4), 0, st, *sim, B, n, bpf, bpw, prior);
+        }
+    }
+    if (!sim)
+        hipLaunchKernelGGL((k_load_tile<T, ALG>), dim3((n + 63) / 64, tiles), dim3(256), 0, st, (const T*)priors_v, y0, B, n,
+                           prior, xbits, xera, tflags);
     hipLaunchKernelGGL(k_init_live, dim3((tiles + 255) / 256), dim3(256), 0, st, live, B, tiles);
 
     const int cap = max_iter > 0 ? max_iter : 100000;  // max_iter <= 0 == unlimited upstream (src/bpa.py:28); bounded here
@@ -833,6 +871,23 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
 }
 
 }  // namespace
+
+// ldpc_simulate on the streaming kernels, BI-AWGN with the all-`codeword` word: channel + LLR generated into the tiles, then the decode
+int stream_simulate_biawgn(Decoder* d, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
+                           int32_t max_iter, uint32_t flags, uint8_t* xhat, int32_t* iters, hipStream_t st) {
+    if (B <= 0) return LDPC_OK;
+    if (d->alg == ALG_BEC || B > (int64_t)65535 * 64) {
+        set_error("stream_simulate_biawgn: LLR decoders, at most %d frames per call", 65535 * 64);
+        return LDPC_E_ARG;
+    }
+    const double var = pow(10.0, -param / 10.0);  // src/biawgn.py:10 -- the host arithmetic of channel_generate()
+    const SimSource s{sqrt(var), 2.0 / var, codeword, seed, frame0, (uint32_t)stream_id};
+    if (d->alg == ALG_MSA)
+        return d->dtype == DT_F64 ? run<double, ALG_MSA>(d, nullptr, nullptr, B, max_iter, flags, xhat, iters, nullptr, st, &s)
+                                  : run<float, ALG_MSA>(d, nullptr, nullptr, B, max_iter, flags, xhat, iters, nullptr, st, &s);
+    return d->dtype == DT_F64 ? run<double, ALG_SPA>(d, nullptr, nullptr, B, max_iter, flags, xhat, iters, nullptr, st, &s)
+                              : run<float, ALG_SPA>(d, nullptr, nullptr, B, max_iter, flags, xhat, iters, nullptr, st, &s);
+}
 
 int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
                   uint8_t* xhat, int32_t* iters, void* soft_out, hipStream_t st) {
