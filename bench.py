@@ -102,9 +102,13 @@ def cpu_baseline(code, snr, max_iter, precision="f64", budget_s=10.0):
     # per-frame scipy.sparse baseline, one process per core, each decoding its own frame stream for about budget_s seconds
     try:
         procs = min(cores, 64)
-        per = _scipy_probe((code.m, code.n, code.edge_chk, code.edge_var, snr, max_iter, 2, 1))["frames_per_s"]
-        frames_each = max(2, int(per * budget_s))
         with mp.get_context("fork").Pool(procs) as pool:
+            # a short pass of every process sizes the sample (the rate per process UNDER LOAD, not that of one process alone)
+            pool.map(_scipy_probe, [(code.m, code.n, code.edge_chk, code.edge_var, snr, max_iter, 1, 10 + i) for i in range(procs)])  # imports, warm-up
+            t0 = time.time()
+            pool.map(_scipy_probe, [(code.m, code.n, code.edge_chk, code.edge_var, snr, max_iter, 3, 50 + i) for i in range(procs)])
+            per = 3.0 / max(time.time() - t0, 1e-3)
+            frames_each = max(3, int(per * budget_s))
             t0 = time.time()
             res = pool.map(_scipy_probe, [(code.m, code.n, code.edge_chk, code.edge_var, snr, max_iter, frames_each, 100 + i) for i in range(procs)])
             wall = time.time() - t0
