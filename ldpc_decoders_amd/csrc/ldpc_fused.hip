@@ -373,9 +373,10 @@ int fused_plan_create(Decoder* d) {
                 if (addr[g0 + l] < 0) addr[g0 + l] = rep;
         }
     };
-    if (DC % 2 == 0) {
-        // even dc: a padded check lane reads ONE marginal dc times, so its sign parity is even and it never shows up in
-        // the syndrome (no lane mask needed).  Pick, per half-wave, the slot that collides least with the real reads.
+    // Padded check lanes repeat an address of their own half-wave (broadcast, no extra LDS cycle); the kernels mask them out of the
+    // syndrome (cn_valid).  The 16-wave shape has no register for that mask: there a padded lane reads ONE marginal dc times (even dc:
+    // even sign parity, invisible in the syndrome) -- per half-wave the slot that collides least with the real reads.
+    if (BIG && DC % 2 == 0) {
         for (int R = 0; R < CR; ++R)
             for (int h = 0; h < 2; ++h) {
                 bool any_pad = false;
@@ -405,6 +406,30 @@ int fused_plan_create(Decoder* d) {
     }
     fill_padding(cn_addr, 0);
     fill_padding(vn_addr, c2v_base);
+    if (std::getenv("LDPC_FUSED_DEBUG")) {
+        // bank-conflict cycles of the FINAL gather tables (padding included), by the model of MI355X_MICROARCH.md: a wave64 gather is served
+        // in two half-waves; within one, every extra distinct address on a bank costs a cycle (4-byte reads: 32 banks, 8-byte: 64)
+        auto table_conflicts = [&](const std::vector<int64_t>& addr) {
+            long extra = 0;
+            const int banks = esz == 8 ? 64 : 32;
+            for (size_t g0 = 0; g0 + 32 <= addr.size(); g0 += 32) {
+                int worst = 1;
+                for (int b = 0; b < banks; ++b) {
+                    std::vector<int64_t> seen;
+                    for (int l = 0; l < 32; ++l) {
+                        const int64_t a = addr[g0 + l];
+                        if ((int)((a / 4) % banks) != b && !(esz == 8 && (int)((a / 4 + 1) % banks) == b)) continue;
+                        if (std::find(seen.begin(), seen.end(), a) == seen.end()) seen.push_back(a);
+                    }
+                    worst = std::max(worst, (int)seen.size());
+                }
+                extra += worst - 1;
+            }
+            return extra;
+        };
+        fprintf(stderr, "ldpc fused tables: conflict cycles per sweep: check-phase gathers %ld, variable-phase gathers %ld (planner: %g)\n",
+                table_conflicts(cn_addr), table_conflicts(vn_addr), L.extra_cycles_planned);
+    }
     for (int K = 0; K < CR * DC; ++K)
         for (int lane = 0; lane < 64; ++lane) put16(cn_tab, CNW, CRW * DC, K, lane, (uint32_t)(cn_addr[(size_t)K * 64 + lane] >> tab_shift));
     for (int K = 0; K < vr.total_gathers(); ++K)

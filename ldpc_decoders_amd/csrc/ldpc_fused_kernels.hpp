@@ -163,15 +163,13 @@ constexpr int sim_opaque_vn(int, int, int) { return LDPC_SIM_OPAQUE_VN_WORDS; }
 #else
 constexpr int sim_opaque_cn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_MSA ? 8 : 15;           // one frame per CU (16 waves): min-sum 8 + 15 -> no spill
-    if (alg == ALG_MSA && vrx == 0) return 0;             // regular min-sum (the headline shape): nothing needed
-    if (alg == ALG_BEC && vrx == 0) return 4;             // regular erasure decoder: 4 + 4
-    return 8;
+    if (vrx == 0) return alg == ALG_MSA ? 2 : (alg == ALG_BEC ? 4 : 15);  // regular shapes: min-sum 2 + 4, erasure 4 + 4, sum-product all
+    return alg == ALG_BEC ? 8 : 15;                       // irregular shapes (wide variable rounds)
 }
 constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_BEC ? 0 : 15;           // (the 16-wave erasure kernel streams its variable table anyway)
-    if (alg == ALG_MSA && vrx == 0) return 0;
-    if (alg == ALG_BEC && vrx == 0) return 4;
-    return 15;
+    if (vrx == 0) return alg == ALG_SPA ? 15 : 4;
+    return alg == ALG_MSA ? 8 : 15;
 }
 #endif
 constexpr int SIM_ACC_LANE0 = 60;  // hist_bins <= 60 (fused_simulate_supported)
@@ -284,6 +282,16 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
         // one register each, opaque to the optimiser: otherwise it keeps the ten per-round masks of `valid` as ten separate
         // launch-invariant values and spills them around the sweep loop
         asm volatile("" : "+v"(valid), "+v"(dummy));
+    }
+    // bit r: check slot (w*CRW + r, lane) holds a real check.  A PADDED check lane gathers whatever is free for its half-wave (an
+    // address a real lane reads anyway: LDS broadcast, no extra cycle) and is masked out of the syndrome here.  (Rounds 1-2 let it read
+    // ONE marginal dc times instead -- even sign parity, no mask needed for even dc -- but that one address sat on a busy bank in
+    // most of the dc gathers: 49 of the 67 measured bank-conflict cycles per frame-sweep of the n = 1200 plan.)
+    unsigned cn_valid = 0;
+    if constexpr (!BIG) {
+#pragma unroll
+        for (int r = 0; r < CRW; ++r) cn_valid |= ((cn_active[r] >> lane) & 1ull) ? (1u << r) : 0u;
+        asm volatile("" : "+v"(cn_valid));
     }
 
     // verdict exchange between the NW waves of a frame: each wave publishes "my checks see an unsatisfied syndrome" in a
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 u64 par = 0;
 #pragma unroll
                 for (int j = 0; j < DC; ++j) par ^= __ballot(lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, r * DC + j)) < 0.0f);
-                if constexpr (DC % 2 == 0) unsat |= par; else unsat |= par & cn_active[r];
+                unsat |= par & cn_active[r];  // padded check lanes read arbitrary marginals: masked out
             }
             left_at_0 = early && !any_unsat(unsat != 0);
             if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
@@ -651,7 +659,14 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                         mx ^= __float_as_uint(mg[r & 1][j]);
                         vx ^= __float_as_uint(v[j]);
                     }
-                    if constexpr (DC % 2 == 0) synd |= mx; else synd |= ((cn_active[r] >> lane) & 1ull) ? mx : 0u;
+                    // bit 31 only is tested: the sign parity of a REAL check of this round.  (BIG: 128 registers hold no extra mask; there a
+                    // padded lane still reads ONE marginal dc times -- even parity for the even dc this shape has, ldpc_fused.hip)
+                    if constexpr (BIG) {
+                        static_assert(!BIG || DC % 2 == 0, "the 16-wave shape relies on even check degree for its padded lanes");
+                        synd |= mx;
+                    } else {
+                        synd |= mx & (cn_valid << (31 - r));
+                    }
                     // leave-one-out reduction of |v|: minimum (min-sum) or join of 1 - tanh(|v|/2) (sum-product, ldpc_cn.hpp)
                     float pre[DC], suf[DC];
                     float preo[ALG == ALG_MSA ? 1 : DC], sufo[ALG == ALG_MSA ? 1 : DC];  // odd parts (sum-product only)
@@ -866,6 +881,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
         valid |= vmap[q] >= 0 ? (1u << q) : 0u;
         dummy |= vmap[q] == -2 ? (1u << q) : 0u;
     }
+    unsigned cn_valid = 0;  // bit r: check slot (w*CRW + r, lane) holds a real check (padded lanes gather anything, see k_fused_bp)
+#pragma unroll
+    for (int r = 0; r < CRW; ++r) cn_valid |= ((cn_active[r] >> lane) & 1ull) ? (1u << r) : 0u;
+    asm volatile("" : "+v"(cn_valid));
     // sum-product: positions of short check rows that read the certain slot (bit r*DC+j).  Their message must stay 0: the certain
     // marginal is +inf, and the verbatim rule would feed inf - (+-inf) = NaN back into the row once the other edges saturate
     // (upstream has no such edge: tanh(inf/2) = 1 contributes log 1 = 0 to the row sum and leaves the parity alone).
@@ -990,8 +1009,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
                 u64 par = 0;
 #pragma unroll
                 for (int j = 0; j < DC; ++j) par ^= __ballot(gat(half_of<CRW * DC>(cn_idx, r * DC + j)) < 0.0);
-                // even dc: a padded check lane reads one marginal dc times -> even parity; odd dc: mask the padded lanes out
-                if constexpr (DC % 2 == 0) unsat |= par; else unsat |= par & cn_active[r];
+                unsat |= par & cn_active[r];  // padded check lanes read arbitrary marginals: masked out
             }
             left_at_0 = early && !any_unsat(unsat != 0);
             phase_barrier();
@@ -1042,7 +1060,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
                             vx ^= (uint32_t)__double2hiint(v[j]);
                             mx ^= (uint32_t)__double2hiint(mg[r & 1][j]);
                         }
-                        if constexpr (DC % 2 == 0) synd |= mx; else synd |= ((cn_active[r] >> lane) & 1ull) ? mx : 0u;
+                        synd |= mx & (cn_valid << (31 - r));  // bit 31 only is tested: the sign parity of a REAL check of this round
                         double mag[DC];
                         if constexpr (DC == 6) {  // 11 minimum instructions for the six leave-one-out minima
                             const double s3 = fmin(a[4], a[5]), s2 = fmin(fmin(a[3], a[4]), a[5]), s1 = fmin(a[2], s2);
@@ -1078,7 +1096,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
                         u64 par = 0;
 #pragma unroll
                         for (int j = 0; j < DC; ++j) par ^= __ballot(mg[r & 1][j] < 0.0);
-                        if constexpr (DC % 2 == 0) synd_mask |= par; else synd_mask |= par & cn_active[r];
+                        synd_mask |= par & cn_active[r];
                         cn_spa<DC>(v, DC);  // the streaming kernel's rule, edges in canonical order (see the plan)
 #pragma unroll
                         for (int j = 0; j < DC; ++j) c2v_old[r][j] = ((padpos >> (r * DC + j)) & 1ull) ? 0.0 : v[j];
