@@ -219,7 +219,8 @@ def fused_roofline(kernel_name, frame_sweeps_per_s, cus, counters=None):
     valu = frame_sweeps_per_s * e["valu_active_cycles_per_frame_sweep"] / (cus * 4 * NOMINAL_CLOCK_HZ)
     bound = "lds" if lds >= valu else "valu"
     peak = NOMINAL_CLOCK_HZ * cus * 256 / 1e9  # the LDS array is 64 banks x 4 B wide per clock and CU
-    return dict(bound=bound, frac=round(max(lds, valu), 4), lds_frac=round(lds, 4), valu_frac=round(valu, 4),
+    useful = frame_sweeps_per_s * (e["lds_idx_active_per_frame_sweep"] - e["bank_conflict_per_frame_sweep"]) / (cus * NOMINAL_CLOCK_HZ)
+    return dict(bound=bound, frac=round(max(lds, valu), 4), lds_frac=round(lds, 4), lds_frac_without_bank_conflicts=round(useful, 4), valu_frac=round(valu, 4),
                 achieved=round(lds * peak, 1) if bound == "lds" else round(valu * 100, 2), peak=round(peak, 1) if bound == "lds" else 100.0,
                 unit="GB/s" if bound == "lds" else "% of VALU issue cycles",
                 lds_cycles_per_frame_sweep=e["lds_idx_active_per_frame_sweep"], bank_conflict_cycles_per_frame_sweep=e["bank_conflict_per_frame_sweep"],
@@ -353,7 +354,8 @@ def run_bench(args, comm, make_handle=None, device="cuda"):
                                 frame_sweeps_per_s=round(fsps, 1), note="no committed PMC counters for %s: run tools/collect_rooflines.sh" % kname)
                 roof.update(kernel=kname, traffic=traffic, hbm_model=hbm_model,
                             note="LDS-resident kernel: frac = busy cycles of the binding unit / available cycles at 2.4 GHz.  Cycles per frame-sweep are "
-                                 "PMC counters (SQ_LDS_IDX_ACTIVE, 4 x SQ_ACTIVE_INST_VALU) of THIS kernel (the simulate variant that is timed), "
+                                 "PMC counters of THIS kernel (the simulate variant that is timed): SQ_LDS_IDX_ACTIVE; VALU = an issue model on the measured instruction mix "
+                                 "(2 cycles per wave64 instruction, 4 per fp64 add/mul/fma, 8 per transcendental), "
                                  "committed under profiles/, x the frame-sweeps/s of the HIP-event timing of this run; `traffic` = PMC HBM bytes per launch",
                             **common)
             else:
