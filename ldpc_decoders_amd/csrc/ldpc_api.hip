@@ -273,6 +273,8 @@ int ldpc_decoder_fused_info(ldpc_decoder_t h, double* out8) {
 int ldpc_decoder_kernel_name(ldpc_decoder_t h, int simulate, char* buf, int64_t len) {
     Decoder* d = (Decoder*)h;
     if (!d || !buf || len <= 0) return LDPC_E_ARG;
+    buf[0] = 0;
+    if (d->backend == BK_STREAM) return LDPC_OK;  // a decoder pinned to the streaming kernels never launches its LDS-resident shape
     return fused_kernel_name(d, simulate != 0, buf, (size_t)len);
 }
 

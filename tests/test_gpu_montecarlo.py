@@ -165,3 +165,32 @@ def test_main_py_random_codeword_runs_on_the_device(tmp_path):
     assert res["-1"]["wec"] >= 3000 and res["0"]["wec"] >= 3000
     # fp32 sum-product over BI-AWGN is codeword-symmetric: both runs estimate the same word-error rate
     assert abs(res["-1"]["wer"] - res["0"]["wer"]) < 0.1 * res["0"]["wer"]
+
+
+def test_kernel_name_and_profile_classes():
+    # what the measurement tools rely on: the library names the LDS-resident kernel a decoder launches exactly as the code object (and
+    # rocprofv3) does -- the key of its committed PMC counters --, and the HIP-event classes cover the whole streaming decode
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    h = _handle()
+    built = {k.split("(")[0] for k in kernel_resources.kernels_of()}
+    for sim in (False, True):
+        name = h.kernel_name(sim)
+        assert name.startswith("k_fused_") and name in built, name
+    assert ", true, " in h.kernel_name(True) and ", false, " in h.kernel_name(False)
+    hs = DecoderHandle(h.code, "MSA", "f32", "stream")
+    assert hs.kernel_name(True) == ""
+    hs.set_profiling(True)
+    hs.read_profile(reset=True)
+    cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+    hs.simulate("biawgn", 2.0, 0, 5, 0, 0, 2048, 50, cnt)
+    prof = hs.read_profile(reset=True)
+    hs.set_profiling(False)
+    cn, vn, tot = prof["stream_check_pass"], prof["stream_variable_pass"], prof["stream_decode_total"]
+    assert cn[1] == vn[1] > 5 and tot[1] == 1 and tot[0] >= cn[0] + vn[0] > 0 and prof["fused_decode"][1] == 0, prof
