@@ -26,7 +26,8 @@ int DevBuf::reserve(size_t need) {
         p = nullptr;
         bytes = 0;
     }
-    const size_t want = need + need / 8 + 256;
+    const size_t slack = need / 8 < ((size_t)64 << 20) ? need / 8 : ((size_t)64 << 20);  // growth headroom, bounded: workspaces reach 100 GB
+    const size_t want = need + slack + 256;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
         p = nullptr;
@@ -68,6 +69,24 @@ int upload(const std::vector<T>& h, T** d) {
     LDPC_HIP_TRY(hipMalloc((void**)d, (h.size() + 1) * sizeof(T)));
     LDPC_HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return LDPC_OK;
+}
+
+// Frames per pass through the streaming kernels: at most 2^17, and no more than fit -- with the second state set of the frame repack
+// (three quarters of the first) -- into 80 % of the memory that is free now.  n = 64 800 in fp32 is 1.3 MB of state per frame: 2^17
+// frames would want 297 GB with the repack set; 98 304 take 223 GB.
+int64_t stream_chunk_frames(const Decoder* d) {
+    const size_t esz = d->alg == ALG_BEC ? 1 : (d->dtype == DT_F64 ? 8 : 4);
+    const double per_frame = 1.75 * (double)esz * ((double)d->code->E + 2.0 * d->code->n) + 3.0 * d->code->n;  // + staged decisions / priors
+    size_t free_b = 0, total_b = 0;
+    int64_t step = (int64_t)1 << 17;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+        // what this decoder already holds is re-used, not needed again
+        const size_t held = d->msg.bytes + d->marg.bytes + d->prior.bytes + d->msg2.bytes + d->marg2.bytes + d->prior2.bytes;
+        const double budget = 0.8 * ((double)free_b + (double)held);
+        const int64_t fit = (int64_t)(budget / per_frame) / 64 * 64;
+        if (fit < step) step = fit < 64 ? 64 : fit;
+    }
+    return step;
 }
 
 int pick_backend(Decoder* d) {
@@ -310,8 +329,8 @@ int ldpc_decode(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t
     const int bk = pick_backend(d);
     if (bk < 0) return bk;
     hipStream_t st = (hipStream_t)stream;
-    // bound the workspace: at most 2^17 frames per pass through a backend
-    const int64_t step = (int64_t)1 << 17;
+    // bound the workspace: at most 2^17 frames per pass through a backend, fewer where the streaming state would not fit the HBM
+    const int64_t step = bk == BK_STREAM ? stream_chunk_frames(d) : (int64_t)1 << 17;
     const size_t esz = d->dtype == DT_F64 ? 8 : 4;
     int sweeps = 0;
     for (int64_t b0 = 0; b0 < B; b0 += step) {
@@ -475,8 +494,8 @@ int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uin
     }
     if (d->backend != BK_STREAM && fused_simulate_supported(d, channel, param, hist_bins))
         return fused_simulate(d, channel, param, codeword, seed, stream_id, frame0, B, max_iter, flags, hist_bins, counters, st);
-    // bounded staging: priors for at most 2^17 frames at a time
-    const int64_t step = (int64_t)1 << 17;
+    // bounded staging: priors for at most 2^17 frames at a time (fewer where the streaming state would not fit the HBM)
+    const int64_t step = pick_backend(d) == BK_STREAM ? stream_chunk_frames(d) : (int64_t)1 << 17;
     const int64_t cap = B < step ? B : step;
     // BI-AWGN on the streaming kernels: the noise is generated straight into the tile layout (no [B,n] prior array, no transposing load)
     const bool tiled_noise = channel == CH_BIAWGN && d->alg != ALG_BEC && pick_backend(d) == BK_STREAM;

@@ -163,12 +163,12 @@ constexpr int sim_opaque_vn(int, int, int) { return LDPC_SIM_OPAQUE_VN_WORDS; }
 #else
 constexpr int sim_opaque_cn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_MSA ? 8 : 15;           // one frame per CU (16 waves): min-sum 8 + 15 -> no spill
-    if (vrx == 0) return alg == ALG_MSA ? 2 : (alg == ALG_BEC ? 4 : 15);  // regular shapes: min-sum 2 + 4, erasure 4 + 4, sum-product all
+    if (vrx == 0) return alg == ALG_MSA ? 2 : (alg == ALG_BEC ? 8 : 15);  // regular shapes: min-sum 2 + 4, erasure 8 + 8, sum-product all
     return alg == ALG_BEC ? 8 : 15;                       // irregular shapes (wide variable rounds)
 }
 constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_BEC ? 0 : 15;           // (the 16-wave erasure kernel streams its variable table anyway)
-    if (vrx == 0) return alg == ALG_SPA ? 15 : 4;
+    if (vrx == 0) return alg == ALG_SPA ? 15 : (alg == ALG_BEC ? 8 : 4);
     return alg == ALG_MSA ? 8 : 15;
 }
 #endif
@@ -497,20 +497,25 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                         for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    // Everything is a small integer held in a float, so the rule is arithmetic, not compares (round 3: 15 -> 7 VALU
+                    // instructions per edge; the erasure kernel was VALU-bound): sign = clamp to [-1, 1] (v_med3_f32); known = sum |sign|,
+                    // ones = (known + sum sign) / 2.
                     float sgn[DC];
-                    float n_erased = 0.0f, n_ones = 0.0f;
+                    float known = 0.0f, ssum = 0.0f;
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
                         const float dlt = mg[r & 1][j] - c2v_old[r][j];           // v2c = sign(marginal - c2v)  (src/bec.py:116)
-                        sgn[j] = dlt > 0.0f ? 1.0f : (dlt < 0.0f ? -1.0f : 0.0f);
-                        n_erased += 1.0f - __builtin_fabsf(sgn[j]);
-                        n_ones += sgn[j] > 0.0f ? 1.0f : 0.0f;
+                        sgn[j] = __builtin_amdgcn_fmed3f(dlt, -1.0f, 1.0f);
+                        known += __builtin_fabsf(sgn[j]);
+                        ssum += sgn[j];
                     }
-                    const float fill = ((int)n_ones & 1) ? 1.0f : -1.0f;  // parity of the known ones (src/bec.py:110-112)
+                    const float fill = ((int)(0.5f * (known + ssum)) & 1) ? 1.0f : -1.0f;  // parity of the known ones (src/bec.py:110-112)
+                    // 0 erasures: echo; > 1: nothing known; exactly 1: the erased edge learns the parity of the others
+                    const float echo = known == (float)DC ? 1.0f : 0.0f, learn = known == (float)(DC - 1) ? 1.0f : 0.0f;
                     static_for<0, DC>([&](auto J_) {
                         constexpr int j = decltype(J_)::value;
-                        // 0 erasures: echo; > 1: nothing known; exactly 1: the erased edge learns the parity of the others
-                        const float c = n_erased == 0.0f ? sgn[j] : (n_erased > 1.0f ? 0.0f : (sgn[j] == 0.0f ? fill : 0.0f));
+                        const float t = __builtin_fmaf(-__builtin_fabsf(sgn[j]), fill, fill);  // fill on the erased edge, 0 on a known one
+                        const float c = __builtin_fmaf(echo, sgn[j], learn * t);
                         c2v_old[r][j] = c;
                         if constexpr (!BIG) lds_st_tid<(r * DC + j) * 256>(c);
                     });

@@ -315,7 +315,6 @@ SIM_KERNELS_WITHOUT_SPILLS = [
     "k_fused_bp<1, 6, 3, 5, 10, 2, true, 0, 3>",    # config 3, fp32 sum-product (BSC / BI-AWGN)
     "k_fused_bp<0, 6, 3, 5, 10, 16, true, 3, 8>",   # config 4, one frame per CU (rate-1/2 irregular n = 10 000)
     "k_fused_bp<0, 6, 3, 5, 10, 2, true, 2, 8>",    # irregular n = 1200 ensembles (1200_rho_x5_*), min-sum
-    "k_fused_bp<2, 6, 3, 5, 10, 2, true, 2, 8>",    # ... erasure decoder
     "k_fused_bp<0, 6, 3, 4, 8, 1, true, 0, 3>",     # n <= 512
     "k_fused_bp<0, 6, 3, 6, 11, 4, true, 0, 3>",    # Margulis n = 2640
 ]
@@ -332,6 +331,8 @@ def test_simulate_kernels_do_not_spill():
 
     ks = kernel_resources.kernels_of()
     assert len(ks) > 100, "code objects of libldpc_hip.so not found"
+    # (not in the list: the irregular erasure shape <2, 6, 3, 5, 10, 2, true, 2, 8> -- 9 launch-invariant registers spilled since the erasure
+    # rule became arithmetic; measured 7.7 % faster with them than the spill-free compare form -- and the check-degree 4/5/7/8 shapes)
     by_name = {k.split("(")[0]: v for k, v in ks.items()}
     for name in SIM_KERNELS_WITHOUT_SPILLS:
         assert name in by_name, "kernel %s not in the library" % name
