@@ -855,6 +855,9 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     if (soft_out && ALG != ALG_BEC)
         hipLaunchKernelGGL(k_soft_out<T>, dim3((n + 3) / 4, tiles), dim3(256), 0, st, marg, (T*)soft_out, B, n);
     LDPC_HIP_TRY(hipGetLastError());
+    // polls still in flight copy into the pinned ring; the next decode of this handle may run on another stream and reuse the slots:
+    // let the last copy land first (everything of this decode is enqueued by now, the GPU is not waiting for the host)
+    if (!pending.empty()) LDPC_HIP_TRY(hipEventSynchronize(poll_ev[pending.back().slot]));
     if (d->profile) {
         LDPC_HIP_TRY(hipEventRecord(e_end, st));
         LDPC_HIP_TRY(hipStreamSynchronize(st));
