@@ -243,7 +243,7 @@ def run_bench(args, comm, make_handle=None, device="cuda"):
         from ldpc_decoders_amd._device import DecoderHandle as make_handle  # noqa: N813
     code = load_code(args.code)
     handle = make_handle(code, "MSA", args.precision, args.backend)
-    sim = DeviceSimulator(handle, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=args.max_iter + 1, device=device)
+    sim = DeviceSimulator(handle, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=min(args.max_iter + 1, 60), device=device)
     s = 8 if args.precision == "f64" else 4
     bytes_per_frame_iter = s * (4 * code.E + code.n)
     side_legs = not args.no_profile and comm.world == 1 and device == "cuda"
@@ -260,7 +260,7 @@ def run_bench(args, comm, make_handle=None, device="cuda"):
     stream_res = None
     if backend_used == "fused" and side_legs:
         h2 = make_handle(code, "MSA", args.precision, "stream")
-        sim2 = DeviceSimulator(h2, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=args.max_iter + 1)
+        sim2 = DeviceSimulator(h2, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=min(args.max_iter + 1, 60))
         stream_res = run_point(sim2, h2, comm, args.snr, 2, 1, args.batch, 0, torch)
         del sim2, h2
 
@@ -290,7 +290,7 @@ def run_bench(args, comm, make_handle=None, device="cuda"):
     f32_res = None
     if args.precision == "f64" and side_legs:
         h3 = make_handle(code, "MSA", "f32", args.backend)
-        sim3 = DeviceSimulator(h3, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=args.max_iter + 1)
+        sim3 = DeviceSimulator(h3, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=min(args.max_iter + 1, 60))
         f32_res = run_point(sim3, h3, comm, args.snr, args.steps, 1, args.batch, 0, torch, True, 3)
         f32_res["backend"] = h3.last_stats()[0]
         f32_res["kernel"] = h3.kernel_name(True) if f32_res["backend"] == "fused" else ""
