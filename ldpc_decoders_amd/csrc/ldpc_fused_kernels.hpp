@@ -77,6 +77,12 @@ __device__ __forceinline__ void lds_st_tid(float v) {
 }
 __device__ __forceinline__ void lds_set_m0(uint32_t base) { asm volatile("s_mov_b32 m0, %0" ::"s"(base) : "memory"); }
 
+// The few words the waves of a frame hand each other (syndrome verdicts, frame numbers, error counts) are accessed as LDS words:
+// through a generic `volatile uint32_t*` the compiler emits flat_store / flat_load ... sc0 sc1 -- the aperture check of the vector
+// memory pipeline, vmcnt AND lgkmcnt to wait for -- on the serial store -> barrier -> load chain that ends every sweep.
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+__device__ __forceinline__ lds_vu32* lds_word(const void* p) { return (lds_vu32*)(uintptr_t)(uint32_t)(uintptr_t)p; }  // low half of a generic LDS address = the LDS byte address
+
 // Workgroup barrier that also drains this wave's LDS queue: the ds_write_addtid stores above are inline asm, invisible to
 // the compiler's s_waitcnt insertion, so a plain __syncthreads() may reach s_barrier with such stores still in flight.
 __device__ __forceinline__ void wg_barrier() {
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
     };
     if (A.zero_row && w == 0) reinterpret_cast<float*>(smem)[NPAD + CR * DC * 64 + lane] = 0.0f;  // the always-zero row
     const bool own_last = !(SYS && w == NW - 1);  // with a system row, wave NW-1 never writes its last marginal row
-    auto sysw = [&](int i) { return reinterpret_cast<volatile uint32_t*>(smem + A.sys_off) + i; };
+    auto sysw = [&](int i) { return lds_word(smem + A.sys_off) + i; };
     if constexpr (SYS) {
         if (threadIdx.x == 0) *sysw(33) = 0u;  // published by the barrier at the top of the frame loop
     }
@@ -305,11 +311,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             wg_barrier();
             return __ballot(*sysw(lane & (NW - 1)) != 0u) != 0;
         } else {
-            if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_sync) = mine ? 1u : 0u;
+            if (lane == 0) *lds_word(smem + my_sync) = mine ? 1u : 0u;
             wg_barrier();
             uint32_t v = 0;
 #pragma unroll
-            for (int i = 0; i < NW; ++i) v |= *reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[i]);
+            for (int i = 0; i < NW; ++i) v |= *lds_word(smem + A.sync_off[i]);
             return v != 0u;
         }
     };
@@ -326,11 +332,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             const uint32_t v = *sysw(16 + (lane & (NW - 1)));
             return (__ballot((v & 1u) != 0u) != 0 ? 1u : 0u) | (__ballot((v & 2u) != 0u) != 0 ? 2u : 0u);
         } else {
-            if (lane == 0) *reinterpret_cast<volatile uint32_t*>(smem + my_msync) = mine;
+            if (lane == 0) *lds_word(smem + my_msync) = mine;
             wg_barrier();
             uint32_t v = 0;
 #pragma unroll
-            for (int i = 0; i < NW; ++i) v |= *reinterpret_cast<volatile uint32_t*>(smem + A.msync_off[i]);
+            for (int i = 0; i < NW; ++i) v |= *lds_word(smem + A.msync_off[i]);
             return v;
         }
     };
@@ -350,11 +356,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             return __builtin_amdgcn_readfirstlane(sum);
         } else {
             const uint32_t mine_off = ALG == ALG_BEC ? my_sync : my_msync;
-            if (lane == 0) *reinterpret_cast<volatile int32_t*>(smem + mine_off) = mine;
+            if (lane == 0) *lds_word(smem + mine_off) = (uint32_t)mine;
             wg_barrier();
             int sum = 0;
 #pragma unroll
-            for (int i = 0; i < NW; ++i) sum += *reinterpret_cast<volatile int32_t*>(smem + (ALG == ALG_BEC ? A.sync_off[i] : A.msync_off[i]));
+            for (int i = 0; i < NW; ++i) sum += (int)*lds_word(smem + (ALG == ALG_BEC ? A.sync_off[i] : A.msync_off[i]));
             return sum;
         }
     };
@@ -389,10 +395,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             wg_barrier();  // the verdict slots of the previous frame have been read by everybody
             if (w == 0) {
                 const long long f0 = next_frame();
-                if (lane == 0) *(SYS ? sysw(32) : reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0])) = (uint32_t)(int32_t)f0;
+                if (lane == 0) *(SYS ? sysw(32) : lds_word(smem + A.sync_off[0])) = (uint32_t)(int32_t)f0;
             }
             wg_barrier();
-            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*(SYS ? sysw(32) : reinterpret_cast<volatile uint32_t*>(smem + A.sync_off[0])));
+            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*(SYS ? sysw(32) : lds_word(smem + A.sync_off[0])));
         }
         if (fr_s < 0) break;
         const u64 fr = (u64)fr_s;
@@ -863,7 +869,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
     const int n = A.n, max_iter = A.max_iter;
     const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
     const bool own_last = !(NW > 1 && w == NW - 1) || lane < 32;  // the system words live in the upper half of the last marginal row
-    auto sysw = [&](int i) { return reinterpret_cast<volatile uint32_t*>(smem + A.sys_off) + i; };
+    auto sysw = [&](int i) { return lds_word(smem + A.sys_off) + i; };
     // table entries: 16-bit byte offsets, or -- frames beyond 64 KB of LDS (WIDE) -- 16-bit indices of 8-byte elements
     constexpr bool WIDE = (size_t)(VR * 64 + CRW * NW * DC * 64) * 8 > 65536;
     auto gat = [&](uint32_t entry) { return *reinterpret_cast<const double*>(smem + (WIDE ? (entry << 3) : entry)); };

@@ -356,3 +356,15 @@ def test_compiler_never_touches_m0_in_the_fused_kernels():
     assert stores > 1000, "ds_write_addtid_b32 stores not found in the library"
     assert not foreign, "M0 used outside lds_set_m0: %s" % foreign[:5]
     assert not consumers, "instructions that read M0 implicitly: %s" % consumers[:5]
+
+
+def test_fused_kernels_reach_their_hand_off_words_as_lds():
+    """Verdicts, frame numbers and error counts travel between the waves of a frame through LDS words (lds_word(),
+    csrc/ldpc_fused_kernels.hpp).  A generic pointer there compiles to flat_store / flat_load sc0 sc1 in the sweep loop's serial tail."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+
+    flat = kernel_resources.flat_report()
+    assert not flat, "flat accesses in the fused kernels: %s" % flat[:5]

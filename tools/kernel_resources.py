@@ -97,6 +97,23 @@ def m0_report(lib=DEFAULT_LIB):
     return stores, foreign, consumers
 
 
+def flat_report(lib=DEFAULT_LIB):
+    """flat_load / flat_store instructions in the code objects of the fused kernels (those with ds_write_addtid_b32 stores).  The words
+    the waves of a frame hand each other live in the LDS; reached through a generic pointer they become flat accesses (aperture check,
+    both counters to wait for) on the store -> barrier -> load chain that ends every sweep -- measured 3-10 % of the kernel time."""
+    blob = open(lib, "rb").read()
+    found = []
+    for _, co in code_objects(blob):
+        with tempfile.NamedTemporaryFile(suffix=".co") as fp:
+            fp.write(co)
+            fp.flush()
+            txt = subprocess.run([OBJDUMP, "-d", fp.name], capture_output=True, text=True).stdout
+        if "ds_write_addtid_b32" not in txt:
+            continue
+        found += [ln.split("//")[0].strip() for ln in txt.splitlines() if re.search(r"\bflat_(load|store)_", ln)]
+    return found
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=DEFAULT_LIB)
