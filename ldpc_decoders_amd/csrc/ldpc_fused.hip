@@ -170,7 +170,7 @@ ShapeChoice choose_shape(const Code* c, int alg, int dtype) {
     const std::vector<ShapeEntry>& kShapes = all_shapes();
     for (int i = 0; i < (int)kShapes.size() && out.si < 0; ++i) {
         const ShapeEntry& s = kShapes[i];
-        const int CR = s.CRW * s.NW, VR = s.VRW * s.NW;
+        const int CR = fused_check_rows(s), VR = s.VRW * s.NW;
         const bool big = s.NW > 4 || (s.NW > 1 && s.VRX > 0) || s.esz == 8;  // shapes with a system row: (half) a row of variable slots is reserved
         if (s.esz != want_esz) continue;
         if (s.alg != alg || c->max_dc != s.DC || c->m > CR * 64 || c->n + (short_rows ? 1 : 0) > VR * 64 - (big ? (s.esz == 8 ? 32 : 64) : 0)) continue;
@@ -201,7 +201,7 @@ ShapeChoice choose_shape(const Code* c, int alg, int dtype) {
 // (`moves` <= 0: $LDPC_FUSED_PLAN_MOVES / $LDPC_FUSED_PLAN_MS / the default), which is then kept in `save_dir` (if not empty).
 bool obtain_layout(const Code* c, const ShapeChoice& ch, bool use_store, long moves, const std::string& save_dir, FusedLayout* L) {
     const ShapeEntry& shape = all_shapes()[ch.si];
-    const int CR = shape.CRW * shape.NW;
+    const int CR = fused_check_rows(shape);
     const uint64_t key = layout_key(*c, shape.DC, CR, ch.vr, shape.NW);
     char name[40];
     snprintf(name, sizeof(name), "%016llx.plan", (unsigned long long)key);
@@ -281,7 +281,7 @@ int fused_plan_create(Decoder* d) {
     const std::vector<ShapeEntry>& kShapes = all_shapes();
     const ShapeEntry& shape = kShapes[si];
     const int DC = shape.DC, DV = shape.DV, NW = shape.NW, CRW = shape.CRW, VRW = shape.VRW;
-    const int CR = CRW * NW, VR = VRW * NW, NPAD = VR * 64;
+    const int CR = fused_check_rows(shape), VR = VRW * NW, NPAD = VR * 64;  // CR < CRW * NW: the last waves run fewer check rows
     const VarRounds& vr = ch.vr;
     const bool BIG = NW > 4;                         // dword-index tables, 160 KB frame
     const int esz = shape.esz;
@@ -313,7 +313,7 @@ int fused_plan_create(Decoder* d) {
     const int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
     std::vector<uint32_t> cn_tab((size_t)NW * CNW * 64, 0), vn_tab((size_t)NW * VNW * 64, 0);
     std::vector<int32_t> var_of_slot((size_t)NPAD, -1);
-    std::vector<u64> cn_active((size_t)CR, 0);
+    std::vector<u64> cn_active((size_t)CRW * NW, 0);  // indexed (wave, row of the wave); rows a wave does not have stay 0
     // global gather index K = R*DC + j (check side) or Q*DV + j (variable side) -> (wave, packed half-word) of the table
     auto put16 = [](std::vector<uint32_t>& tab, int words_per_wave, int per_wave, int K, int lane, uint32_t val) {
         const int wv = K / per_wave, k = K % per_wave;

@@ -21,7 +21,8 @@
 //   NW = 2: twice the resident waves per CU (the kernel is latency-bound at 2 waves per SIMD); one s_barrier after each
 //           phase, the syndrome verdicts of the waves are exchanged through padded c2v slots each wave owns.
 //   NW = 4: codes up to m = 1536 / n = 2816 (48 KB of LDS per frame, 3 frames per CU), same hand-off scheme.
-//           (NW = 4 with 3 check rounds per wave was measured for n = 1200: slower than NW = 2, 4.15 vs 3.74 ms.)
+//           (NW = 4 with 3 check rounds per wave was measured for n = 1200 in fp32: slower than NW = 2, 4.15 vs 3.74 ms.  The fp64
+//           kernel below does run n = 1200 with four waves -- on 10 check rows instead of 12, see fused_check_rows.)
 //
 // Arithmetic identical to the streaming backend / reference (src/bpa.py:17-63, 86-102): the leave-one-out minimum
 // equals "second minimum at the first arg-min, first minimum elsewhere"; min/compare/negate/add/sub only.
@@ -41,6 +42,15 @@ struct ShapeEntry {
     const void* kernel_sim;  // simulate: noise in the kernel, counters out (null: decode only)
     int esz = 4;             // bytes per LDS element: 4 (fp32 kernels), 8 (fp64 kernels)
 };
+// Rows of 64 check slots a frame holds in the LDS.  Normally CRW per wave.  The fp64 shapes of four and more waves for regular codes
+// keep only the rows a code can fill -- E = m DC <= n DV, hence m <= VR 64 DV / DC -- and the last wave(s) run fewer rows: the (3,6)
+// n = 1200 frame is 10 check rows + 20 marginal rows = 40 KB, four frames per CU, with FOUR waves each (rows 3 + 3 + 3 + 1) instead of two.
+constexpr int fused_check_rows(int esz, int DC, int DV, int CRW, int VRW, int NW, int VRX) {
+    const int all = CRW * NW, fill = (VRW * NW * DV + DC - 1) / DC;
+    return (esz == 8 && VRX == 0 && NW >= 4 && fill < all) ? fill : all;
+}
+inline int fused_check_rows(const ShapeEntry& s) { return fused_check_rows(s.esz, s.DC, s.DV, s.CRW, s.VRW, s.NW, s.VRX); }
+
 // shape tables, one per translation unit (built in parallel); preference order = table order
 const ShapeEntry* fused_shapes_f32_dc6(int* count);
 const ShapeEntry* fused_shapes_f32_dcx(int* count);
@@ -851,9 +861,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
 // SIM: channel + LLR in the kernel (Philox noise, the inline functions of the stand-alone channel kernels: bit-identical
 // priors) and error counting in the kernel -- priors and decisions never exist in HBM.
 template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const FusedArgs A) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const FusedArgs A) {
     static_assert(ALG == ALG_MSA || ALG == ALG_SPA, "LLR decoders");
     constexpr int VR = VRW * NW, NPAD = VR * 64;
+    constexpr int CRT = fused_check_rows(8, DC, DV, CRW, VRW, NW, VRX);  // check rows of the frame; < CRW * NW: the last waves run fewer rows
+    constexpr bool RAGGED = CRT != CRW * NW;
     constexpr int VNK = VRX * DVX + (VRW - VRX) * DV;  // gathers of a wave's variable phase: VRX wide rounds (irregular codes) first
     constexpr int VN0 = VRX * DVX, VRN = VRW - VRX;
     constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
@@ -871,7 +883,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
     const bool own_last = !(NW > 1 && w == NW - 1) || lane < 32;  // the system words live in the upper half of the last marginal row
     auto sysw = [&](int i) { return lds_word(smem + A.sys_off) + i; };
     // table entries: 16-bit byte offsets, or -- frames beyond 64 KB of LDS (WIDE) -- 16-bit indices of 8-byte elements
-    constexpr bool WIDE = (size_t)(VR * 64 + CRW * NW * DC * 64) * 8 > 65536;
+    constexpr bool WIDE = (size_t)(VR * 64 + CRT * DC * 64) * 8 > 65536;
+    const int my_rows = RAGGED ? (CRT - w * CRW < 0 ? 0 : (CRT - w * CRW < CRW ? CRT - w * CRW : CRW)) : CRW;  // wave-uniform
     auto gat = [&](uint32_t entry) { return *reinterpret_cast<const double*>(smem + (WIDE ? (entry << 3) : entry)); };
     if (threadIdx.x == 0) {  // the always-zero double (system-row bytes 136..143) that missing edges gather
         *sysw(34) = 0u;
@@ -883,7 +896,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
     for (int i = 0; i < CNW; ++i) cn_idx[i] = A.cn_tab[(w * CNW + i) * 64 + lane];
 #pragma unroll
     for (int i = 0; i < VNW; ++i) vn_idx[i] = A.vn_tab[(w * VNW + i) * 64 + lane];
-    int vmap[VRW];
+    int vmap[VRW];  // 128-VGPR shape: not kept, re-read from the (L1-resident) table where a frame starts and ends
     unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
     unsigned dummy = 0;  // bit q: the "certain" slot that pads short check rows (var_of_slot == -2): prior +inf
 #pragma unroll
@@ -892,6 +905,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
         valid |= vmap[q] >= 0 ? (1u << q) : 0u;
         dummy |= vmap[q] == -2 ? (1u << q) : 0u;
     }
+    auto vmap_at = [&](int q) -> int { if constexpr (NW == 4) return vslot[q * 64 + lane]; else return vmap[q]; };
+    if constexpr (NW == 4) asm volatile("" : "+v"(valid), "+v"(dummy));  // 128 VGPRs: one word each, not one register per tested bit
     unsigned cn_valid = 0;  // bit r: check slot (w*CRW + r, lane) holds a real check (padded lanes gather anything, see k_fused_bp)
 #pragma unroll
     for (int r = 0; r < CRW; ++r) cn_valid |= ((cn_active[r] >> lane) & 1ull) ? (1u << r) : 0u;
@@ -966,7 +981,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
         if constexpr (SIM) {
             // channel + LLR in the kernel: one Philox block = 4 consecutive variables, exactly as k_biawgn<double> / k_discrete<double>
             // do (same inline functions, same fp64 expressions -> bit-identical priors); every prior goes to the LDS slot of its variable
-            for (int blk = threadIdx.x; blk * 4 < n; blk += 64 * NW) {
+            int blk0 = threadIdx.x;
+            if constexpr (NW == 4) asm volatile("" : "+v"(blk0));  // 128 VGPRs: the per-lane addresses of this loop are recomputed per frame, not kept (spilled) across the sweeps
+            for (int blk = blk0; blk * 4 < n; blk += 64 * NW) {
                 const Philox4 ph = philox_word_block(A.seed, A.stream, A.frame0 + fr, (uint32_t)blk);
                 const int4 sl = *reinterpret_cast<const int4*>(A.slot_of_var + blk * 4);
                 const int slots[4] = {sl.x, sl.y, sl.z, sl.w};
@@ -997,7 +1014,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
         } else {
             const double* pf = priors + fr * n;
 #pragma unroll
-            for (int q = 0; q < VRW; ++q) prior[q] = vmap[q] >= 0 ? pf[vmap[q]] : (((dummy >> q) & 1u) ? __builtin_huge_val() : 0.0);
+            for (int q = 0; q < VRW; ++q) prior[q] = vmap_at(q) >= 0 ? pf[vmap_at(q)] : (((dummy >> q) & 1u) ? __builtin_huge_val() : 0.0);
         }
 #pragma unroll
         for (int r = 0; r < CRW; ++r)
@@ -1009,7 +1026,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
             const uint8_t* yf = A.y0 + fr * n;
 #pragma unroll
             for (int q = 0; q < VRW; ++q) {
-                const bool one = vmap[q] >= 0 && yf[vmap[q]] != 0;
+                const bool one = vmap_at(q) >= 0 && yf[vmap_at(q)] != 0;
                 if (q < VRW - 1 || own_last) my_marg[q * 64] = one ? -1.0 : 1.0;
                 xb |= one ? (1u << q) : 0u;
             }
@@ -1040,22 +1057,33 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
             phase_barrier();
             for (;;) {
                 if (max_iter > 0 && it >= max_iter) break;
+                if constexpr (NW == 4) {  // 128 VGPRs: the packed tables stay packed (unpacked once per use); hoisted out of the loop, the
+                                          // unpacked addresses would be spilled and re-read from scratch in every sweep
+#pragma unroll
+                    for (int i = 0; i < CNW; ++i) asm volatile("" : "+v"(cn_idx[i]));
+#pragma unroll
+                    for (int i = 0; i < VNW; ++i) asm volatile("" : "+v"(vn_idx[i]));
+                }
                 // ---- check phase (+ syndrome of the previous decisions: sign of the gathered marginals)
                 uint32_t synd = 0;   // min-sum: bit 31 = some owned check is unsatisfied (XOR of IEEE sign bits)
                 u64 synd_mask = 0;   // sum-product: lanes whose check is unsatisfied ((marginal < 0) compares: NaN counts as bit 0)
+                auto check_rows = [&](auto NR_) {
+                constexpr int NR = decltype(NR_)::value;
                 double mg[2][DC];
 #pragma unroll
                 for (int j = 0; j < DC; ++j) mg[0][j] = gat(half_of<CRW * DC>(cn_idx, j));
-                static_for<0, CRW>([&](auto R_) {
+                static_for<0, NR>([&](auto R_) {
                     constexpr int r = decltype(R_)::value;
-                    if constexpr (r + 1 < CRW) {
+                    constexpr int cur = r & 1, nxt = (r + 1) & 1;
+                    if constexpr (r + 1 < NR) {  // also for a row this wave does not have: its table entries are 0, one broadcast read
 #pragma unroll
-                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = gat(half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
+                        for (int j = 0; j < DC; ++j) mg[nxt][j] = gat(half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (RAGGED && r >= my_rows) return;  // (scalar branch) no branch between a row's gathers and the waits that count them
                     double v[DC];
 #pragma unroll
-                    for (int j = 0; j < DC; ++j) v[j] = mg[r & 1][j] - c2v_old[r][j];
+                    for (int j = 0; j < DC; ++j) v[j] = mg[cur][j] - c2v_old[r][j];
                     if constexpr (ALG == ALG_MSA) {
                         double a[DC];
                         uint32_t vx = 0, mx = 0;  // XOR of the sign words (high dwords); v is never -0.0 (marginals start from +0.0 sums)
@@ -1064,12 +1092,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
 #pragma unroll
                         for (int j = 0; j + 2 < DC; j += 3) {  // three inputs per instruction (v_bitop3_b32, truth table 0x96)
                             vx ^= xor3((uint32_t)__double2hiint(v[j]), (uint32_t)__double2hiint(v[j + 1]), (uint32_t)__double2hiint(v[j + 2]));
-                            mx ^= xor3((uint32_t)__double2hiint(mg[r & 1][j]), (uint32_t)__double2hiint(mg[r & 1][j + 1]), (uint32_t)__double2hiint(mg[r & 1][j + 2]));
+                            mx ^= xor3((uint32_t)__double2hiint(mg[cur][j]), (uint32_t)__double2hiint(mg[cur][j + 1]), (uint32_t)__double2hiint(mg[cur][j + 2]));
                         }
 #pragma unroll
                         for (int j = DC - DC % 3; j < DC; ++j) {
                             vx ^= (uint32_t)__double2hiint(v[j]);
-                            mx ^= (uint32_t)__double2hiint(mg[r & 1][j]);
+                            mx ^= (uint32_t)__double2hiint(mg[cur][j]);
                         }
                         synd |= mx & (cn_valid << (31 - r));  // bit 31 only is tested: the sign parity of a REAL check of this round
                         double mag[DC];
@@ -1106,7 +1134,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
                     } else {
                         u64 par = 0;
 #pragma unroll
-                        for (int j = 0; j < DC; ++j) par ^= __ballot(mg[r & 1][j] < 0.0);
+                        for (int j = 0; j < DC; ++j) par ^= __ballot(mg[cur][j] < 0.0);
                         synd_mask |= par & cn_active[r];
                         cn_spa<DC>(v, DC);  // the streaming kernel's rule, edges in canonical order (see the plan)
 #pragma unroll
@@ -1117,6 +1145,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
                         });
                     }
                 });
+                };
+                check_rows(std::integral_constant<int, CRW>{});
                 const bool unsat = any_unsat(ALG == ALG_MSA ? (__ballot((synd & 0x80000000u) != 0u) != 0) : (synd_mask != 0));
                 // it == 0: only the BSC checks the received word itself (src/bpa.py:20,29); in SIM mode marg holds +-llr there
                 if (early && (it > 0 || (SIM && A.sim_channel == CH_BSC)) && !unsat) break;
@@ -1206,12 +1236,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void k_fused_f64(const Fu
             uint8_t* xf = A.xhat + fr * n;
 #pragma unroll
             for (int q = 0; q < VRW; ++q)
-                if (vmap[q] >= 0) xf[vmap[q]] = (uint8_t)((xb >> q) & 1u);
+                if (vmap_at(q) >= 0) xf[vmap_at(q)] = (uint8_t)((xb >> q) & 1u);
             if (A.soft != nullptr) {  // marginals of the last executed sweep: still in this wave's LDS rows
                 double* sf = reinterpret_cast<double*>(A.soft) + fr * n;
 #pragma unroll
                 for (int q = 0; q < VRW; ++q)
-                    if (vmap[q] >= 0) sf[vmap[q]] = it > 0 ? my_marg[q * 64] : 0.0;
+                    if (vmap_at(q) >= 0) sf[vmap_at(q)] = it > 0 ? my_marg[q * 64] : 0.0;
             }
         }
     }

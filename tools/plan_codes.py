@@ -43,13 +43,15 @@ def main():
     ap.add_argument("--codes-dir", default=os.path.join(ROOT, "ldpc_decoders_amd", "data", "codes"))
     ap.add_argument("--jobs", type=int, default=max(1, (os.cpu_count() or 2) - 2))
     ap.add_argument("--nw", default="", help="LDPC_FUSED_NW: plan a non-default number of waves per frame")
+    ap.add_argument("--shapes", nargs="*", default=None, help="subset of MSA:f32 MSA:f64 SPA:f64 (default: all three)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     names = a.codes if a.codes is not None else sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(a.codes_dir, "*.txt")))
     env = dict(os.environ)
     if a.nw:
         env["LDPC_FUSED_NW"] = a.nw
-    todo = [(n, alg, prec) for n in names for alg, prec in SHAPES]
+    shapes = SHAPES if not a.shapes else [tuple(x.split(":")) for x in a.shapes]
+    todo = [(n, alg, prec) for n in names for alg, prec in shapes]
     running, rc = [], 0
     while todo or running:
         while todo and len(running) < a.jobs:
