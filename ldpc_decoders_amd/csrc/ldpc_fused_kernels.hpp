@@ -272,6 +272,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
     };
     if (A.zero_row && w == 0) reinterpret_cast<float*>(smem)[NPAD + CR * DC * 64 + lane] = 0.0f;  // the always-zero row
     const bool own_last = !(SYS && w == NW - 1);  // with a system row, wave NW-1 never writes its last marginal row
+    // the sign of an outgoing message is merged with ONE v_and_or_b32 (inline asm; the compiler emits v_and_b32 + v_or_b32 for the same
+    // expression in this kernel): the IEEE sign bit lives in a scalar register
+    const uint32_t sign_mask = 0x80000000u;
     auto sysw = [&](int i) { return lds_word(smem + A.sys_off) + i; };
     if constexpr (SYS) {
         if (threadIdx.x == 0) *sysw(33) = 0u;  // published by the barrier at the top of the frame loop
@@ -729,7 +732,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                         constexpr int j = decltype(J_)::value;
                         float mag;
                         if constexpr (ALG == ALG_MSA) mag = fminf(pre[j], suf[j]); else mag = spa_llr_of_eo(pre[j], preo[j], suf[j], sufo[j]);
-                        const float c = __uint_as_float(__float_as_uint(mag) | ((vx ^ __float_as_uint(v[j])) & 0x80000000u));
+                        float c;  // mag | ((vx ^ v[j]) & sign bit)
+                        if constexpr (ALG == ALG_MSA) asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(c) : "v"(vx ^ __float_as_uint(v[j])), "s"(sign_mask), "v"(mag));
+                        else c = __uint_as_float(__float_as_uint(mag) | ((vx ^ __float_as_uint(v[j])) & 0x80000000u));
                         c2v_old[r][j] = c;
                         if constexpr (!BIG) lds_st_tid<(r * DC + j) * 256>(c);
                     });

@@ -17,6 +17,7 @@ CASES=(
 )
 for C in "${CASES[@]}"; do
   NAME=${C%%|*}; ARGS=${C#*|}
+  [ -n "$ONLY" ] && ! [[ $NAME =~ $ONLY ]] && continue   # ONLY='c2_f32|c4_f32' tools/ab_sim.sh ...
   for rep in 1 2 3; do
     for V in "$@"; do
     LIB=$R/ldpc_decoders_amd/csrc/variants/libldpc_hip_$V.so
