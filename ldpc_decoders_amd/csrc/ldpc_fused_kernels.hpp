@@ -754,13 +754,15 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 // ---------------- variable phase
                 lds_set_m0(m0_marg);
                 xb = 0;
+                unsigned xr = 0;  // min-sum: the decision bits shifted in row after row (one v_alignbit_b32 each), bit-reversed once per sweep
                 // one variable: ordered sum from +0.0 (as scipy; keeps -0.0 out of the marginals), prior last, decision bit
                 auto finish_var = [&](auto Q_, float s) {
                     constexpr int q = decltype(Q_)::value;
                     const float m1 = prior[q] + s;
                     if (q < VRW - 1 || own_last) lds_st_tid<q * 256>(m1);
                     // decision: (m1 < 0); for min-sum the sign bit itself (m1 is never -0.0 and never NaN for finite priors)
-                    if constexpr (ALG == ALG_MSA) xb |= (__float_as_uint(m1) >> 31) << q; else xb |= (m1 < 0.0f) ? (1u << q) : 0u;
+                    if constexpr (ALG == ALG_MSA) xr = __builtin_amdgcn_alignbit(xr, __float_as_uint(m1), 31);  // (xr << 1) | sign: rows come in ascending q
+                    else xb |= (m1 < 0.0f) ? (1u << q) : 0u;
                 };
                 if constexpr (VRX > 0) {  // wide rounds of irregular codes: DVX gathers per variable, one round per stage
                     float cw[2][DVX];
@@ -806,6 +808,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                         }
                     });
                 });
+                if constexpr (ALG == ALG_MSA) xb = __brev(xr) >> (32 - VRW);  // bit q = row q again
                 if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
                 ++it;
             }
@@ -1157,12 +1160,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                 if (early && (it > 0 || (SIM && A.sim_channel == CH_BSC)) && !unsat) break;
                 // ---- variable phase: ordered sum from +0.0 (scipy COO), prior last, decision bit
                 xb = 0;
+                unsigned xr = 0;  // min-sum: decision bits shifted in row after row, bit-reversed once per sweep (as in k_fused_bp)
                 auto finish_var = [&](auto Q_, double sn) {
                     constexpr int q = decltype(Q_)::value;
                     const double m1 = prior[q] + sn;
                     if (q < VRW - 1 || own_last) lds_st64<q * 512>(marg_vaddr, m1);
                     // (m1 < 0).  Min-sum: the sign bit itself -- m1 is never -0.0 (sums start from +0.0) nor NaN for finite priors
-                    if constexpr (ALG == ALG_MSA) xb |= ((uint32_t)__double2hiint(m1) >> 31) << q; else xb |= (m1 < 0.0) ? (1u << q) : 0u;
+                    if constexpr (ALG == ALG_MSA) xr = __builtin_amdgcn_alignbit(xr, (uint32_t)__double2hiint(m1), 31);
+                    else xb |= (m1 < 0.0) ? (1u << q) : 0u;
                 };
                 if constexpr (VRX > 0) {  // wide rounds: DVX gathers per variable (missing edges read the zero double)
                     double cw[2][DVX];
@@ -1212,6 +1217,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                         }
                     });
                 });
+                if constexpr (ALG == ALG_MSA) xb = __brev(xr) >> (32 - VRW);
                 phase_barrier();
                 ++it;
             }
