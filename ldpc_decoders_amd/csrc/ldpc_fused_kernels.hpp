@@ -1120,15 +1120,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                         }
                         synd |= mx & (cn_valid << (31 - r));  // bit 31 only is tested: the sign parity of a REAL check of this round
                         double mag[DC];
-                        if constexpr (DC == 6) {  // 11 minimum instructions for the six leave-one-out minima
-                            const double s3 = fmin(a[4], a[5]), s2 = fmin(fmin(a[3], a[4]), a[5]), s1 = fmin(a[2], s2);
-                            const double p2 = fmin(a[0], a[1]), p3 = fmin(fmin(a[0], a[1]), a[2]);
-                            mag[0] = fmin(fmin(a[1], a[2]), s2);
-                            mag[1] = fmin(a[0], s1);
-                            mag[2] = fmin(p2, s2);
-                            mag[3] = fmin(p3, s3);
-                            mag[4] = fmin(fmin(p3, a[3]), a[5]);
-                            mag[5] = fmin(fmin(p3, a[3]), a[4]);
+                        if constexpr (DC == 6) {  // 12 two-input minima for the six leave-one-out minima (prefix p, suffix s; no v_min3_f64 exists)
+                            const double p2 = fmin(a[0], a[1]), p3 = fmin(p2, a[2]), p4 = fmin(p3, a[3]);
+                            const double s2 = fmin(a[4], a[5]), s3 = fmin(a[3], s2), s4 = fmin(a[2], s3);
+                            mag[0] = fmin(a[1], s4);
+                            mag[1] = fmin(a[0], s4);
+                            mag[2] = fmin(p2, s3);
+                            mag[3] = fmin(p3, s2);
+                            mag[4] = fmin(p4, a[5]);
+                            mag[5] = fmin(p4, a[4]);
                         } else {  // prefix / suffix minima: the leave-one-out minimum == "second minimum at the first arg-min, first elsewhere"
                             double pre[DC], suf[DC];
                             pre[0] = __builtin_huge_val();
