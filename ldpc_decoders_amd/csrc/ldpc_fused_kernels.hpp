@@ -715,13 +715,16 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                         pre[3] = fminf(p3, s3);                suf[3] = pre[3];
                         pre[4] = fminf(fminf(p3, a[3]), a[5]); suf[4] = pre[4];
                         pre[5] = fminf(fminf(p3, a[3]), a[4]); suf[5] = pre[5];
-                    } else if constexpr (ALG == ALG_MSA) {
-                        pre[0] = __builtin_huge_valf();
+                    } else if constexpr (ALG == ALG_MSA) {  // prefix / suffix minima, 3 DC - 6 instructions (no +inf seeds: fminf(inf, x) is not foldable)
+                        static_assert(DC >= 3, "prefix / suffix network");
+                        pre[1] = a[0];
 #pragma unroll
-                        for (int j = 1; j < DC; ++j) pre[j] = fminf(pre[j - 1], a[j - 1]);
-                        suf[DC - 1] = __builtin_huge_valf();
+                        for (int j = 2; j < DC; ++j) pre[j] = fminf(pre[j - 1], a[j - 1]);
+                        suf[DC - 2] = a[DC - 1];
 #pragma unroll
-                        for (int j = DC - 2; j >= 0; --j) suf[j] = fminf(suf[j + 1], a[j + 1]);
+                        for (int j = DC - 3; j >= 0; --j) suf[j] = fminf(suf[j + 1], a[j + 1]);
+                        pre[0] = suf[0];            // fminf(pre[j], suf[j]) below: the two ends are one-sided
+                        suf[DC - 1] = pre[DC - 1];
                     } else {
                         // sum-product: (E, O) pairs of prod (1 + u_i), prefix in (pre, preo), suffix in (suf, sufo) -- ldpc_cn.hpp
 #pragma unroll
@@ -1130,15 +1133,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                             mag[4] = fmin(p4, a[5]);
                             mag[5] = fmin(p4, a[4]);
                         } else {  // prefix / suffix minima: the leave-one-out minimum == "second minimum at the first arg-min, first elsewhere"
-                            double pre[DC], suf[DC];
-                            pre[0] = __builtin_huge_val();
+                            static_assert(DC >= 3, "prefix / suffix network");
+                            double pre[DC], suf[DC];  // 3 DC - 6 instructions (no +inf seeds: fmin(inf, x) is not foldable)
+                            pre[1] = a[0];
 #pragma unroll
-                            for (int j = 1; j < DC; ++j) pre[j] = fmin(pre[j - 1], a[j - 1]);
-                            suf[DC - 1] = __builtin_huge_val();
+                            for (int j = 2; j < DC; ++j) pre[j] = fmin(pre[j - 1], a[j - 1]);
+                            suf[DC - 2] = a[DC - 1];
 #pragma unroll
-                            for (int j = DC - 2; j >= 0; --j) suf[j] = fmin(suf[j + 1], a[j + 1]);
+                            for (int j = DC - 3; j >= 0; --j) suf[j] = fmin(suf[j + 1], a[j + 1]);
+                            mag[0] = suf[0];
+                            mag[DC - 1] = pre[DC - 1];
 #pragma unroll
-                            for (int j = 0; j < DC; ++j) mag[j] = fmin(pre[j], suf[j]);
+                            for (int j = 1; j < DC - 1; ++j) mag[j] = fmin(pre[j], suf[j]);
                         }
 #pragma unroll
                         for (int j = 0; j < DC; ++j) {
