@@ -667,20 +667,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                     // -0.0 here: marginals are built as prior + ((0.0 + c_a) + c_b + c_c) (see the variable phase).
                     float v[DC], a[DC];
                     uint32_t vx = 0, mx = 0;
-                    if constexpr (ALG == ALG_MSA && DC % 2 == 0) {  // explicit pairs: v_pk_add_f32 (the messages come out of inline asm, which the
-                                                                      // compiler's own vectoriser does not pair up)
-                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    // (six v_sub_f32: forcing the pairs back into v_pk_add_f32 with an explicit 2-vector subtraction -- the compiler stopped pairing
+                    // them when the messages became inline-asm outputs -- measured 1 % SLOWER on every fp32 shape, profiles/r03A_history.txt)
 #pragma unroll
-                        for (int j = 0; j < DC; j += 2) {
-                            const f32x2 m2 = {mg[r & 1][j], mg[r & 1][j + 1]}, o2 = {c2v_old[r][j], c2v_old[r][j + 1]};
-                            const f32x2 d2 = m2 - o2;
-                            v[j] = d2.x;
-                            v[j + 1] = d2.y;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < DC; ++j) v[j] = mg[r & 1][j] - c2v_old[r][j];
-                    }
+                    for (int j = 0; j < DC; ++j) v[j] = mg[r & 1][j] - c2v_old[r][j];
 #pragma unroll
                     for (int j = 0; j < DC; ++j) a[j] = __builtin_fabsf(v[j]);
                     // XOR of the raw words, three inputs per instruction (v_bitop3_b32, truth table 0x96)

@@ -3,6 +3,10 @@
 # with each library variant (tools/build_variant.sh), two runs each
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
+# a variant library lives in csrc/variants/: it would look for the shipped plans in csrc/plans (its own "../plans") and, not finding them,
+# anneal a short plan of its own -- a handicap of several per cent that has nothing to do with the code under test
+export LDPC_FUSED_PLAN_DIR=$R/ldpc_decoders_amd/plans
+export LDPC_FUSED_PLAN_SAVE=none
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 CASES=(
