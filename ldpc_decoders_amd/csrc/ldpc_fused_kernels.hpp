@@ -110,6 +110,21 @@ template <bool BIG>
 __device__ __forceinline__ float lds_gat(const unsigned char* base, uint32_t entry) {
     return *reinterpret_cast<const float*>(base + (BIG ? (entry << 2) : entry));
 }
+// gather through entry k of a packed table.  BIG: address = 4 * (16-bit half of the word) + base in ONE instruction (v_mad_u32_u16 with op_sel
+// picking the half) instead of and/shift + shift-add -- the 16-wave shape keeps all its tables packed (128 VGPRs) and unpacks 54 entries per sweep
+typedef __attribute__((address_space(3))) const float lds_cf32;
+template <bool BIG, int K, bool MAD = BIG>
+__device__ __forceinline__ float gat_tab(const unsigned char* base, const uint32_t (&tab)[(K + 1) / 2], int k) {
+    if constexpr (BIG && MAD) {
+        uint32_t addr;
+        const uint32_t b = (uint32_t)(uintptr_t)base;
+        if (k & 1) asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(addr) : "v"(tab[k >> 1]), "s"(b));
+        else asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(addr) : "v"(tab[k >> 1]), "s"(b));
+        return *(lds_cf32*)(uintptr_t)addr;
+    } else {
+        return lds_gat<BIG>(base, half_of<K>(tab, k));
+    }
+}
 // c2v store of the BIG shape: ds_write_addtid reaches M0[15:0] + 16-bit offset only, so rows beyond that use an address
 // register (lane-contiguous all the same; 4 instead of 2 store-path cycles)
 // Two rows per instruction: ds_write2st64_b32 stores a at vaddr + R0*256 and b at vaddr + R1*256 (offsets in units of 64 dwords
@@ -178,13 +193,14 @@ constexpr int sim_opaque_cn(int, int, int) { return LDPC_SIM_OPAQUE_CN_WORDS; }
 constexpr int sim_opaque_vn(int, int, int) { return LDPC_SIM_OPAQUE_VN_WORDS; }
 #else
 constexpr int sim_opaque_cn(int alg, int nw, int vrx) {
-    if (nw > 4) return alg == ALG_MSA ? 8 : 15;           // one frame per CU (16 waves): min-sum 8 + 15 -> no spill
-    if (vrx == 0) return alg == ALG_MSA ? 2 : (alg == ALG_BEC ? 8 : 15);  // regular shapes: min-sum 2 + 4, erasure 8 + 8, sum-product all
+    if (nw > 4) return alg == ALG_MSA ? 0 : 15;           // one frame per CU (16 waves): min-sum by the compiler's own allocation (see MAD in the kernel)
+    if (vrx == 0) return alg == ALG_MSA ? 2 : (alg == ALG_BEC ? 0 : 15);  // regular shapes: min-sum 2 + 4, sum-product all; erasure: the compiler's own
+                                                                          // allocation (9 spilled registers, 1.488 against 1.568 ms spill-free)
     return alg == ALG_BEC ? 8 : 15;                       // irregular shapes (wide variable rounds)
 }
 constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
-    if (nw > 4) return alg == ALG_BEC ? 0 : 15;           // (the 16-wave erasure kernel streams its variable table anyway)
-    if (vrx == 0) return alg == ALG_SPA ? 15 : (alg == ALG_BEC ? 8 : 4);
+    if (nw > 4) return alg == ALG_SPA ? 15 : 0;           // (the 16-wave erasure kernel streams its variable table anyway)
+    if (vrx == 0) return alg == ALG_SPA ? 15 : (alg == ALG_BEC ? 0 : 4);
     return alg == ALG_MSA ? 8 : 15;
 }
 #endif
@@ -271,6 +287,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
         if constexpr (VMAP_RESIDENT) return vmap_reg[q]; else return vslot[q * 64 + lane];
     };
     if (A.zero_row && w == 0) reinterpret_cast<float*>(smem)[NPAD + CR * DC * 64 + lane] = 0.0f;  // the always-zero row
+    // the 16-wave shape's gathers: one-instruction unpack (gat_tab) -- except in the min-sum Monte-Carlo kernel, where the compiler's own
+    // choice is measurably better still: it unpacks the variable-phase addresses once, spills 19 of them and reloads 13 per sweep from its
+    // private segment (13 scratch_load_dword on an otherwise idle vector-memory pipe instead of 47 unpack instructions): 17.86 ms against
+    // 18.70 (one-instruction unpack, no spill) and 19.10 (shift + add unpack, no spill) per 32 768 frames, profiles/r03C_spill_or_unpack.txt
+    constexpr bool MAD = BIG && !(ALG == ALG_MSA && SIM);
     const bool own_last = !(SYS && w == NW - 1);  // with a system row, wave NW-1 never writes its last marginal row
     // the sign of an outgoing message is merged with ONE v_and_or_b32 (inline asm; the compiler emits v_and_b32 + v_or_b32 for the same
     // expression in this kernel): the IEEE sign bit lives in a scalar register
@@ -508,12 +529,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 opaque_tables();
                 float mg[2][DC];
 #pragma unroll
-                for (int j = 0; j < DC; ++j) mg[0][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, j));
+                for (int j = 0; j < DC; ++j) mg[0][j] = gat_tab<BIG, CRW * DC, MAD>(smem, cn_idx, j);
                 static_for<0, CRW>([&](auto R_) {
                     constexpr int r = decltype(R_)::value;
                     if constexpr (r + 1 < CRW) {
 #pragma unroll
-                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
+                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = gat_tab<BIG, CRW * DC, MAD>(smem, cn_idx, (r + 1) * DC + j);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     // Everything is a small integer held in a float, so the rule is arithmetic, not compares (round 3: 15 -> 7 VALU
@@ -560,12 +581,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 if constexpr (VRX > 0) {
                     float cw[2][DVX];
 #pragma unroll
-                    for (int j = 0; j < DVX; ++j) cw[0][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, j));
+                    for (int j = 0; j < DVX; ++j) cw[0][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, j);
                     static_for<0, VRX>([&](auto Q_) {
                         constexpr int q = decltype(Q_)::value;
                         if constexpr (q + 1 < VRX) {
 #pragma unroll
-                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, (q + 1) * DVX + j));
+                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, (q + 1) * DVX + j);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         float sw = cw[q & 1][0];
@@ -579,7 +600,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 for (int u = 0; u < VG_BEC; ++u)
 #pragma unroll
                     for (int j = 0; j < DV; ++j)
-                        if (u < VRN) cv[0][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                        if (u < VRN) cv[0][u][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, VN0 + u * DV + j);
                 static_for<0, (VRN + VG_BEC - 1) / VG_BEC>([&](auto G_) {
                     constexpr int g = decltype(G_)::value;
                     if constexpr (g + 1 < (VRN + VG_BEC - 1) / VG_BEC) {
@@ -588,7 +609,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
 #pragma unroll
                             for (int j = 0; j < DV; ++j)
                                 if ((g + 1) * VG_BEC + u < VRN)
-                                    cv[(g + 1) & 1][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG_BEC + u) * DV + j));
+                                    cv[(g + 1) & 1][u][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, VN0 + ((g + 1) * VG_BEC + u) * DV + j);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     static_for<0, VG_BEC>([&](auto U_) {
@@ -630,7 +651,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             for (int r = 0; r < CRW; ++r) {
                 u64 par = 0;
 #pragma unroll
-                for (int j = 0; j < DC; ++j) par ^= __ballot(lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, r * DC + j)) < 0.0f);
+                for (int j = 0; j < DC; ++j) par ^= __ballot(gat_tab<BIG, CRW * DC, MAD>(smem, cn_idx, r * DC + j) < 0.0f);
                 unsat |= par & cn_active[r];  // padded check lanes read arbitrary marginals: masked out
             }
             left_at_0 = early && !any_unsat(unsat != 0);
@@ -653,12 +674,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 uint32_t synd = 0;  // bit 31: some owned check is unsatisfied by the previous decisions
                 float mg[2][DC];
 #pragma unroll
-                for (int j = 0; j < DC; ++j) mg[0][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, j));
+                for (int j = 0; j < DC; ++j) mg[0][j] = gat_tab<BIG, CRW * DC, MAD>(smem, cn_idx, j);
                 static_for<0, CRW>([&](auto R_) {
                     constexpr int r = decltype(R_)::value;
                     if constexpr (r + 1 < CRW) {
 #pragma unroll
-                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = lds_gat<BIG>(smem, half_of<CRW * DC>(cn_idx, (r + 1) * DC + j));
+                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = gat_tab<BIG, CRW * DC, MAD>(smem, cn_idx, (r + 1) * DC + j);
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this round's arithmetic
                     // Sign handling on the raw IEEE bits (bit 31), all in the vector ALU: row parity = XOR of the sign
@@ -771,12 +792,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 if constexpr (VRX > 0) {  // wide rounds of irregular codes: DVX gathers per variable, one round per stage
                     float cw[2][DVX];
 #pragma unroll
-                    for (int j = 0; j < DVX; ++j) cw[0][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, j));
+                    for (int j = 0; j < DVX; ++j) cw[0][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, j);
                     static_for<0, VRX>([&](auto Q_) {
                         constexpr int q = decltype(Q_)::value;
                         if constexpr (q + 1 < VRX) {
 #pragma unroll
-                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, (q + 1) * DVX + j));
+                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, (q + 1) * DVX + j);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         float sw = 0.0f + cw[q & 1][0];
@@ -790,7 +811,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 for (int u = 0; u < VG; ++u)
 #pragma unroll
                     for (int j = 0; j < DV; ++j)
-                        if (u < VRN) cv[0][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                        if (u < VRN) cv[0][u][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, VN0 + u * DV + j);
                 static_for<0, NVG>([&](auto G_) {
                     constexpr int g = decltype(G_)::value;
                     if constexpr (g + 1 < NVG) {
@@ -799,7 +820,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
 #pragma unroll
                             for (int j = 0; j < DV; ++j)
                                 if ((g + 1) * VG + u < VRN)
-                                    cv[(g + 1) & 1][u][j] = lds_gat<BIG>(smem, half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG + u) * DV + j));
+                                    cv[(g + 1) & 1][u][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, VN0 + ((g + 1) * VG + u) * DV + j);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     static_for<0, VG>([&](auto U_) {
@@ -1196,7 +1217,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                 // narrow rounds, VG of them per pipeline stage: the gathers of stage g+1 are in flight while stage g is summed.  Measured on
                 // the headline workload (min-sum, 65 536 frames x 49.4 sweeps): VG = 1 / 2 / 3 -> 6.37 / 6.28 / 6.21 ms; sum-product has no
                 // registers to spare (VG = 3 adds spills there)
+#ifdef LDPC_F64_NW4_VG  // experiment: variable rounds per pipeline stage of the four-wave shape
+                constexpr int VG = ALG == ALG_MSA ? (NW == 4 ? LDPC_F64_NW4_VG : 3) : 1;
+#else
                 constexpr int VG = ALG == ALG_MSA ? 3 : 1;
+#endif
                 constexpr int NVG = (VRN + VG - 1) / VG;
                 double cv[2][VG][DV];
 #pragma unroll

@@ -313,13 +313,20 @@ SIM_KERNELS_WITHOUT_SPILLS = [
     "k_fused_bp<0, 6, 3, 5, 10, 2, true, 0, 3>",    # config 2, fp32 min-sum, n = 1200 (3,6): the kernel `bench.py --precision f32` times
     "k_fused_f64<0, 6, 3, 3, 5, 4, true, 0, 3>",    # config 2, fp64 min-sum: the kernel `bench.py` times by default (four waves per frame)
     "k_fused_f64<0, 6, 3, 5, 10, 2, true, 0, 3>",   # its two-wave sibling (LDPC_FUSED_NW=2; the shape of fp64 sum-product)
-    "k_fused_bp<2, 6, 3, 5, 10, 2, true, 0, 3>",    # config 3, erasure decoder
     "k_fused_bp<1, 6, 3, 5, 10, 2, true, 0, 3>",    # config 3, fp32 sum-product (BSC / BI-AWGN)
-    "k_fused_bp<0, 6, 3, 5, 10, 16, true, 3, 8>",   # config 4, one frame per CU (rate-1/2 irregular n = 10 000)
     "k_fused_bp<0, 6, 3, 5, 10, 2, true, 2, 8>",    # irregular n = 1200 ensembles (1200_rho_x5_*), min-sum
     "k_fused_bp<0, 6, 3, 4, 8, 1, true, 0, 3>",     # n <= 512
     "k_fused_bp<0, 6, 3, 6, 11, 4, true, 0, 3>",    # Margulis n = 2640
 ]
+
+
+# Two Monte-Carlo kernels are deliberately NOT in that list: spill-free forms of both exist (round 3 shipped them) and are measurably
+# slower than the compiler's own allocation, which unpacks gather addresses once per frame, spills some and reloads them per sweep on the
+# otherwise idle vector-memory pipe (same-box, same plans, profiles/r03C_spill_or_unpack.txt).  Bounded here so that a regression shows.
+SIM_KERNELS_WITH_A_SPILL_BUDGET = {
+    "k_fused_bp<0, 6, 3, 5, 10, 16, true, 3, 8>": 24,  # config 4, one frame per CU: 19 spilled, 17.86 ms against 18.70 (spill-free) per 32 768 frames
+    "k_fused_bp<2, 6, 3, 5, 10, 2, true, 0, 3>": 12,   # config 3, erasure decoder: 9 spilled, 1.488 ms against 1.568 per 65 536 frames
+}
 
 
 def test_simulate_kernels_do_not_spill():
@@ -340,6 +347,11 @@ def test_simulate_kernels_do_not_spill():
         assert name in by_name, "kernel %s not in the library" % name
         r = by_name[name]
         assert r["spill"] == 0 and r["scratch"] == 0, "%s: %d spilled VGPRs, %d B of scratch per lane" % (name, r["spill"], r["scratch"])
+    for name, budget in SIM_KERNELS_WITH_A_SPILL_BUDGET.items():
+        assert name in by_name, "kernel %s not in the library" % name
+        assert by_name[name]["spill"] <= budget and by_name[name]["vgpr"] <= 128, "%s: %s" % (name, by_name[name])
+    for name in SIM_KERNELS_WITHOUT_SPILLS:
+        r = by_name[name]
         if (name.startswith("k_fused_bp") and (", 2, true" in name or ", 16, true" in name)) or name.startswith("k_fused_f64<0, 6, 3, 3, 5, 4"):
             assert r["vgpr"] <= 128  # four waves per SIMD: the occupancy the fp32 multi-wave shapes and the four-wave fp64 shape are built for
 
