@@ -5,5 +5,5 @@ d=json.loads(sys.stdin.readline()); print('%.4g frames/s  %.3f ms  %s' % (d['fra
 for rep in 1 2; do for P in f32 f64; do for C in gen:reg:1200:4:8 gen:reg:1200:3:4; do
 A="--code $C --alg MSA --channel biawgn --param 1.5 --batch 65536 --precision $P --launches 4"
 echo "$C $P new : $(run $A)"
-echo "$C $P head: $(LDPC_LIB_PATH=$R/ldpc_decoders_amd/csrc/variants/libldpc_hip_head.so run $A)"
+echo "$C $P head: $(LDPC_FUSED_PLAN_DIR=$R/ldpc_decoders_amd/plans LDPC_LIB_PATH=$R/ldpc_decoders_amd/csrc/variants/libldpc_hip_head.so run $A)"
 done; done; done
