@@ -194,13 +194,13 @@ constexpr int sim_opaque_vn(int, int, int) { return LDPC_SIM_OPAQUE_VN_WORDS; }
 #else
 constexpr int sim_opaque_cn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_MSA ? 0 : 15;           // one frame per CU (16 waves): min-sum by the compiler's own allocation (see MAD in the kernel)
-    if (vrx == 0) return alg == ALG_MSA ? 2 : (alg == ALG_BEC ? 0 : 15);  // regular shapes: min-sum 2 + 4, sum-product all; erasure: the compiler's own
+    if (vrx == 0) return alg == ALG_MSA ? 0 : (alg == ALG_BEC ? 0 : 15);  // regular shapes: min-sum 0 + 2, sum-product all; erasure: the compiler's own
                                                                           // allocation (9 spilled registers, 1.488 against 1.568 ms spill-free)
     return alg == ALG_BEC ? 8 : 15;                       // irregular shapes (wide variable rounds)
 }
 constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_SPA ? 15 : 0;           // (the 16-wave erasure kernel streams its variable table anyway)
-    if (vrx == 0) return alg == ALG_SPA ? 15 : (alg == ALG_BEC ? 0 : 4);
+    if (vrx == 0) return alg == ALG_SPA ? 15 : (alg == ALG_BEC ? 0 : 2);
     return alg == ALG_MSA ? 8 : 15;
 }
 #endif
