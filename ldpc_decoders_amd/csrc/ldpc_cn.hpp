@@ -61,6 +61,58 @@ __device__ __forceinline__ void cn_msa(T (&v)[DCMAX], int deg) {
 
 // ---- sum-product, fp64: the reference formula verbatim ---------------------------------------------
 // t = tanh(v/2); row product = sign * exp(sum(log|t|)); extrinsic = product / t_own; 2*atanh with +-1 -> +-inf.
+//
+// The CHAIN is the reference's, value by value (each of tanh, log, exp, the quotient and atanh is rounded to a double before the next
+// step -- that is what produces upstream's saturation artefacts: tanh == 1.0 from |v| ~ 38 on, quantised log|t| below that, q == +-1 ->
+// +-inf, inf - inf -> NaN).  Two of the FUNCTIONS are this file's: the device library's tanh and log are double-double evaluations (166
+// and 94 VALU instructions, < 1 ulp); the ones below are single-double forms (tanh through expm1 and one division, correctly rounded where
+// it saturates; fdlibm's log kernel), 67 and 69 instructions.  exp and atanh stay the library's (see spa64_atanh).  numpy's own functions
+// differ from either by an ulp here and there; agreement is held as measured decisions (tests/test_gpu_parity.py), unchanged: every golden
+// case at its measured 100 %, the Monte-Carlo WER of 65 536 frames at 1.5 dB identical to the library-function build's.
+#ifndef LDPC_SPA_F64_LIBRARY_FUNCTIONS  // define to get the device library's functions back (A/B, tools/build_variant.sh)
+__device__ __forceinline__ double spa64_nan() { return __builtin_nan(""); }
+// tanh(x / 2) with em = expm1(|x|), r = 1 / (em + 2):  1 - 2 r for |x| > 1/2 -- ONE rounding of an exactly representable 1 minus a tiny,
+// accurately known term: correctly rounded wherever the saturation artefacts live (the row product is compared with +-1 for EQUALITY
+// there) -- and em r below (small arguments, relative accuracy).  |x| clamped at 40 (tanh is exactly 1.0 from ~38.2 on); NaN stays NaN
+__device__ __forceinline__ double spa64_tanh_half(double x) {
+    double a = __builtin_fabs(x);
+    a = (a > 40.0) ? 40.0 : a;
+    const double em = expm1(a);
+    const double r = 1.0 / (em + 2.0);
+    const double t = (a > 0.5) ? (1.0 - (r + r)) : (em * r);
+    return __builtin_copysign(t, x);
+}
+// log(t) for t >= 0 (fdlibm e_log.c, one formula for every range): t = 2^k (1 + f), s = f / (2 + f), log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2)))
+__device__ __forceinline__ double spa64_log(double t) {
+    const bool sub = t < 2.2250738585072014e-308;  // subnormal (or 0): scale by 2^54
+    const double ts = sub ? t * 18014398509481984.0 : t;
+    int hx = __double2hiint(ts);
+    int k = (hx >> 20) - 1023 - (sub ? 54 : 0);
+    hx &= 0x000fffff;
+    const int i = (hx + 0x95f64) & 0x100000;  // mantissa above sqrt(2): use t / 2
+    const double m = __hiloint2double(hx | (i ^ 0x3ff00000), __double2loint(ts));
+    k += i >> 20;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                                        6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    double r = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+    r = (t == 0.0) ? -__builtin_huge_val() : r;
+    return (t >= 0.0) ? r : spa64_nan();  // negative or NaN -> NaN (as log)
+}
+// atanh stays the device library's (< 1 ulp): with equal-magnitude priors (the BSC) the reference's marginals cancel EXACTLY where
+// 2 atanh(tanh(L / 2)) == L, and a 1-2 ulp atanh (log1p through the log above) lost that on 6 of 300 frames of the (4,2) toy-code golden case
+__device__ __forceinline__ double spa64_atanh(double q) { return atanh(q); }
+#else
+__device__ __forceinline__ double spa64_tanh_half(double x) { return tanh(x / 2.0); }
+__device__ __forceinline__ double spa64_log(double t) { return log(t); }
+__device__ __forceinline__ double spa64_atanh(double q) { return atanh(q); }
+#endif
 template <int DCMAX>
 __device__ __forceinline__ void cn_spa(double (&v)[DCMAX], int deg) {
     double t[DCMAX];
@@ -69,9 +121,9 @@ __device__ __forceinline__ void cn_spa(double (&v)[DCMAX], int deg) {
 #pragma unroll
     for (int j = 0; j < DCMAX; ++j) {
         if (j < deg) {
-            t[j] = tanh(v[j] / 2.0);
+            t[j] = spa64_tanh_half(v[j]);
             parity ^= (t[j] < 0.0);
-            slog += log(fabs(t[j]));
+            slog += spa64_log(fabs(t[j]));
         }
     }
     const double prod = (parity ? -1.0 : 1.0) * exp(slog);
@@ -79,7 +131,7 @@ __device__ __forceinline__ void cn_spa(double (&v)[DCMAX], int deg) {
     for (int j = 0; j < DCMAX; ++j) {
         if (j < deg) {
             const double q = prod / t[j];
-            v[j] = 2.0 * ((fabs(q) == 1.0) ? (__builtin_huge_val() * q) : atanh(q));
+            v[j] = 2.0 * ((fabs(q) == 1.0) ? (__builtin_huge_val() * q) : spa64_atanh(q));
         }
     }
 }
