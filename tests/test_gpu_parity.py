@@ -473,6 +473,35 @@ def test_fp64_min_sum_on_the_lds_kernel():
     assert (i3.cpu().numpy() == 3).all()
 
 
+@pytest.mark.parametrize("code_name", ["1200_3_6_rand_ldpc_1", "512_3_6_rand_ldpc_2", "1200_3_6_ldpc"])
+def test_fp64_two_and_four_waves_per_frame_agree(code_name, monkeypatch):
+    # the four-wave fp64 min-sum shape (10 check rows, last wave short: csrc fused_check_rows) against its two-wave sibling and the C oracle:
+    # decisions and iteration counts of ragged batches, then the in-kernel Monte-Carlo counters (same Philox frames)
+    import torch
+    from ldpc_decoders_amd import bpa
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    g, code = _code(code_name)
+    rng = np.random.RandomState(5)
+    y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(1.8)), (333, g.n))
+    pri = O.biawgn_priors(y, 1.8)
+    xo, io = C.bp_decode(g, "MSA", None, pri, 50, dtype=np.float64)
+    out, counters = {}, {}
+    for nw in ("2", "4"):
+        monkeypatch.setenv("LDPC_FUSED_NW", nw)
+        dec = bpa.MSA(code, max_iter=50, precision="f64", backend="fused")
+        assert dec.handle.fused_info()["waves_per_frame"] == float(nw)
+        out[nw] = dec.decode_batch(None, pri)
+        assert (out[nw][0] == xo).all() and (out[nw][1] == io).all()
+        h = DecoderHandle(code, "MSA", "f64", "fused")
+        cnt = torch.zeros(4 + 51, dtype=torch.int64, device="cuda")
+        h.simulate("biawgn", 1.5, 0, 11, 0, 0, 20000, 50, cnt, hist_bins=51)
+        counters[nw] = cnt.cpu().numpy()
+    monkeypatch.delenv("LDPC_FUSED_NW")
+    assert (counters["2"] == counters["4"]).all() and counters["4"][0] == 20000 and counters["4"][1] > 0
+    assert bpa.MSA(code, max_iter=50, precision="f64").handle.fused_info()["waves_per_frame"] == 4.0  # what "auto" picks
+
+
 @pytest.mark.parametrize("code_name", ["1200_3_6_rand_ldpc_1", "1200_rho_x5_rand_ldpc_5", "margulis"])
 def test_fp64_lds_kernel_is_deterministic(code_name):
     # repeated decodes of one resident batch on the multi-wave fp64 kernels (2 and 8 waves per frame): identical outputs
