@@ -64,9 +64,9 @@ __device__ __forceinline__ void cn_msa(T (&v)[DCMAX], int deg) {
 //
 // The CHAIN is the reference's, value by value (each of tanh, log, exp, the quotient and atanh is rounded to a double before the next
 // step -- that is what produces upstream's saturation artefacts: tanh == 1.0 from |v| ~ 38 on, quantised log|t| below that, q == +-1 ->
-// +-inf, inf - inf -> NaN).  Two of the FUNCTIONS are this file's: the device library's tanh and log are double-double evaluations (166
-// and 94 VALU instructions, < 1 ulp); the ones below are single-double forms (tanh through expm1 and one division, correctly rounded where
-// it saturates; fdlibm's log kernel), 67 and 69 instructions.  exp and atanh stay the library's (see spa64_atanh).  numpy's own functions
+// +-inf, inf - inf -> NaN).  Three of the FUNCTIONS are this file's: the device library's tanh, log and atanh are double-double evaluations
+// (166 / 94 / 160 VALU instructions, < 1 ulp); the ones below are single-double forms (tanh through expm1 and one division, correctly rounded where
+// it saturates; fdlibm's log kernel; fdlibm's atanh through its log1p), 67 / 69 / ~95 instructions.  exp stays the library's.  numpy's own functions
 // differ from either by an ulp here and there; agreement is held as measured decisions (tests/test_gpu_parity.py), unchanged: every golden
 // case at its measured 100 %, the Monte-Carlo WER of 65 536 frames at 1.5 dB identical to the library-function build's.
 #ifndef LDPC_SPA_F64_LIBRARY_FUNCTIONS  // define to get the device library's functions back (A/B, tools/build_variant.sh)
@@ -105,9 +105,57 @@ __device__ __forceinline__ double spa64_log(double t) {
     r = (t == 0.0) ? -__builtin_huge_val() : r;
     return (t >= 0.0) ? r : spa64_nan();  // negative or NaN -> NaN (as log)
 }
-// atanh stays the device library's (< 1 ulp): with equal-magnitude priors (the BSC) the reference's marginals cancel EXACTLY where
-// 2 atanh(tanh(L / 2)) == L, and a 1-2 ulp atanh (log1p through the log above) lost that on 6 of 300 frames of the (4,2) toy-code golden case
-__device__ __forceinline__ double spa64_atanh(double q) { return atanh(q); }
+// log1p(x) for x >= 0: fdlibm s_log1p.c operation by operation (its branches as selects): below 0.41422 the argument itself is f (no
+// rounding of 1 + x at all), otherwise u = fl(1 + x) = 2^k (1 + f) with the correction c = (rounding error of 1 + x) / u carried beside k ln2_lo
+// (c is a correction of a correction: multiplied by rcp(u) instead of divided)
+__device__ __forceinline__ double spa64_log1p(double x) {
+    const int hx = __double2hiint(x);
+    const bool small = hx < 0x3FDA827A;
+    const bool exact1 = x < 9007199254740992.0;  // 1 + x still has the bits of x
+    const double u = exact1 ? 1.0 + x : x;
+    int hu = __double2hiint(u);
+    int k = (hu >> 20) - 1023;
+    double c = ((k > 0) ? 1.0 - (u - x) : x - (u - 1.0)) * __builtin_amdgcn_rcp(u);
+    c = exact1 ? c : 0.0;
+    hu &= 0x000fffff;
+    const bool lowm = hu < 0x6a09e;  // mantissa below sqrt(2)
+    const double un = __hiloint2double(hu | (lowm ? 0x3ff00000 : 0x3fe00000), __double2loint(u));
+    k = lowm ? k : k + 1;
+    int hz = lowm ? hu : ((0x00100000 - hu) >> 2);  // == 0: |f| < 2^-20
+    const double f = small ? x : un - 1.0;
+    k = small ? 0 : k;
+    c = small ? 0.0 : c;
+    hz = small ? 1 : hz;
+    const double dk = (double)k;
+    const double hfsq = 0.5 * f * f;
+    const double R0 = hfsq * (1.0 - 0.66666666666666666 * f);
+    const double r0 = (k == 0) ? f - R0 : dk * 6.93147180369123816490e-01 - ((R0 - (dk * 1.90821492927058770002e-10 + c)) - f);
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double R = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.479819860511658591e-01,
+                     1.531383769920937332e-01), 1.818357216161805012e-01), 2.222219843214978396e-01), 2.857142874366239149e-01), 3.999999999940941908e-01),
+                     6.666666666666735130e-01);  // the polynomial alone in fused multiply-adds (a correction term: its last bit never reaches the result's)
+    const double r1 = (k == 0) ? f - (hfsq - s * (hfsq + R))
+                               : dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + (dk * 1.90821492927058770002e-10 + c))) - f);
+    double r = (hz == 0) ? r0 : r1;
+    const int ax = hx & 0x7fffffff;
+    r = (ax < 0x3e200000) ? ((ax < 0x3c900000) ? x : x - x * x * 0.5) : r;  // |x| < 2^-29
+    return r;
+}
+// atanh: fdlibm e_atanh.c (0.5 log1p(2a + 2a a / (1 - a)) below 1/2, 0.5 log1p(2a / (1 - a)) above; one division serves both).  NOT a 1-2
+// ulp shortcut: over the BSC all priors are +-L and upstream's marginals cancel EXACTLY wherever 2 atanh(tanh(L / 2)) == L -- log1p through
+// the plain log above lost that on 6 of the 300 frames of the reference's bsc-4_2_test case, on the GPU and in a numpy model of these
+// functions alike; this form passes every golden case in the model and here.  |q| > 1 or NaN -> NaN, as atanh.
+__device__ __forceinline__ double spa64_atanh(double q) {
+    const double a = __builtin_fabs(q);
+    const bool lo = a < 0.5;
+    const double t2 = a + a;
+    const double quot = (lo ? t2 * a : t2) / (1.0 - a);
+    double t = 0.5 * spa64_log1p(lo ? t2 + quot : quot);
+    t = (a < 3.7252902984619140625e-09) ? a : t;  // |q| < 2^-28
+    t = (a <= 1.0) ? t : spa64_nan();             // |q| > 1 or NaN (|q| == 1 is taken out by the caller)
+    return __builtin_copysign(t, q);
+}
 #else
 __device__ __forceinline__ double spa64_tanh_half(double x) { return tanh(x / 2.0); }
 __device__ __forceinline__ double spa64_log(double t) { return log(t); }
