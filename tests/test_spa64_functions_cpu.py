@@ -135,12 +135,10 @@ def decode_case(path, atanh_fn, monkeypatch):
     return same, (it[keep][conv] == c["iters"][keep][conv])
 
 
-FAST = ["bsc_SPA_4_2_test_0p1", "bsc_SPA_12_3_4_ldpc_0p1", "biawgn_SPA_7_4_hamming_2p0", "bsc_SPA_1200_rho_x5_rand_ldpc_5_0p06", "biawgn_SPA_1200_rho_x5_rand_ldpc_5_2p0"]
-ALL = sorted(p for p in glob.glob(os.path.join(GOLDEN, "decode_*_SPA_*.npz")) if "decode_bec_" not in p)
-CASES = ALL if os.environ.get("LDPC_TEST_ALL_SPA64_MODEL_CASES") == "1" else [p for p in ALL if any(k in p for k in FAST)]
+ALL = sorted(p for p in glob.glob(os.path.join(GOLDEN, "decode_*_SPA_*.npz")) if "decode_bec_" not in p)  # 18 cases, 2 770 frames, ~10 s
 
 
-@pytest.mark.parametrize("path", CASES, ids=case_id)
+@pytest.mark.parametrize("path", ALL, ids=case_id)
 def test_kernel_functions_keep_every_golden_frame(path, monkeypatch):
     same, it_same = decode_case(path, atanh_fdlibm, monkeypatch)
     assert same.all() and it_same.all()
