@@ -891,6 +891,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
 // Check degrees DC in 4..8, NW waves per frame with the system-row hand-off protocol of the big fp32 shapes (upper half of the last marginal row
 // reserved: dwords [0,16) verdict channel A, [16,32) channel B, [32] frame hand-out, [34,36) an always-zero double).  Same tables
 // and layout plan as the fp32 kernels with 8-byte elements; gathers are ds_read_b64 (2 LDS cycles, as b32), stores ds_write_b64.
+// NW = 4 (min-sum, n = 1200): the frame keeps only the check rows a code can fill (fused_check_rows), the last wave runs fewer rows, the
+// register budget is 128 (tables stay packed, see the opaque words at the top of the sweep).
 // SIM: channel + LLR in the kernel (Philox noise, the inline functions of the stand-alone channel kernels: bit-identical
 // priors) and error counting in the kernel -- priors and decisions never exist in HBM.
 template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
