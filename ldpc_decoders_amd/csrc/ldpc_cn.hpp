@@ -105,12 +105,11 @@ __device__ __forceinline__ double spa64_log(double t) {
     r = (t == 0.0) ? -__builtin_huge_val() : r;
     return (t >= 0.0) ? r : spa64_nan();  // negative or NaN -> NaN (as log)
 }
-// log1p(x) for x >= 0: fdlibm s_log1p.c operation by operation (its branches as selects): below 0.41422 the argument itself is f (no
-// rounding of 1 + x at all), otherwise u = fl(1 + x) = 2^k (1 + f) with the correction c = (rounding error of 1 + x) / u carried beside k ln2_lo
-// (c is a correction of a correction: multiplied by rcp(u) instead of divided)
+// log1p(x) for x >= 0: fdlibm s_log1p.c (its range branches as selects; its two shortcut branches -- |f| < 2^-20 and |x| < 2^-29, which only
+// save work there -- left out): below 0.41422 the argument itself is f (no rounding of 1 + x at all), otherwise u = fl(1 + x) = 2^k (1 + f) with
+// the correction c = (rounding error of 1 + x) / u carried beside k ln2_lo (c is a correction of a correction: multiplied by rcp(u), not divided)
 __device__ __forceinline__ double spa64_log1p(double x) {
-    const int hx = __double2hiint(x);
-    const bool small = hx < 0x3FDA827A;
+    const bool small = __double2hiint(x) < 0x3FDA827A;
     const bool exact1 = x < 9007199254740992.0;  // 1 + x still has the bits of x
     const double u = exact1 ? 1.0 + x : x;
     int hu = __double2hiint(u);
@@ -121,26 +120,18 @@ __device__ __forceinline__ double spa64_log1p(double x) {
     const bool lowm = hu < 0x6a09e;  // mantissa below sqrt(2)
     const double un = __hiloint2double(hu | (lowm ? 0x3ff00000 : 0x3fe00000), __double2loint(u));
     k = lowm ? k : k + 1;
-    int hz = lowm ? hu : ((0x00100000 - hu) >> 2);  // == 0: |f| < 2^-20
     const double f = small ? x : un - 1.0;
     k = small ? 0 : k;
     c = small ? 0.0 : c;
-    hz = small ? 1 : hz;
     const double dk = (double)k;
     const double hfsq = 0.5 * f * f;
-    const double R0 = hfsq * (1.0 - 0.66666666666666666 * f);
-    const double r0 = (k == 0) ? f - R0 : dk * 6.93147180369123816490e-01 - ((R0 - (dk * 1.90821492927058770002e-10 + c)) - f);
     const double s = f / (2.0 + f);
     const double z = s * s;
     const double R = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.479819860511658591e-01,
                      1.531383769920937332e-01), 1.818357216161805012e-01), 2.222219843214978396e-01), 2.857142874366239149e-01), 3.999999999940941908e-01),
                      6.666666666666735130e-01);  // the polynomial alone in fused multiply-adds (a correction term: its last bit never reaches the result's)
-    const double r1 = (k == 0) ? f - (hfsq - s * (hfsq + R))
-                               : dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + (dk * 1.90821492927058770002e-10 + c))) - f);
-    double r = (hz == 0) ? r0 : r1;
-    const int ax = hx & 0x7fffffff;
-    r = (ax < 0x3e200000) ? ((ax < 0x3c900000) ? x : x - x * x * 0.5) : r;  // |x| < 2^-29
-    return r;
+    return (k == 0) ? f - (hfsq - s * (hfsq + R))
+                    : dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + (dk * 1.90821492927058770002e-10 + c))) - f);
 }
 // atanh: fdlibm e_atanh.c (0.5 log1p(2a + 2a a / (1 - a)) below 1/2, 0.5 log1p(2a / (1 - a)) above; one division serves both).  NOT a 1-2
 // ulp shortcut: over the BSC all priors are +-L and upstream's marginals cancel EXACTLY wherever 2 atanh(tanh(L / 2)) == L -- log1p through
@@ -152,8 +143,7 @@ __device__ __forceinline__ double spa64_atanh(double q) {
     const double t2 = a + a;
     const double quot = (lo ? t2 * a : t2) / (1.0 - a);
     double t = 0.5 * spa64_log1p(lo ? t2 + quot : quot);
-    t = (a < 3.7252902984619140625e-09) ? a : t;  // |q| < 2^-28
-    t = (a <= 1.0) ? t : spa64_nan();             // |q| > 1 or NaN (|q| == 1 is taken out by the caller)
+    t = (a <= 1.0) ? t : spa64_nan();  // |q| > 1 or NaN (|q| == 1 is taken out by the caller)
     return __builtin_copysign(t, q);
 }
 #else

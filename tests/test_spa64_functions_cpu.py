@@ -59,10 +59,9 @@ def log_pos(t):  # spa64_log (fma-free evaluation of the polynomial: the model's
     return np.where(t >= 0.0, r, np.nan)
 
 
-def log1p_pos(x):  # spa64_log1p == fdlibm s_log1p.c for x >= 0
+def log1p_pos(x):  # spa64_log1p == fdlibm s_log1p.c for x >= 0 without its two shortcut branches (c divided here, times rcp on the device)
     x = np.asarray(x, dtype=np.float64)
-    hx = _hi(x)
-    small = hx < 0x3FDA827A
+    small = _hi(x) < 0x3FDA827A
     exact1 = x < 9007199254740992.0
     u = np.where(exact1, 1.0 + x, x)
     hu = _hi(u)
@@ -73,22 +72,15 @@ def log1p_pos(x):  # spa64_log1p == fdlibm s_log1p.c for x >= 0
     lowm = hu < 0x6a09e
     un = np.where(lowm, _with_hi(u, hu | 0x3ff00000), _with_hi(u, hu | 0x3fe00000))
     k = np.where(lowm, k, k + 1)
-    hz = np.where(lowm, hu, (0x00100000 - hu) >> 2)
     f = np.where(small, x, un - 1.0)
     k = np.where(small, 0, k)
     c = np.where(small, 0.0, c)
-    hz = np.where(small, 1, hz)
     dk = k.astype(np.float64)
     hfsq = 0.5 * f * f
-    R0 = hfsq * (1.0 - 0.66666666666666666 * f)
-    r0 = np.where(k == 0, f - R0, dk * LN2_HI - ((R0 - (dk * LN2_LO + c)) - f))
     s = f / (2.0 + f)
     z = s * s
     R = z * (LG[0] + z * (LG[1] + z * (LG[2] + z * (LG[3] + z * (LG[4] + z * (LG[5] + z * LG[6]))))))
-    r1 = np.where(k == 0, f - (hfsq - s * (hfsq + R)), dk * LN2_HI - ((hfsq - (s * (hfsq + R) + (dk * LN2_LO + c))) - f))
-    r = np.where(hz == 0, r0, r1)
-    ax = hx & 0x7fffffff
-    return np.where(ax < 0x3e200000, np.where(ax < 0x3c900000, x, x - x * x * 0.5), r)
+    return np.where(k == 0, f - (hfsq - s * (hfsq + R)), dk * LN2_HI - ((hfsq - (s * (hfsq + R) + (dk * LN2_LO + c))) - f))
 
 
 def atanh_fdlibm(q):  # spa64_atanh
@@ -98,7 +90,6 @@ def atanh_fdlibm(q):  # spa64_atanh
     with np.errstate(all="ignore"):
         quot = np.where(lo, t2 * a, t2) / (1.0 - a)
         t = 0.5 * log1p_pos(np.where(lo, t2 + quot, quot))
-    t = np.where(a < 3.7252902984619140625e-09, a, t)
     t = np.where(a <= 1.0, t, np.nan)
     return np.copysign(t, q)
 
