@@ -82,7 +82,7 @@ __device__ __forceinline__ double spa64_tanh_half(double x) {
     const double t = (a > 0.5) ? (1.0 - (r + r)) : (em * r);
     return __builtin_copysign(t, x);
 }
-// log(t) for t >= 0 (fdlibm e_log.c, one formula for every range): t = 2^k (1 + f), s = f / (2 + f), log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2)))
+// log(t) for finite t >= 0 or NaN (fdlibm e_log.c, one formula for every range): t = 2^k (1 + f), s = f / (2 + f), log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2)))
 __device__ __forceinline__ double spa64_log(double t) {
     const bool sub = t < 2.2250738585072014e-308;  // subnormal (or 0): scale by 2^54
     const double ts = sub ? t * 18014398509481984.0 : t;
@@ -103,7 +103,8 @@ __device__ __forceinline__ double spa64_log(double t) {
     const double hfsq = 0.5 * f * f;
     double r = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
     r = (t == 0.0) ? -__builtin_huge_val() : r;
-    return (t >= 0.0) ? r : spa64_nan();  // negative or NaN -> NaN (as log)
+    return r + (t - t);  // NaN -> NaN by arithmetic (t - t is 0 for every finite t): a select here is compiled into a branch AROUND the whole
+                         // evaluation, and thirty such regions per check phase keep the six edges of a row from being interleaved
 }
 // log1p(x) for x >= 0: fdlibm s_log1p.c (its range branches as selects; its two shortcut branches -- |f| < 2^-20 and |x| < 2^-29, which only
 // save work there -- left out): below 0.41422 the argument itself is f (no rounding of 1 + x at all), otherwise u = fl(1 + x) = 2^k (1 + f) with
@@ -130,8 +131,10 @@ __device__ __forceinline__ double spa64_log1p(double x) {
     const double R = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.479819860511658591e-01,
                      1.531383769920937332e-01), 1.818357216161805012e-01), 2.222219843214978396e-01), 2.857142874366239149e-01), 3.999999999940941908e-01),
                      6.666666666666735130e-01);  // the polynomial alone in fused multiply-adds (a correction term: its last bit never reaches the result's)
-    return (k == 0) ? f - (hfsq - s * (hfsq + R))
-                    : dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + (dk * 1.90821492927058770002e-10 + c))) - f);
+    double r0 = f - (hfsq - s * (hfsq + R));
+    double rk = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + (dk * 1.90821492927058770002e-10 + c))) - f);
+    asm volatile("" : "+v"(r0), "+v"(rk));  // both evaluated, then selected: no branch (see spa64_log)
+    return (k == 0) ? r0 : rk;
 }
 // atanh: fdlibm e_atanh.c (0.5 log1p(2a + 2a a / (1 - a)) below 1/2, 0.5 log1p(2a / (1 - a)) above; one division serves both).  NOT a 1-2
 // ulp shortcut: over the BSC all priors are +-L and upstream's marginals cancel EXACTLY wherever 2 atanh(tanh(L / 2)) == L -- log1p through
@@ -143,6 +146,7 @@ __device__ __forceinline__ double spa64_atanh(double q) {
     const double t2 = a + a;
     const double quot = (lo ? t2 * a : t2) / (1.0 - a);
     double t = 0.5 * spa64_log1p(lo ? t2 + quot : quot);
+    asm volatile("" : "+v"(t));        // evaluated for every lane: no branch around it (see spa64_log)
     t = (a <= 1.0) ? t : spa64_nan();  // |q| > 1 or NaN (|q| == 1 is taken out by the caller)
     return __builtin_copysign(t, q);
 }
@@ -169,7 +173,13 @@ __device__ __forceinline__ void cn_spa(double (&v)[DCMAX], int deg) {
     for (int j = 0; j < DCMAX; ++j) {
         if (j < deg) {
             const double q = prod / t[j];
+#ifndef LDPC_SPA_F64_LIBRARY_FUNCTIONS
+            double at = spa64_atanh(q);  // at |q| == 1 its value is discarded (2 / 0 = inf inside: no trap, no NaN test on it)
+            asm volatile("" : "+v"(at));
+            v[j] = 2.0 * ((fabs(q) == 1.0) ? (__builtin_huge_val() * q) : at);
+#else
             v[j] = 2.0 * ((fabs(q) == 1.0) ? (__builtin_huge_val() * q) : spa64_atanh(q));
+#endif
         }
     }
 }
