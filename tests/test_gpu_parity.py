@@ -172,6 +172,52 @@ def test_soft_llr_tolerance(path, alg, prec, backend, rtol):
     print("soft LLR %s %s %s %s: worst |dev-ref|/(1+|ref|) = %.3g (bar %.3g)" % (case_id(path), alg, prec, backend, worst, rtol))
 
 
+@pytest.mark.parametrize("backend", ["stream", "fused"])
+def test_spa_fp64_special_priors(backend):
+    # the fp64 sum-product rule on inputs its own tanh / log / atanh (csrc/ldpc_cn.hpp spa64_*) must treat as the reference's libm does:
+    # zeros (log 0 = -inf -> NaN / 0 artefacts), saturating and infinite LLRs (tanh == 1, q == +-1 -> +-inf, inf - inf = NaN), NaN itself, tiny
+    # and huge magnitudes -- marginals after one and two sweeps against the numpy oracle, NaN / inf patterns included
+    import torch
+    from ldpc_decoders_amd import bpa
+
+    g, code = _code("1200_3_6_rand_ldpc_1")
+    rng = np.random.RandomState(12)
+    B = 48
+    pri = O.biawgn_priors(-1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(2.0)), (B, g.n)), 2.0)
+    specials = [0.0, -0.0, np.inf, -np.inf, 1e300, -1e300, 1e-300, 4e-320, 37.0, 38.5, 40.5, 745.0, 1e-9, 0.49999, 0.5, 0.5000001, np.nan]
+    for f in range(B):
+        pos = rng.choice(g.n, size=60, replace=False)
+        pri[f, pos] = rng.choice(specials, size=60)
+    pri[0] = 0.0
+    pri[1] = np.inf
+    pri[2, ::2] = -np.inf
+    clean = np.ones(B, dtype=bool)  # frames whose marginals were finite-for-finite so far (a NaN-vs-inf difference, below, feeds the next sweep)
+    for sweeps in (1, 2):
+        dec = bpa.SPA(code, max_iter=sweeps, precision="f64", backend=backend)
+        _, iters, marg = dec.handle.decode_soft_device(torch.from_numpy(pri).cuda(), None, sweeps, flags=1)
+        assert dec.handle.last_stats()[0] == backend and (iters.cpu().numpy() == sweeps).all()
+        marg = marg.cpu().numpy()
+        v2c = pri[:, g.var].copy()
+        with np.errstate(all="ignore"):
+            for _ in range(sweeps):
+                c2v = O.spa_check_update(g, v2c)
+                ref = pri + g.sum_cols(c2v)
+                v2c = ref[:, g.var] - c2v
+        # finite where the reference is finite, non-finite where it is not.  WHICH non-finite value is not pinned: a row whose other edges
+        # are all saturated computes exp(log t) / t, which lands on 1 (-> +-inf) or one ulp above (-> atanh = NaN) by the last bit of log and
+        # exp -- numpy's, glibc's and this library's differ there (the decision is bit 0 either way for a positive sign)
+        m, r = marg[clean], ref[clean]
+        assert (np.isfinite(m) == np.isfinite(r)).all()
+        both_inf = np.isinf(m) & np.isinf(r)
+        assert (np.sign(m[both_inf]) == np.sign(r[both_inf])).all()
+        ok = np.isfinite(r)
+        assert ok.any() and (~ok).any()
+        err = np.abs(m[ok] - r[ok]) / (1 + np.abs(r[ok]))
+        assert err.max() <= 1e-9, err.max()
+        clean &= ((np.isnan(marg) == np.isnan(ref)) & (np.isinf(marg) == np.isinf(ref))).all(axis=1)
+    assert clean.sum() >= B // 2  # most frames agree in every NaN and inf as well
+
+
 def test_soft_output_with_early_exit_matches_between_backends():
     # with the syndrome exit ON, both backends return the marginals of each frame's LAST executed sweep (0 for a frame that
     # never swept) -- fp64 min-sum: bit-identical
