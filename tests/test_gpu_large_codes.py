@@ -173,7 +173,7 @@ def test_config3_spa_bsc_full_batch():
     assert 0.6 <= (ber / wer) / (ref["ber"] / ref["wer"]) <= 1.6
 
 
-# fp32 message arithmetic against the fp64 oracle: measured on the 4 096 re-decoded frames (profiles/r03_parity_measured.txt), two
+# fp32 message arithmetic against the fp64 oracle: measured on the 4 096 re-decoded frames (profiles/r03H_parity_measured.txt), two
 # non-converging frames end in different words; the list names them, any other frame must be identical
 CONFIG3_SPA_FRAMES_THAT_MAY_DIFFER = {18000, 36016}
 

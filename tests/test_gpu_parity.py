@@ -80,7 +80,7 @@ def test_bec_exact_vs_reference(path):
 
 
 # Frames that MAY differ from the reference in fp64 sum-product, by (case id, backend): device libm differs from numpy's by ulps, which
-# can flip a chaotic non-converging frame.  MEASURED (every golden case x both backends, profiles/r03_spa_agreement.txt): no frame
+# can flip a chaotic non-converging frame.  MEASURED (every golden case x both backends, profiles/r03H_parity_measured.txt): no frame
 # differs anywhere, so the list is empty and the test demands identity; a kernel change that flips a frame must name it here.
 SPA_F64_ALLOWED_FLIPS = {}
 
@@ -90,7 +90,7 @@ SPA_F64_ALLOWED_FLIPS = {}
 def test_spa_fp64_vs_reference(path, backend):
     # fp64 SPA follows the reference formula; held to what is measured: every frame's decisions identical to the reference (allow-list
     # above), iteration counts of the frames that converge upstream identical too.  Both backends.  The measured agreement of every
-    # case is printed (pytest -s; profiles/r03_spa_agreement.txt keeps the lines of the round).
+    # case is printed (pytest -s; profiles/r03H_parity_measured.txt keeps the lines of the round).
     from ldpc_decoders_amd import bpa
 
     c = load_case(path)
@@ -264,7 +264,7 @@ def test_spa_fp32_decisions(path):
     calm_same = (xhat[calm] == want[calm]).all(axis=1) if len(calm) else np.ones(1, dtype=bool)
     print("fp32 sum-product, %s backend=%s: frames identical to the fp64 phi statement %d/%d (%.1f %%); to the reference on the %d frames below |LLR| 30: %.1f %%"
           % (case_id(path), dec.handle.last_stats()[0], same.sum(), len(same), 100 * same.mean(), len(calm), 100 * calm_same.mean()))
-    # held to what is measured (profiles/r03_spa_agreement.txt): every frame identical to the fp64 phi statement, every calm frame
+    # held to what is measured (profiles/r03H_parity_measured.txt): every frame identical to the fp64 phi statement, every calm frame
     # identical to the reference; frames allowed to differ are named here
     allowed = SPA_F32_ALLOWED_FLIPS.get(case_id(path), set())
     assert set(int(f) for f in np.flatnonzero(~same)) <= allowed
