@@ -68,7 +68,9 @@ __device__ __forceinline__ void cn_msa(T (&v)[DCMAX], int deg) {
 // (166 / 94 / 160 VALU instructions, < 1 ulp); the ones below are single-double forms (tanh through expm1 and one division, correctly rounded where
 // it saturates; fdlibm's log kernel; fdlibm's atanh through its log1p), 67 / 69 / ~95 instructions.  exp stays the library's.  numpy's own functions
 // differ from either by an ulp here and there; agreement is held as measured decisions (tests/test_gpu_parity.py), unchanged: every golden
-// case at its measured 100 %, the Monte-Carlo WER of 65 536 frames at 1.5 dB identical to the library-function build's.
+// case at its measured 100 % (a numpy model of these functions keeps all 2 770 golden frames: tests/test_spa64_functions_cpu.py); in a
+// Monte-Carlo run one frame of 131 072 changes its word-error status against the library-function build.  The whole rule is BRANCH-FREE
+// on purpose (NaN by arithmetic, selects after an empty asm on their operands): exec-mask regions keep a row's six edges from interleaving.
 #ifndef LDPC_SPA_F64_LIBRARY_FUNCTIONS  // define to get the device library's functions back (A/B, tools/build_variant.sh)
 __device__ __forceinline__ double spa64_nan() { return __builtin_nan(""); }
 // tanh(x / 2) with em = expm1(|x|), r = 1 / (em + 2):  1 - 2 r for |x| > 1/2 -- ONE rounding of an exactly representable 1 minus a tiny,
