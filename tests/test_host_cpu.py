@@ -314,6 +314,7 @@ SIM_KERNELS_WITHOUT_SPILLS = [
     "k_fused_f64<0, 6, 3, 3, 5, 4, true, 0, 3>",    # config 2, fp64 min-sum: the kernel `bench.py` times by default (four waves per frame)
     "k_fused_f64<0, 6, 3, 5, 10, 2, true, 0, 3>",   # its two-wave sibling (LDPC_FUSED_NW=2; the shape of fp64 sum-product)
     "k_fused_bp<1, 6, 3, 5, 10, 2, true, 0, 3>",    # config 3, fp32 sum-product (BSC / BI-AWGN)
+    "k_fused_f64<1, 6, 3, 5, 10, 2, true, 0, 3>",   # config 3, fp64 sum-product (the reference's chain; branch-free rule, ldpc_cn.hpp)
     "k_fused_bp<0, 6, 3, 5, 10, 2, true, 2, 8>",    # irregular n = 1200 ensembles (1200_rho_x5_*), min-sum
     "k_fused_bp<0, 6, 3, 4, 8, 1, true, 0, 3>",     # n <= 512
     "k_fused_bp<0, 6, 3, 6, 11, 4, true, 0, 3>",    # Margulis n = 2640
