@@ -973,6 +973,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
             return __ballot(*sysw(lane & (NW - 1)) != 0u) != 0;
         }
     };
+    // the same exchange in two halves, so that the first gathers of the variable phase can be issued BETWEEN the barrier and the use of the
+    // verdict (they read messages every wave has written by then; LDS returns in order, so waiting for the verdict word does not wait for them;
+    // on an exit they are simply dropped): one LDS round trip off the serial path of every sweep
+    auto post_verdict = [&](bool mine) {
+        if (lane == 0) *sysw(w) = mine ? 1u : 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    auto load_verdict = [&]() -> uint32_t { return *sysw(lane & (NW - 1)); };
     auto phase_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the inline-asm row stores are invisible to the compiler's own waits
         if constexpr (NW > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
@@ -1185,7 +1194,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                 });
                 };
                 check_rows(std::integral_constant<int, CRW>{});
-                const bool unsat = any_unsat(ALG == ALG_MSA ? (__ballot((synd & 0x80000000u) != 0u) != 0) : (synd_mask != 0));
+                // narrow variable rounds, VG of them per pipeline stage (see the variable phase below)
+#ifdef LDPC_F64_NW4_VG  // experiment: variable rounds per pipeline stage of the four-wave shape
+                constexpr int VG = ALG == ALG_MSA ? (NW == 4 ? LDPC_F64_NW4_VG : 3) : 1;
+#else
+                constexpr int VG = ALG == ALG_MSA ? 3 : 1;
+#endif
+                constexpr int NVG = (VRN + VG - 1) / VG;
+                constexpr bool EARLY_GATHERS = NW > 1 && VRX == 0 && ALG == ALG_MSA;
+                double cv[2][VG][DV];
+                bool unsat;
+                const bool mine_unsat = ALG == ALG_MSA ? (__ballot((synd & 0x80000000u) != 0u) != 0) : (synd_mask != 0);
+                if constexpr (EARLY_GATHERS) {
+                    post_verdict(mine_unsat);
+                    const uint32_t vw = load_verdict();
+#pragma unroll
+                    for (int u = 0; u < VG; ++u)
+#pragma unroll
+                        for (int j = 0; j < DV; ++j)
+                            if (u < VRN) cv[0][u][j] = gat(half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                    __builtin_amdgcn_sched_barrier(0);
+                    unsat = __ballot(vw != 0u) != 0;
+                } else {
+                    unsat = any_unsat(mine_unsat);
+                }
                 // it == 0: only the BSC checks the received word itself (src/bpa.py:20,29); in SIM mode marg holds +-llr there
                 if (early && (it > 0 || (SIM && A.sim_channel == CH_BSC)) && !unsat) break;
                 // ---- variable phase: ordered sum from +0.0 (scipy COO), prior last, decision bit
@@ -1219,18 +1251,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                 // narrow rounds, VG of them per pipeline stage: the gathers of stage g+1 are in flight while stage g is summed.  Measured on
                 // the headline workload (min-sum, 65 536 frames x 49.4 sweeps): VG = 1 / 2 / 3 -> 6.37 / 6.28 / 6.21 ms; sum-product has no
                 // registers to spare (VG = 3 adds spills there)
-#ifdef LDPC_F64_NW4_VG  // experiment: variable rounds per pipeline stage of the four-wave shape
-                constexpr int VG = ALG == ALG_MSA ? (NW == 4 ? LDPC_F64_NW4_VG : 3) : 1;
-#else
-                constexpr int VG = ALG == ALG_MSA ? 3 : 1;
-#endif
-                constexpr int NVG = (VRN + VG - 1) / VG;
-                double cv[2][VG][DV];
+                if constexpr (!EARLY_GATHERS) {
 #pragma unroll
-                for (int u = 0; u < VG; ++u)
+                    for (int u = 0; u < VG; ++u)
 #pragma unroll
-                    for (int j = 0; j < DV; ++j)
-                        if (u < VRN) cv[0][u][j] = gat(half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                        for (int j = 0; j < DV; ++j)
+                            if (u < VRN) cv[0][u][j] = gat(half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                }
                 static_for<0, NVG>([&](auto G_) {
                     constexpr int g = decltype(G_)::value;
                     if constexpr (g + 1 < NVG) {
