@@ -57,7 +57,7 @@ int upload_vec(const std::vector<T>& h, T** d) {
 const std::vector<ShapeEntry>& all_shapes() {
     static const std::vector<ShapeEntry> v = [] {
         std::vector<ShapeEntry> out;
-        for (auto fn : {fused_shapes_f32_dc6, fused_shapes_f32_dcx, fused_shapes_f64_dc6, fused_shapes_f64_dcx}) {
+        for (auto fn : {fused_shapes_f32_dc6, fused_shapes_f32_dcx, fused_shapes_f64_dc6, fused_shapes_f64_dcx, fused_shapes_bec}) {
             int cnt = 0;
             const ShapeEntry* p = fn(&cnt);
             out.insert(out.end(), p, p + cnt);
@@ -143,8 +143,11 @@ int fused_kernel_name(const Decoder* d, bool sim, char* buf, size_t len) {
     const FusedPlan* p = d->fused;
     if (!p || !p->ok) return LDPC_OK;
     const ShapeEntry& s = all_shapes()[p->shape];
-    snprintf(buf, len, "%s<%d, %d, %d, %d, %d, %d, %s, %d, %d>", s.esz == 8 ? "k_fused_f64" : "k_fused_bp", s.alg, s.DC, s.DV, s.CRW, s.VRW, s.NW,
-             sim ? "true" : "false", s.VRX, s.DVX);
+    if (s.alg == ALG_BEC)  // the bit-sliced erasure kernels have no algorithm parameter
+        snprintf(buf, len, "k_fused_becs<%d, %d, %d, %d, %d, %s, %d, %d>", s.DC, s.DV, s.CRW, s.VRW, s.NW, sim ? "true" : "false", s.VRX, s.DVX);
+    else
+        snprintf(buf, len, "%s<%d, %d, %d, %d, %d, %d, %s, %d, %d>", s.esz == 8 ? "k_fused_f64" : "k_fused_bp", s.alg, s.DC, s.DV, s.CRW, s.VRW, s.NW,
+                 sim ? "true" : "false", s.VRX, s.DVX);
     return LDPC_OK;
 }
 
@@ -160,8 +163,9 @@ struct ShapeChoice {
 
 ShapeChoice choose_shape(const Code* c, int alg, int dtype) {
     ShapeChoice out;
-    // fp64 message arithmetic (min-sum, sum-product): the 8-byte kernels; the erasure decoder is integer valued, one kernel family
-    const int want_esz = (alg != ALG_BEC && dtype == DT_F64) ? 8 : 4;
+    // fp64 message arithmetic (min-sum, sum-product): the 8-byte kernels; the erasure decoder is bit-sliced (ldpc_bec_kernels.hpp): one
+    // kernel family whatever `dtype` says, 8-byte elements = two bit planes of 32 frames
+    const int want_esz = (alg == ALG_BEC || dtype == DT_F64) ? 8 : 4;
     const bool full_dv = c->min_dv == c->max_dv;  // every variable has all its DV edges: no zero row needed
     const bool short_rows = c->min_dc != c->max_dc;
     if (c->min_dc < 1) return out;
@@ -270,6 +274,81 @@ int fused_plan_host(const Code* c, int alg, int dtype, long moves, const char* o
     return LDPC_OK;
 }
 
+
+// Tables of the bit-sliced erasure kernels (ldpc_bec_kernels.hpp) from a layout plan.  Slab layout in units of 8-byte elements:
+// v2c rows [NW * VNK][64] (variable-major: row = the variable phase's gather index, VarRounds::first_gather), summary rows [CR][64],
+// the system row (element 0 = {0,0}, element 1 = a known 0).  Check row R belongs to wave R % NW as its local row R / NW.
+static int becs_build_plan(Decoder* d, FusedPlan* p, const ShapeEntry& shape, const VarRounds& vr, const FusedLayout& L) {
+    const Code* c = d->code;
+    const int DC = shape.DC, NW = shape.NW, CRW = shape.CRW, VRW = shape.VRW;
+    const int CR = fused_check_rows(shape), VR = VRW * NW, NPAD = VR * 64;
+    const int VNK = vr.per_wave();
+    const int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
+    const uint32_t sum_base = (uint32_t)NW * VNK * 64, sys_base = sum_base + (uint32_t)CR * 64;
+    const uint32_t zero_e = sys_base, known0_e = sys_base + 1;
+    p->lds_bytes = (size_t)(sys_base + 64) * 8;
+    if (p->lds_bytes > (size_t)160 * 1024 || sys_base + 64 > 65536u || CR > CRW * NW) return LDPC_OK;  // plan stays !ok
+    std::vector<uint32_t> cn_tab((size_t)NW * CNW * 64, 0), vn_tab((size_t)NW * VNW * 64, 0);
+    std::vector<int32_t> var_of_slot((size_t)NPAD, -1);
+    for (int v = 0; v < c->n; ++v) var_of_slot[L.var_slot[v]] = v;
+    auto put16 = [](std::vector<uint32_t>& tab, int words_per_wave, int wv, int k, int lane, uint32_t val) {
+        uint32_t& w = tab[((size_t)wv * words_per_wave + (k >> 1)) * 64 + lane];
+        w = (k & 1) ? ((w & 0x0000ffffu) | (val << 16)) : ((w & 0xffff0000u) | val);
+    };
+    // check side: position j of check slot (R, lane) gathers the v2c element its variable writes for this edge; a short row reads a known 0
+    std::vector<int64_t> cn_e((size_t)CRW * NW * DC * 64, -1);  // [R][j][lane], -1 = padded check lane
+    for (int cc = 0; cc < c->m; ++cc) {
+        const int R = L.chk_slot[cc] / 64, lane = L.chk_slot[cc] % 64;
+        for (int j = 0; j < DC; ++j) cn_e[((size_t)R * DC + j) * 64 + lane] = known0_e;
+        for (int k = c->row_ptr[cc]; k < c->row_ptr[cc + 1]; ++k) {
+            const int vs = L.var_slot[c->edge_var[k]];
+            cn_e[((size_t)R * DC + L.edge_pos[k]) * 64 + lane] = (int64_t)(vr.first_gather(vs / 64) + L.var_pos[k]) * 64 + vs % 64;
+        }
+    }
+    // padded check lanes may read anything: an address a real lane of their half-wave reads anyway (LDS broadcast, no extra cycle)
+    for (size_t g0 = 0; g0 < cn_e.size(); g0 += 32) {
+        int64_t rep = zero_e;
+        for (int l = 0; l < 32; ++l)
+            if (cn_e[g0 + l] >= 0) { rep = cn_e[g0 + l]; break; }
+        for (int l = 0; l < 32; ++l)
+            if (cn_e[g0 + l] < 0) cn_e[g0 + l] = rep;
+    }
+    for (int R = 0; R < CRW * NW; ++R)
+        for (int j = 0; j < DC; ++j)
+            for (int lane = 0; lane < 64; ++lane) put16(cn_tab, CNW, R % NW, (R / NW) * DC + j, lane, (uint32_t)cn_e[((size_t)R * DC + j) * 64 + lane]);
+    // variable side: gather position g of slot (Q, lane) reads the summary of its check; missing edges -- and every position of a padded
+    // slot, which must stay silent -- read {0,0}: "no message"
+    for (int Q = 0; Q < VR; ++Q)
+        for (int j = 0; j < vr.width(Q); ++j)
+            for (int lane = 0; lane < 64; ++lane) put16(vn_tab, VNW, Q / VRW, vr.first_gather(Q) % VNK + j, lane, zero_e);
+    for (int64_t k = 0; k < c->E; ++k) {
+        const int vs = L.var_slot[c->edge_var[k]], cs = L.chk_slot[c->edge_chk[k]];
+        const int Q = vs / 64;
+        put16(vn_tab, VNW, Q / VRW, vr.first_gather(Q) % VNK + L.var_pos[k], vs % 64, sum_base + (uint32_t)cs);
+    }
+    LDPC_HIP_TRY(hipSetDevice(c->device));
+    LDPC_TRY(upload_vec(cn_tab, &p->d_cn_tab));
+    LDPC_TRY(upload_vec(vn_tab, &p->d_vn_tab));
+    LDPC_TRY(upload_vec(var_of_slot, &p->d_var_of_slot));
+    {
+        std::vector<int32_t> sov(L.var_slot.begin(), L.var_slot.end());
+        while (sov.size() % 4) sov.push_back(0);
+        LDPC_TRY(upload_vec(sov, &p->d_slot_of_var));
+    }
+    LDPC_HIP_TRY(hipMalloc((void**)&p->d_next, 2 * 8 * 64));
+    hipDeviceProp_t prop;
+    LDPC_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    p->num_cu = prop.multiProcessorCount;
+    const int by_lds = (int)((size_t)160 * 1024 / p->lds_bytes);
+    int cap = 8;
+    if (const char* wenv = std::getenv("LDPC_FUSED_WAVES")) cap = atoi(wenv) > 0 ? atoi(wenv) : cap;
+    p->groups_per_cu = by_lds < cap ? by_lds : cap;
+    LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel_sim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    p->ok = p->groups_per_cu >= 1;
+    return LDPC_OK;
+}
+
 int fused_plan_create(Decoder* d) {
     const Code* c = d->code;
     d->fused = new FusedPlan();
@@ -307,6 +386,7 @@ int fused_plan_create(Decoder* d) {
     p->extra_identity = L.extra_cycles_identity;
     p->extra_planned = L.extra_cycles_planned;
     p->base_cycles = L.base_cycles;
+    if (d->alg == ALG_BEC) return becs_build_plan(d, p, shape, vr, L);
     const std::vector<int>&chk_slot = L.chk_slot, &var_slot = L.var_slot, &edge_pos = L.edge_pos, &var_pos = L.var_pos;
 
     const int VNK = vr.total_gathers() / NW;  // gathers of one wave's variable phase (wide rounds exist only for NW == 1)
@@ -499,7 +579,8 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
     unsigned long long* next_set = p->d_next + (size_t)p->next_sel * 64;
     if (!(p->next_clean && p->next_stream == st)) LDPC_HIP_TRY(hipMemsetAsync(next_set, 0, 8 * 64, st));
     long long groups = (long long)p->num_cu * p->groups_per_cu;
-    if (groups > B) groups = B;
+    const long long units = shape.alg == ALG_BEC ? (B + 31) / 32 : B;  // the bit-sliced erasure kernels hand out slabs of 32 frames
+    if (groups > units) groups = units;
     a.B = B;
     a.n = c->n;
     a.max_iter = max_iter > 0 ? max_iter : 100000;

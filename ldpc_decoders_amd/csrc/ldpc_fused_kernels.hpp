@@ -56,6 +56,7 @@ const ShapeEntry* fused_shapes_f32_dc6(int* count);
 const ShapeEntry* fused_shapes_f32_dcx(int* count);
 const ShapeEntry* fused_shapes_f64_dc6(int* count);
 const ShapeEntry* fused_shapes_f64_dcx(int* count);
+const ShapeEntry* fused_shapes_bec(int* count);  // bit-sliced erasure decoder (ldpc_bec_kernels.hpp)
 
 namespace {
 

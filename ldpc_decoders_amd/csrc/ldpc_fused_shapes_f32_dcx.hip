@@ -4,7 +4,7 @@
 
 namespace ldpc {
 
-#define LDPC_ALL_ALGS(...) shape_entry<ALG_MSA, __VA_ARGS__>(), shape_entry<ALG_SPA, __VA_ARGS__>(), shape_entry<ALG_BEC, __VA_ARGS__>()
+#define LDPC_ALL_ALGS(...) shape_entry<ALG_MSA, __VA_ARGS__>(), shape_entry<ALG_SPA, __VA_ARGS__>()
 
 const ShapeEntry* fused_shapes_f32_dcx(int* count) {
     static const ShapeEntry k[] = {
