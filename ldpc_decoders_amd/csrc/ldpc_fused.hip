@@ -144,7 +144,7 @@ int fused_kernel_name(const Decoder* d, bool sim, char* buf, size_t len) {
     if (!p || !p->ok) return LDPC_OK;
     const ShapeEntry& s = all_shapes()[p->shape];
     if (s.alg == ALG_BEC)  // the bit-sliced erasure kernels have no algorithm parameter
-        snprintf(buf, len, "k_fused_becs<%d, %d, %d, %d, %d, %s, %d, %d>", s.DC, s.DV, s.CRW, s.VRW, s.NW, sim ? "true" : "false", s.VRX, s.DVX);
+        snprintf(buf, len, "%s<%d, %d, %d, %d, %d, %d, %d>", sim ? "k_fused_becs_mc" : "k_fused_becs", s.DC, s.DV, s.CRW, s.VRW, s.NW, s.VRX, s.DVX);
     else
         snprintf(buf, len, "%s<%d, %d, %d, %d, %d, %d, %s, %d, %d>", s.esz == 8 ? "k_fused_f64" : "k_fused_bp", s.alg, s.DC, s.DV, s.CRW, s.VRW, s.NW,
                  sim ? "true" : "false", s.VRX, s.DVX);

@@ -318,7 +318,7 @@ SIM_KERNELS_WITHOUT_SPILLS = [
     "k_fused_bp<0, 6, 3, 5, 10, 2, true, 2, 8>",    # irregular n = 1200 ensembles (1200_rho_x5_*), min-sum
     "k_fused_bp<0, 6, 3, 4, 8, 1, true, 0, 3>",     # n <= 512
     "k_fused_bp<0, 6, 3, 6, 11, 4, true, 0, 3>",    # Margulis n = 2640
-    "k_fused_becs<6, 3, 3, 5, 4, true, 0, 3>",      # config 3, erasure decoder, bit-sliced (csrc/ldpc_bec_kernels.hpp: no ALG parameter)
+    "k_fused_becs_mc<6, 3, 3, 5, 4, 0, 3>",        # config 3, erasure decoder, bit-sliced (csrc/ldpc_bec_kernels.hpp: no ALG parameter)
 ]
 
 
@@ -352,7 +352,7 @@ def test_simulate_kernels_do_not_spill():
         assert by_name[name]["spill"] <= budget and by_name[name]["vgpr"] <= 128, "%s: %s" % (name, by_name[name])
     for name in SIM_KERNELS_WITHOUT_SPILLS:
         r = by_name[name]
-        if (name.startswith("k_fused_bp") and (", 2, true" in name or ", 16, true" in name)) or name.startswith("k_fused_f64<0, 6, 3, 3, 5, 4") or name.startswith("k_fused_becs<6, 3, 3, 5, 4"):
+        if (name.startswith("k_fused_bp") and (", 2, true" in name or ", 16, true" in name)) or name.startswith("k_fused_f64<0, 6, 3, 3, 5, 4") or name.startswith("k_fused_becs_mc<6, 3, 3, 5, 4"):
             assert r["vgpr"] <= 128  # four waves per SIMD: the occupancy the fp32 multi-wave shapes and the four-wave fp64 shape are built for
 
 
