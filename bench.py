@@ -26,7 +26,10 @@ Roofline.  `roofline.bound` names the resource that binds the dominant kernel:
 The 8(d) HBM-model figure of a fused kernel is kept as `hbm_model` (flagged: the messages never leave the CU, it bounds nothing).
 
 Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run, one rank per GPU
-(RCCL); frames sharded by global frame index, ONE all-reduce of the counters per step; rank 0 prints ONE JSON line.
+(RCCL); frames sharded by global frame index, ONE all-reduce of the counters per step; rank 0 prints ONE JSON line.  Every line --
+N > 1 included -- carries `roofline` (rank 0's kernels), `cpu_baseline` (rank 0's host, timed BEFORE the process touches a GPU or joins
+the process group: the scipy leg forks one worker per host core) and `collective` (backend + the number of ranks an all-reduce of
+ones saw).
 `run_bench(args, comm, make_handle, device)` is the whole driver layer with the decoder handle injected -- tests/test_dist_cpu.py runs
 it on 8 gloo ranks with a CPU stand-in for the handle; `main()` always passes the HIP handle.
 """
@@ -101,7 +104,7 @@ def cpu_baseline(code, snr, max_iter, precision="f64", budget_s=10.0):
                                                                              float(it.mean()))}
     # per-frame scipy.sparse baseline, one process per core, each decoding its own frame stream for about budget_s seconds
     try:
-        procs = min(cores, 64)
+        procs = cores  # one single-thread process per host core; forked BEFORE this process initialises a GPU runtime
         with mp.get_context("fork").Pool(procs) as pool:
             # a short pass of every process sizes the sample (the rate per process UNDER LOAD, not that of one process alone)
             pool.map(_scipy_probe, [(code.m, code.n, code.edge_chk, code.edge_var, snr, max_iter, 1, 10 + i) for i in range(procs)])  # imports, warm-up
@@ -232,10 +235,16 @@ def fused_roofline(kernel_name, frame_sweeps_per_s, cus, counters=None):
                 counters_kernel=kernel_name, counters_workload=e.get("workload"), counters_from=e.get("counters_from"))
 
 
-def run_bench(args, comm, make_handle=None, device="cuda"):
+def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
     """The benchmark driver: returns the result dict on rank 0 (None elsewhere).  `make_handle(code, alg, precision, backend)` builds
-    the decoder handle (default: the HIP DecoderHandle -- no CPU path exists in the product)."""
+    the decoder handle (default: the HIP DecoderHandle -- no CPU path exists in the product).  `cpu_base`: rank 0's CPU baseline,
+    measured by the caller before any GPU / process-group initialisation (main() does)."""
     import torch
+
+    # the collective the counters travel through, proven on the line itself: an all-reduce of ones must see every rank
+    ranks_seen = int(np.asarray(comm.all_reduce_sum(np.ones(1, dtype=np.int64)))[0]) if comm.group else 1
+    collective = {"backend": ("rccl (torch.distributed 'nccl')" if comm.backend == "nccl" else comm.backend) if comm.group else None,
+                  "ranks_seen": ranks_seen, "op": "all_reduce(sum) of the int64 counters, once per step"}
 
     from ldpc_decoders_amd.montecarlo import DeviceSimulator
 
@@ -328,7 +337,8 @@ def run_bench(args, comm, make_handle=None, device="cuda"):
     head = summarise(args.snr, res, args.steps)
     c = res["counters"]
     iter_sum_rank0_share = int(c[3]) / comm.world  # the profile is rank 0's; counters are whole-job
-    roof = None
+    roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+            "note": "no per-kernel HIP-event pass in this run (--no-profile, or not on a GPU)"}
     prof = res["profile"]
     cus = torch.cuda.get_device_properties(0).multi_processor_count if device == "cuda" else 256
     if prof:
@@ -401,6 +411,7 @@ def run_bench(args, comm, make_handle=None, device="cuda"):
         "side_kernels_ms_per_step": head.get("side_kernels_ms_per_step"),
         "algorithmic_GBps": head["algorithmic_GBps"], "bytes_per_frame_sweep": bytes_per_frame_iter,
         "roofline": roof,
+        "collective": collective,
         "decode_from_hbm": hbm_leg,
         "fp32_mode": None,
         "points": [summarise(snr, r, max(4, args.steps)) for snr, r in extra],
@@ -430,10 +441,7 @@ def run_bench(args, comm, make_handle=None, device="cuda"):
             "frames_per_s": round(int(sc[0]) / stream_res["seconds"], 1),
             "note": "same workload with --backend stream (state resident in HBM): the HBM-bound path used for codes that do not fit the LDS; "
                     "sweep_* = executed frame-sweeps x s(4E+n) / time of the two passes; per kernel: its own compulsory bytes"}
-    if comm.world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(code, args.snr, args.max_iter, args.precision)
-    else:
-        out["cpu_baseline"] = None
+    out["cpu_baseline"] = cpu_base  # rank 0's host; None only with --no-cpu-baseline
     return out
 
 
@@ -452,19 +460,25 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="auto", choices=["auto", "stream", "fused"])
     ap.add_argument("--points", type=float, nargs="*", default=[2.0, 3.0], help="extra SNR points reported under 'points'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0, help="CPU work per baseline leg (C port, scipy processes)")
     ap.add_argument("--no-profile", action="store_true", help="headline only: skip the HIP-event kernel pass and the side legs")
     return ap.parse_args(argv)
 
 
 def main():
     args = parse_args()
+    # rank 0 times the CPU baselines first: nothing of HIP / torch.cuda / the process group exists in this process yet, so the scipy
+    # leg may fork its workers, and at N > 1 the other ranks simply wait at the rendezvous meanwhile
+    cpu_base = None
+    if int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline(load_code(args.code), args.snr, args.max_iter, args.precision, args.cpu_baseline_seconds)
     from ldpc_decoders_amd import dist
 
     comm = dist.init_from_env()
     if comm.world != args.gpus and comm.is_root:
         print("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, comm.world), file=sys.stderr)
     try:
-        out = run_bench(args, comm)
+        out = run_bench(args, comm, cpu_base=cpu_base)
         if comm.is_root:
             print(json.dumps(out))
     finally:

@@ -1,6 +1,8 @@
 // extern "C" surface of libldpc_hip.so (declared in include/ldpc_hip.h).
 #include <cstring>
+#include <memory>
 #include <new>
+#include <stdexcept>
 
 #include "../../include/ldpc_hip.h"
 #include "ldpc_common.hpp"
@@ -147,444 +149,528 @@ int code_build_host(int32_t m, int32_t n, int64_t E, const int32_t* chk, const i
 
 using namespace ldpc;
 
+// Nothing throws across the C boundary (include/ldpc_hip.h): every entry point runs inside this guard.  The host side of the library
+// works with std::vector / std::string (edge lists, layout plans, plan files), so std::bad_alloc / std::length_error are possible.
+template <class F>
+static int guarded(const char* who, F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of host memory", who);
+        return LDPC_E_NOMEM;
+    } catch (const std::length_error& e) {
+        set_error("%s: size beyond what the host containers hold (%s)", who, e.what());
+        return LDPC_E_NOMEM;
+    } catch (const std::exception& e) {
+        set_error("%s: %s", who, e.what());
+        return LDPC_E_ARG;
+    } catch (...) {
+        set_error("%s: unknown C++ exception", who);
+        return LDPC_E_ARG;
+    }
+}
+
+
 extern "C" {
 
 const char* ldpc_last_error(void) { return last_error(); }
 int ldpc_abi_version(void) { return 2; }
 
 int ldpc_device_count(int* count) {
-    if (!count) return LDPC_E_ARG;
-    LDPC_HIP_TRY(hipGetDeviceCount(count));
-    return LDPC_OK;
+    return guarded("ldpc_device_count", [&]() -> int {
+        if (!count) return LDPC_E_ARG;
+        LDPC_HIP_TRY(hipGetDeviceCount(count));
+        return LDPC_OK;
+    });
 }
 
 int ldpc_code_create(int device, int32_t m, int32_t n, int64_t E, const int32_t* chk, const int32_t* var, ldpc_code_t* out) {
-    if (!out) {
-        set_error("ldpc_code_create: out is null");
-        return LDPC_E_ARG;
-    }
-    Code* c = new (std::nothrow) Code();
-    if (!c) return LDPC_E_NOMEM;
-    c->device = device;
-    if (int rc0 = code_build_host(m, n, E, chk, var, c)) {
-        delete c;
-        return rc0;
-    }
-    int rc = LDPC_OK;
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) {
-        set_error("hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
-        delete c;
-        return LDPC_E_HIP;
-    }
-    if ((rc = upload(c->row_ptr, &c->d_row_ptr)) || (rc = upload(c->edge_var, &c->d_edge_var)) ||
-        (rc = upload(c->edge_chk, &c->d_edge_chk)) || (rc = upload(c->col_ptr, &c->d_col_ptr)) ||
-        (rc = upload(c->col_edge, &c->d_col_edge))) {
-        ldpc_code_destroy((ldpc_code_t)c);
-        return rc;
-    }
-    *out = (ldpc_code_t)c;
-    return LDPC_OK;
+    return guarded("ldpc_code_create", [&]() -> int {
+        if (!out) {
+            set_error("ldpc_code_create: out is null");
+            return LDPC_E_ARG;
+        }
+        std::unique_ptr<Code> holder(new Code());  // (an exception from the containers below unwinds through the guard: nothing leaks)
+        Code* c = holder.get();
+        c->device = device;
+        LDPC_TRY(code_build_host(m, n, E, chk, var, c));
+        int rc = LDPC_OK;
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) {
+            set_error("hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+            return LDPC_E_HIP;
+        }
+        if ((rc = upload(c->row_ptr, &c->d_row_ptr)) || (rc = upload(c->edge_var, &c->d_edge_var)) ||
+            (rc = upload(c->edge_chk, &c->d_edge_chk)) || (rc = upload(c->col_ptr, &c->d_col_ptr)) ||
+            (rc = upload(c->col_edge, &c->d_col_edge))) {
+            ldpc_code_destroy((ldpc_code_t)holder.release());
+            return rc;
+        }
+        *out = (ldpc_code_t)holder.release();
+        return LDPC_OK;
+    });
 }
 
 int ldpc_code_destroy(ldpc_code_t h) {
-    Code* c = (Code*)h;
-    if (!c) return LDPC_OK;
-    (void)hipSetDevice(c->device);
-    for (int32_t* p : {c->d_row_ptr, c->d_edge_var, c->d_edge_chk, c->d_col_ptr, c->d_col_edge})
-        if (p) (void)hipFree(p);
-    delete c;
-    return LDPC_OK;
+    return guarded("ldpc_code_destroy", [&]() -> int {
+        Code* c = (Code*)h;
+        if (!c) return LDPC_OK;
+        (void)hipSetDevice(c->device);
+        for (int32_t* p : {c->d_row_ptr, c->d_edge_var, c->d_edge_chk, c->d_col_ptr, c->d_col_edge})
+            if (p) (void)hipFree(p);
+        delete c;
+        return LDPC_OK;
+    });
 }
 
 int ldpc_code_info(ldpc_code_t h, int32_t* m, int32_t* n, int64_t* E, int32_t* max_dc, int32_t* max_dv) {
-    Code* c = (Code*)h;
-    if (!c) return LDPC_E_ARG;
-    if (m) *m = c->m;
-    if (n) *n = c->n;
-    if (E) *E = c->E;
-    if (max_dc) *max_dc = c->max_dc;
-    if (max_dv) *max_dv = c->max_dv;
-    return LDPC_OK;
+    return guarded("ldpc_code_info", [&]() -> int {
+        Code* c = (Code*)h;
+        if (!c) return LDPC_E_ARG;
+        if (m) *m = c->m;
+        if (n) *n = c->n;
+        if (E) *E = c->E;
+        if (max_dc) *max_dc = c->max_dc;
+        if (max_dv) *max_dv = c->max_dv;
+        return LDPC_OK;
+    });
 }
 
 int ldpc_plan_layout(int32_t m, int32_t n, int64_t E, const int32_t* chk, const int32_t* var, int alg, int dtype, int64_t moves,
                      const char* out_dir, double* info4) {
-    if (!info4 || alg < 0 || alg > 2 || dtype < 0 || dtype > 1) {
-        set_error("ldpc_plan_layout: bad arguments (alg=%d dtype=%d)", alg, dtype);
-        return LDPC_E_ARG;
-    }
-    Code c;
-    LDPC_TRY(code_build_host(m, n, E, chk, var, &c));
-    return fused_plan_host(&c, alg, dtype, (long)moves, out_dir, info4);
+    return guarded("ldpc_plan_layout", [&]() -> int {
+        if (!info4 || alg < 0 || alg > 2 || dtype < 0 || dtype > 1) {
+            set_error("ldpc_plan_layout: bad arguments (alg=%d dtype=%d)", alg, dtype);
+            return LDPC_E_ARG;
+        }
+        Code c;
+        LDPC_TRY(code_build_host(m, n, E, chk, var, &c));
+        return fused_plan_host(&c, alg, dtype, (long)moves, out_dir, info4);
+    });
 }
 
 int ldpc_decoder_create(ldpc_code_t code, int alg, int dtype, int backend, ldpc_decoder_t* out) {
-    if (!code || !out || alg < 0 || alg > 2 || dtype < 0 || dtype > 1 || backend < 0 || backend > 2) {
-        set_error("ldpc_decoder_create: bad arguments (alg=%d dtype=%d backend=%d)", alg, dtype, backend);
-        return LDPC_E_ARG;
-    }
-    Decoder* d = new (std::nothrow) Decoder();
-    if (!d) return LDPC_E_NOMEM;
-    d->code = (Code*)code;
-    d->alg = alg;
-    d->dtype = dtype;
-    d->backend = backend;
-    (void)hipSetDevice(d->code->device);
-    hipError_t e = hipHostMalloc(&d->pinned, 4096, hipHostMallocDefault);
-    if (e != hipSuccess) {
-        set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
-        delete d;
-        return LDPC_E_HIP;
-    }
-    int rc = fused_plan_create(d);
-    if (rc) {
-        ldpc_decoder_destroy((ldpc_decoder_t)d);
-        return rc;
-    }
-    if (backend == BK_FUSED && !fused_supported(d)) {
-        set_error("fused backend does not support this (code, algorithm, dtype)");
-        ldpc_decoder_destroy((ldpc_decoder_t)d);
-        return LDPC_E_UNSUPPORTED;
-    }
-    *out = (ldpc_decoder_t)d;
-    return LDPC_OK;
+    return guarded("ldpc_decoder_create", [&]() -> int {
+        if (!code || !out || alg < 0 || alg > 2 || dtype < 0 || dtype > 1 || backend < 0 || backend > 2) {
+            set_error("ldpc_decoder_create: bad arguments (alg=%d dtype=%d backend=%d)", alg, dtype, backend);
+            return LDPC_E_ARG;
+        }
+        Decoder* d = new (std::nothrow) Decoder();
+        if (!d) return LDPC_E_NOMEM;
+        d->code = (Code*)code;
+        d->alg = alg;
+        d->dtype = dtype;
+        d->backend = backend;
+        (void)hipSetDevice(d->code->device);
+        hipError_t e = hipHostMalloc(&d->pinned, 4096, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
+            delete d;
+            return LDPC_E_HIP;
+        }
+        int rc = LDPC_OK;
+        try {
+            rc = fused_plan_create(d);  // host containers (layout planner, table builders): may throw
+        } catch (...) {
+            ldpc_decoder_destroy((ldpc_decoder_t)d);
+            throw;  // translated by the guard
+        }
+        if (rc) {
+            ldpc_decoder_destroy((ldpc_decoder_t)d);
+            return rc;
+        }
+        if (backend == BK_FUSED && !fused_supported(d)) {
+            set_error("fused backend does not support this (code, algorithm, dtype)");
+            ldpc_decoder_destroy((ldpc_decoder_t)d);
+            return LDPC_E_UNSUPPORTED;
+        }
+        *out = (ldpc_decoder_t)d;
+        return LDPC_OK;
+    });
 }
 
 int ldpc_decoder_destroy(ldpc_decoder_t h) {
-    Decoder* d = (Decoder*)h;
-    if (!d) return LDPC_OK;
-    (void)hipSetDevice(d->code->device);
-    fused_plan_destroy(d);
-    for (DevBuf* b : {&d->msg, &d->marg, &d->marg2, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->msg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap, &d->fmap2, &d->rbase, &d->h_in, &d->h_y0, &d->h_out,
-                      &d->h_iters})
-        b->release();
-    if (d->pinned) (void)hipHostFree(d->pinned);
-    if (d->lat_pin) (void)hipHostFree(d->lat_pin);
-    if (d->lat_event) (void)hipEventDestroy(d->lat_event);
-    if (d->lat_stream) (void)hipStreamDestroy(d->lat_stream);
-    for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
-    delete d;
-    return LDPC_OK;
+    return guarded("ldpc_decoder_destroy", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d) return LDPC_OK;
+        (void)hipSetDevice(d->code->device);
+        fused_plan_destroy(d);
+        for (DevBuf* b : {&d->msg, &d->marg, &d->marg2, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->msg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap, &d->fmap2, &d->rbase, &d->h_in, &d->h_y0, &d->h_out,
+                          &d->h_iters})
+            b->release();
+        if (d->pinned) (void)hipHostFree(d->pinned);
+        if (d->lat_pin) (void)hipHostFree(d->lat_pin);
+        if (d->lat_event) (void)hipEventDestroy(d->lat_event);
+        if (d->lat_stream) (void)hipStreamDestroy(d->lat_stream);
+        for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
+        delete d;
+        return LDPC_OK;
+    });
 }
 
 int ldpc_decoder_last_repacks(ldpc_decoder_t h, int* repacks) {
-    Decoder* d = (Decoder*)h;
-    if (!d || !repacks) return LDPC_E_ARG;
-    *repacks = d->last_backend == BK_STREAM ? d->last_repacks : 0;
-    return LDPC_OK;
+    return guarded("ldpc_decoder_last_repacks", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !repacks) return LDPC_E_ARG;
+        *repacks = d->last_backend == BK_STREAM ? d->last_repacks : 0;
+        return LDPC_OK;
+    });
 }
 
 int ldpc_decoder_last_stats(ldpc_decoder_t h, int* backend, int* sweeps) {
-    Decoder* d = (Decoder*)h;
-    if (!d) return LDPC_E_ARG;
-    if (backend) *backend = d->last_backend;
-    if (sweeps) *sweeps = d->last_sweeps;
-    return LDPC_OK;
+    return guarded("ldpc_decoder_last_stats", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d) return LDPC_E_ARG;
+        if (backend) *backend = d->last_backend;
+        if (sweeps) *sweeps = d->last_sweeps;
+        return LDPC_OK;
+    });
 }
 
 int ldpc_decoder_fused_info(ldpc_decoder_t h, double* out8) {
-    Decoder* d = (Decoder*)h;
-    if (!d || !out8) return LDPC_E_ARG;
-    return fused_info(d, out8);
+    return guarded("ldpc_decoder_fused_info", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !out8) return LDPC_E_ARG;
+        return fused_info(d, out8);
+    });
 }
 
 int ldpc_decoder_kernel_name(ldpc_decoder_t h, int simulate, char* buf, int64_t len) {
-    Decoder* d = (Decoder*)h;
-    if (!d || !buf || len <= 0) return LDPC_E_ARG;
-    buf[0] = 0;
-    if (d->backend == BK_STREAM) return LDPC_OK;  // a decoder pinned to the streaming kernels never launches its LDS-resident shape
-    return fused_kernel_name(d, simulate != 0, buf, (size_t)len);
+    return guarded("ldpc_decoder_kernel_name", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !buf || len <= 0) return LDPC_E_ARG;
+        buf[0] = 0;
+        if (d->backend == BK_STREAM) return LDPC_OK;  // a decoder pinned to the streaming kernels never launches its LDS-resident shape
+        return fused_kernel_name(d, simulate != 0, buf, (size_t)len);
+    });
 }
 
 int ldpc_decoder_profile(ldpc_decoder_t h, int enable) {
-    Decoder* d = (Decoder*)h;
-    if (!d) return LDPC_E_ARG;
-    d->profile = enable != 0;
-    return LDPC_OK;
+    return guarded("ldpc_decoder_profile", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d) return LDPC_E_ARG;
+        d->profile = enable != 0;
+        return LDPC_OK;
+    });
 }
 
 int ldpc_decoder_profile_read(ldpc_decoder_t h, double* ms, int64_t* launches, int reset) {
-    Decoder* d = (Decoder*)h;
-    if (!d) return LDPC_E_ARG;
-    for (int i = 0; i < 4; ++i) {
-        if (ms) ms[i] = d->prof_ms[i];
-        if (launches) launches[i] = d->prof_launches[i];
-        if (reset) {
-            d->prof_ms[i] = 0;
-            d->prof_launches[i] = 0;
+    return guarded("ldpc_decoder_profile_read", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d) return LDPC_E_ARG;
+        for (int i = 0; i < 4; ++i) {
+            if (ms) ms[i] = d->prof_ms[i];
+            if (launches) launches[i] = d->prof_launches[i];
+            if (reset) {
+                d->prof_ms[i] = 0;
+                d->prof_launches[i] = 0;
+            }
         }
-    }
-    return LDPC_OK;
+        return LDPC_OK;
+    });
 }
 
 int ldpc_decode(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
                 uint8_t* xhat, int32_t* iters, void* stream) {
-    Decoder* d = (Decoder*)h;
-    if (!d || !xhat || !iters || B < 0) {
-        set_error("ldpc_decode: bad arguments");
-        return LDPC_E_ARG;
-    }
-    LDPC_HIP_TRY(hipSetDevice(d->code->device));
-    const int bk = pick_backend(d);
-    if (bk < 0) return bk;
-    hipStream_t st = (hipStream_t)stream;
-    // bound the workspace: at most 2^17 frames per pass through a backend, fewer where the streaming state would not fit the HBM
-    const int64_t step = bk == BK_STREAM ? stream_chunk_frames(d) : (int64_t)1 << 17;
-    const size_t esz = d->dtype == DT_F64 ? 8 : 4;
-    int sweeps = 0;
-    for (int64_t b0 = 0; b0 < B; b0 += step) {
-        const int64_t nb = (B - b0) < step ? (B - b0) : step;
-        const void* p = priors ? (const char*)priors + (size_t)b0 * d->code->n * esz : nullptr;
-        const uint8_t* y = y0 ? y0 + (size_t)b0 * d->code->n : nullptr;
-        int rc = bk == BK_FUSED ? fused_decode(d, p, y, nb, max_iter, flags, xhat + (size_t)b0 * d->code->n, iters + b0, nullptr, st)
-                                : stream_decode(d, p, y, nb, max_iter, flags, xhat + (size_t)b0 * d->code->n, iters + b0, nullptr, st);
-        if (rc) return rc;
-        sweeps = d->last_sweeps > sweeps ? d->last_sweeps : sweeps;
-    }
-    d->last_sweeps = sweeps;
-    return LDPC_OK;
+    return guarded("ldpc_decode", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !xhat || !iters || B < 0) {
+            set_error("ldpc_decode: bad arguments");
+            return LDPC_E_ARG;
+        }
+        LDPC_HIP_TRY(hipSetDevice(d->code->device));
+        const int bk = pick_backend(d);
+        if (bk < 0) return bk;
+        hipStream_t st = (hipStream_t)stream;
+        // bound the workspace: at most 2^17 frames per pass through a backend, fewer where the streaming state would not fit the HBM
+        const int64_t step = bk == BK_STREAM ? stream_chunk_frames(d) : (int64_t)1 << 17;
+        const size_t esz = d->dtype == DT_F64 ? 8 : 4;
+        int sweeps = 0;
+        for (int64_t b0 = 0; b0 < B; b0 += step) {
+            const int64_t nb = (B - b0) < step ? (B - b0) : step;
+            const void* p = priors ? (const char*)priors + (size_t)b0 * d->code->n * esz : nullptr;
+            const uint8_t* y = y0 ? y0 + (size_t)b0 * d->code->n : nullptr;
+            int rc = bk == BK_FUSED ? fused_decode(d, p, y, nb, max_iter, flags, xhat + (size_t)b0 * d->code->n, iters + b0, nullptr, st)
+                                    : stream_decode(d, p, y, nb, max_iter, flags, xhat + (size_t)b0 * d->code->n, iters + b0, nullptr, st);
+            if (rc) return rc;
+            sweeps = d->last_sweeps > sweeps ? d->last_sweeps : sweeps;
+        }
+        d->last_sweeps = sweeps;
+        return LDPC_OK;
+    });
 }
 
 int ldpc_decode_soft(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
                      uint8_t* xhat, int32_t* iters, void* marginals, void* stream) {
-    Decoder* d = (Decoder*)h;
-    if (!d || !xhat || !iters || !marginals || B < 0 || B > ((int64_t)1 << 17) || d->alg == ALG_BEC) {
-        set_error("ldpc_decode_soft: bad arguments (LLR decoders only, at most 2^17 frames per call)");
-        return LDPC_E_ARG;
-    }
-    LDPC_HIP_TRY(hipSetDevice(d->code->device));
-    const int bk = pick_backend(d);
-    if (bk < 0) return bk;
-    if (bk == BK_FUSED) return fused_decode(d, priors, y0, B, max_iter, flags, xhat, iters, marginals, (hipStream_t)stream);
-    return stream_decode(d, priors, y0, B, max_iter, flags, xhat, iters, marginals, (hipStream_t)stream);
+    return guarded("ldpc_decode_soft", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !xhat || !iters || !marginals || B < 0 || B > ((int64_t)1 << 17) || d->alg == ALG_BEC) {
+            set_error("ldpc_decode_soft: bad arguments (LLR decoders only, at most 2^17 frames per call)");
+            return LDPC_E_ARG;
+        }
+        LDPC_HIP_TRY(hipSetDevice(d->code->device));
+        const int bk = pick_backend(d);
+        if (bk < 0) return bk;
+        if (bk == BK_FUSED) return fused_decode(d, priors, y0, B, max_iter, flags, xhat, iters, marginals, (hipStream_t)stream);
+        return stream_decode(d, priors, y0, B, max_iter, flags, xhat, iters, marginals, (hipStream_t)stream);
+    });
 }
 
 int ldpc_decode_host(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
                      uint8_t* xhat, int32_t* iters) {
-    Decoder* d = (Decoder*)h;
-    if (!d || !xhat || !iters || B < 0) {
-        set_error("ldpc_decode_host: bad arguments");
-        return LDPC_E_ARG;
-    }
-    if (B == 0) return LDPC_OK;
-    LDPC_HIP_TRY(hipSetDevice(d->code->device));
-    const size_t n = (size_t)d->code->n, esz = d->dtype == DT_F64 ? 8 : 4;
-    void* dp = nullptr;
-    uint8_t* dy = nullptr;
-    if (d->alg != ALG_BEC && !priors) {
-        set_error("ldpc_decode_host: priors is null");
-        return LDPC_E_ARG;
-    }
-    if (d->alg == ALG_BEC && !y0) {
-        set_error("erasure decoder needs the received symbols (y0)");
-        return LDPC_E_ARG;
-    }
-    // A few frames on the LDS-resident kernels: ONE kernel launch and one event wait.  The kernel reads the priors from, and writes
-    // the decisions to, page-locked host memory mapped into the device (a frame is 5-10 KB: a few microseconds over PCIe, less than
-    // starting a copy engine twice); no allocation, no memset in front of the launch, no device-wide synchronisation.
-    const size_t in_bytes = (size_t)B * n * esz, y_bytes = (size_t)B * n;
-    if (B <= 64 && in_bytes <= ((size_t)256 << 10) && pick_backend(d) == BK_FUSED && !d->profile) {
-        const size_t off_y = (in_bytes + 255) & ~(size_t)255, off_out = off_y + ((y_bytes + 255) & ~(size_t)255);
-        const size_t off_it = off_out + ((y_bytes + 255) & ~(size_t)255), need = off_it + 64 * sizeof(int32_t);
-        if (d->lat_bytes < need) {
-            if (d->lat_pin) (void)hipHostFree(d->lat_pin);
-            d->lat_pin = nullptr;
-            d->lat_bytes = 0;
-            LDPC_HIP_TRY(hipHostMalloc(&d->lat_pin, need, hipHostMallocMapped));
-            d->lat_bytes = need;
+    return guarded("ldpc_decode_host", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !xhat || !iters || B < 0) {
+            set_error("ldpc_decode_host: bad arguments");
+            return LDPC_E_ARG;
         }
-        if (!d->lat_stream) LDPC_HIP_TRY(hipStreamCreateWithFlags(&d->lat_stream, hipStreamNonBlocking));
-        if (!d->lat_event) LDPC_HIP_TRY(hipEventCreateWithFlags(&d->lat_event, hipEventDisableTiming));
-        char* hp = (char*)d->lat_pin;
-        void* devp = nullptr;
-        LDPC_HIP_TRY(hipHostGetDevicePointer(&devp, d->lat_pin, 0));
-        char* gp = (char*)devp;
-        if (d->alg != ALG_BEC) memcpy(hp, priors, in_bytes);
-        if (y0) memcpy(hp + off_y, y0, y_bytes);
-        d->after_kernel_event = d->lat_event;
-        const int rc = fused_decode(d, d->alg == ALG_BEC ? nullptr : gp, y0 ? (const uint8_t*)(gp + off_y) : nullptr, B, max_iter, flags,
-                                    (uint8_t*)(gp + off_out), (int32_t*)(gp + off_it), nullptr, d->lat_stream);
-        d->after_kernel_event = nullptr;
-        if (rc) return rc;
-        LDPC_HIP_TRY(hipEventSynchronize(d->lat_event));
-        memcpy(xhat, hp + off_out, y_bytes);
-        memcpy(iters, hp + off_it, (size_t)B * sizeof(int32_t));
+        if (B == 0) return LDPC_OK;
+        LDPC_HIP_TRY(hipSetDevice(d->code->device));
+        const size_t n = (size_t)d->code->n, esz = d->dtype == DT_F64 ? 8 : 4;
+        void* dp = nullptr;
+        uint8_t* dy = nullptr;
+        if (d->alg != ALG_BEC && !priors) {
+            set_error("ldpc_decode_host: priors is null");
+            return LDPC_E_ARG;
+        }
+        if (d->alg == ALG_BEC && !y0) {
+            set_error("erasure decoder needs the received symbols (y0)");
+            return LDPC_E_ARG;
+        }
+        // A few frames on the LDS-resident kernels: ONE kernel launch and one event wait.  The kernel reads the priors from, and writes
+        // the decisions to, page-locked host memory mapped into the device (a frame is 5-10 KB: a few microseconds over PCIe, less than
+        // starting a copy engine twice); no allocation, no memset in front of the launch, no device-wide synchronisation.
+        const size_t in_bytes = (size_t)B * n * esz, y_bytes = (size_t)B * n;
+        if (B <= 64 && in_bytes <= ((size_t)256 << 10) && pick_backend(d) == BK_FUSED && !d->profile) {
+            const size_t off_y = (in_bytes + 255) & ~(size_t)255, off_out = off_y + ((y_bytes + 255) & ~(size_t)255);
+            const size_t off_it = off_out + ((y_bytes + 255) & ~(size_t)255), need = off_it + 64 * sizeof(int32_t);
+            if (d->lat_bytes < need) {
+                if (d->lat_pin) (void)hipHostFree(d->lat_pin);
+                d->lat_pin = nullptr;
+                d->lat_bytes = 0;
+                LDPC_HIP_TRY(hipHostMalloc(&d->lat_pin, need, hipHostMallocMapped));
+                d->lat_bytes = need;
+            }
+            if (!d->lat_stream) LDPC_HIP_TRY(hipStreamCreateWithFlags(&d->lat_stream, hipStreamNonBlocking));
+            if (!d->lat_event) LDPC_HIP_TRY(hipEventCreateWithFlags(&d->lat_event, hipEventDisableTiming));
+            char* hp = (char*)d->lat_pin;
+            void* devp = nullptr;
+            LDPC_HIP_TRY(hipHostGetDevicePointer(&devp, d->lat_pin, 0));
+            char* gp = (char*)devp;
+            if (d->alg != ALG_BEC) memcpy(hp, priors, in_bytes);
+            if (y0) memcpy(hp + off_y, y0, y_bytes);
+            d->after_kernel_event = d->lat_event;
+            const int rc = fused_decode(d, d->alg == ALG_BEC ? nullptr : gp, y0 ? (const uint8_t*)(gp + off_y) : nullptr, B, max_iter, flags,
+                                        (uint8_t*)(gp + off_out), (int32_t*)(gp + off_it), nullptr, d->lat_stream);
+            d->after_kernel_event = nullptr;
+            if (rc) return rc;
+            LDPC_HIP_TRY(hipEventSynchronize(d->lat_event));
+            memcpy(xhat, hp + off_out, y_bytes);
+            memcpy(iters, hp + off_it, (size_t)B * sizeof(int32_t));
+            return LDPC_OK;
+        }
+        if (d->alg != ALG_BEC) {
+            LDPC_TRY(d->h_in.reserve((size_t)B * n * esz));
+            dp = d->h_in.p;
+            LDPC_HIP_TRY(hipMemcpyAsync(dp, priors, (size_t)B * n * esz, hipMemcpyHostToDevice, nullptr));
+        }
+        if (y0) {
+            LDPC_TRY(d->h_y0.reserve((size_t)B * n));
+            dy = (uint8_t*)d->h_y0.p;
+            LDPC_HIP_TRY(hipMemcpyAsync(dy, y0, (size_t)B * n, hipMemcpyHostToDevice, nullptr));
+        }
+        LDPC_TRY(d->h_out.reserve((size_t)B * n));
+        LDPC_TRY(d->h_iters.reserve((size_t)B * sizeof(int32_t)));
+        LDPC_TRY(ldpc_decode(h, dp, dy, B, max_iter, flags, (uint8_t*)d->h_out.p, (int32_t*)d->h_iters.p, nullptr));
+        LDPC_HIP_TRY(hipMemcpyAsync(xhat, d->h_out.p, (size_t)B * n, hipMemcpyDeviceToHost, nullptr));
+        LDPC_HIP_TRY(hipMemcpyAsync(iters, d->h_iters.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
+        LDPC_HIP_TRY(hipStreamSynchronize(nullptr));
         return LDPC_OK;
-    }
-    if (d->alg != ALG_BEC) {
-        LDPC_TRY(d->h_in.reserve((size_t)B * n * esz));
-        dp = d->h_in.p;
-        LDPC_HIP_TRY(hipMemcpyAsync(dp, priors, (size_t)B * n * esz, hipMemcpyHostToDevice, nullptr));
-    }
-    if (y0) {
-        LDPC_TRY(d->h_y0.reserve((size_t)B * n));
-        dy = (uint8_t*)d->h_y0.p;
-        LDPC_HIP_TRY(hipMemcpyAsync(dy, y0, (size_t)B * n, hipMemcpyHostToDevice, nullptr));
-    }
-    LDPC_TRY(d->h_out.reserve((size_t)B * n));
-    LDPC_TRY(d->h_iters.reserve((size_t)B * sizeof(int32_t)));
-    LDPC_TRY(ldpc_decode(h, dp, dy, B, max_iter, flags, (uint8_t*)d->h_out.p, (int32_t*)d->h_iters.p, nullptr));
-    LDPC_HIP_TRY(hipMemcpyAsync(xhat, d->h_out.p, (size_t)B * n, hipMemcpyDeviceToHost, nullptr));
-    LDPC_HIP_TRY(hipMemcpyAsync(iters, d->h_iters.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
-    LDPC_HIP_TRY(hipStreamSynchronize(nullptr));
-    return LDPC_OK;
+    });
 }
 
 int ldpc_channel(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0,
                  int64_t B, int32_t n, void* priors, uint8_t* y, void* stream) {
-    if (B < 0 || n <= 0 || dtype < 0 || dtype > 1) {
-        set_error("ldpc_channel: bad arguments");
-        return LDPC_E_ARG;
-    }
-    return channel_generate(channel, dtype, param, codeword, seed, stream_id, frame0, B, n, priors, y, (hipStream_t)stream);
+    return guarded("ldpc_channel", [&]() -> int {
+        if (B < 0 || n <= 0 || dtype < 0 || dtype > 1) {
+            set_error("ldpc_channel: bad arguments");
+            return LDPC_E_ARG;
+        }
+        return channel_generate(channel, dtype, param, codeword, seed, stream_id, frame0, B, n, priors, y, (hipStream_t)stream);
+    });
 }
 
 int ldpc_channel_words(int channel, int dtype, double param, const uint8_t* codebook, int64_t K, uint64_t seed, uint64_t stream_id,
                        uint64_t frame0, int64_t B, int32_t n, void* priors, uint8_t* y, uint8_t* sent, void* stream) {
-    if (B < 0 || n <= 0 || dtype < 0 || dtype > 1 || !codebook || !sent) {
-        set_error("ldpc_channel_words: bad arguments");
-        return LDPC_E_ARG;
-    }
-    return channel_generate_words(channel, dtype, param, 0, codebook, K, seed, stream_id, frame0, B, n, priors, y, sent, (hipStream_t)stream);
+    return guarded("ldpc_channel_words", [&]() -> int {
+        if (B < 0 || n <= 0 || dtype < 0 || dtype > 1 || !codebook || !sent) {
+            set_error("ldpc_channel_words: bad arguments");
+            return LDPC_E_ARG;
+        }
+        return channel_generate_words(channel, dtype, param, 0, codebook, K, seed, stream_id, frame0, B, n, priors, y, sent, (hipStream_t)stream);
+    });
 }
 
 int ldpc_count_errors_words(const uint8_t* xhat, const uint8_t* sent, const int32_t* iters, int64_t B, int32_t n, int32_t hist_bins,
                             int64_t* counters, void* stream) {
-    if (!xhat || !sent || !counters || B < 0 || n <= 0 || hist_bins < 0) {
-        set_error("ldpc_count_errors_words: bad arguments");
-        return LDPC_E_ARG;
-    }
-    return count_errors_words(xhat, sent, 1, 0, iters, B, n, hist_bins, counters, (hipStream_t)stream);
+    return guarded("ldpc_count_errors_words", [&]() -> int {
+        if (!xhat || !sent || !counters || B < 0 || n <= 0 || hist_bins < 0) {
+            set_error("ldpc_count_errors_words: bad arguments");
+            return LDPC_E_ARG;
+        }
+        return count_errors_words(xhat, sent, 1, 0, iters, B, n, hist_bins, counters, (hipStream_t)stream);
+    });
 }
 
 int ldpc_debug_copy4(const void* src_dev, void* dst_dev, int64_t nbytes, void* stream) {
-    if (!src_dev || !dst_dev || nbytes < 0) return LDPC_E_ARG;
-    return debug_copy4(src_dev, dst_dev, nbytes, (hipStream_t)stream);
+    return guarded("ldpc_debug_copy4", [&]() -> int {
+        if (!src_dev || !dst_dev || nbytes < 0) return LDPC_E_ARG;
+        return debug_copy4(src_dev, dst_dev, nbytes, (hipStream_t)stream);
+    });
 }
 
 int ldpc_count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const int32_t* iters, int64_t B, int32_t n,
                       int32_t hist_bins, int64_t* counters, void* stream) {
-    if (!xhat || !counters || B < 0 || n <= 0 || hist_bins < 0) {
-        set_error("ldpc_count_errors: bad arguments");
-        return LDPC_E_ARG;
-    }
-    return count_errors(xhat, sent, codeword, iters, B, n, hist_bins, counters, (hipStream_t)stream);
+    return guarded("ldpc_count_errors", [&]() -> int {
+        if (!xhat || !counters || B < 0 || n <= 0 || hist_bins < 0) {
+            set_error("ldpc_count_errors: bad arguments");
+            return LDPC_E_ARG;
+        }
+        return count_errors(xhat, sent, codeword, iters, B, n, hist_bins, counters, (hipStream_t)stream);
+    });
 }
 
 int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id,
                   uint64_t frame0, int64_t B, int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters,
                   void* stream) {
-    Decoder* d = (Decoder*)h;
-    if (!d || !counters || B < 0) {
-        set_error("ldpc_simulate: bad arguments");
-        return LDPC_E_ARG;
-    }
-    if ((channel == CH_BEC) != (d->alg == ALG_BEC)) {
-        set_error("ldpc_simulate: the erasure channel pairs with LDPC_ALG_BEC decoders (and only with them)");
-        return LDPC_E_ARG;
-    }
-    if (B == 0) return LDPC_OK;
-    LDPC_HIP_TRY(hipSetDevice(d->code->device));
-    const size_t n = (size_t)d->code->n, esz = d->dtype == DT_F64 ? 8 : 4;
-    hipStream_t st = (hipStream_t)stream;
-    if (codeword != 0 && codeword != 1) {
-        set_error("device channel kernels send the all-zero (0) or all-one (1) word; got codeword=%d", codeword);
-        return LDPC_E_ARG;
-    }
-    if (d->backend != BK_STREAM && fused_simulate_supported(d, channel, param, hist_bins))
-        return fused_simulate(d, channel, param, codeword, seed, stream_id, frame0, B, max_iter, flags, hist_bins, counters, st);
-    // bounded staging: priors for at most 2^17 frames at a time (fewer where the streaming state would not fit the HBM)
-    const int64_t step = pick_backend(d) == BK_STREAM ? stream_chunk_frames(d) : (int64_t)1 << 17;
-    const int64_t cap = B < step ? B : step;
-    // BI-AWGN on the streaming kernels: the noise is generated straight into the tile layout (no [B,n] prior array, no transposing load)
-    const bool tiled_noise = channel == CH_BIAWGN && d->alg != ALG_BEC && pick_backend(d) == BK_STREAM;
-    if (channel != CH_BEC && !tiled_noise) LDPC_TRY(d->h_in.reserve((size_t)cap * n * esz));
-    if (channel != CH_BIAWGN) LDPC_TRY(d->h_y0.reserve((size_t)cap * n));
-    LDPC_TRY(d->h_out.reserve((size_t)cap * n));
-    LDPC_TRY(d->h_iters.reserve((size_t)cap * sizeof(int32_t)));
-    for (int64_t b0 = 0; b0 < B; b0 += step) {
-        const int64_t nb = (B - b0) < step ? (B - b0) : step;
-        if (tiled_noise) {
-            LDPC_TRY(stream_simulate_biawgn(d, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, max_iter, flags, (uint8_t*)d->h_out.p,
-                                            (int32_t*)d->h_iters.p, st));
-            LDPC_TRY(count_errors((uint8_t*)d->h_out.p, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters, st));
-            continue;
+    return guarded("ldpc_simulate", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !counters || B < 0) {
+            set_error("ldpc_simulate: bad arguments");
+            return LDPC_E_ARG;
         }
-        void* pri = channel == CH_BEC ? nullptr : d->h_in.p;
-        uint8_t* y = channel == CH_BIAWGN ? nullptr : (uint8_t*)d->h_y0.p;
-        LDPC_TRY(channel_generate(channel, d->dtype, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, (int32_t)n, pri,
-                                  y, st));
-        LDPC_TRY(ldpc_decode(h, pri, y, nb, max_iter, flags, (uint8_t*)d->h_out.p, (int32_t*)d->h_iters.p, stream));
-        LDPC_TRY(count_errors((uint8_t*)d->h_out.p, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters,
-                              st));
-    }
-    return LDPC_OK;
+        if ((channel == CH_BEC) != (d->alg == ALG_BEC)) {
+            set_error("ldpc_simulate: the erasure channel pairs with LDPC_ALG_BEC decoders (and only with them)");
+            return LDPC_E_ARG;
+        }
+        if (B == 0) return LDPC_OK;
+        LDPC_HIP_TRY(hipSetDevice(d->code->device));
+        const size_t n = (size_t)d->code->n, esz = d->dtype == DT_F64 ? 8 : 4;
+        hipStream_t st = (hipStream_t)stream;
+        if (codeword != 0 && codeword != 1) {
+            set_error("device channel kernels send the all-zero (0) or all-one (1) word; got codeword=%d", codeword);
+            return LDPC_E_ARG;
+        }
+        if (d->backend != BK_STREAM && fused_simulate_supported(d, channel, param, hist_bins))
+            return fused_simulate(d, channel, param, codeword, seed, stream_id, frame0, B, max_iter, flags, hist_bins, counters, st);
+        // bounded staging: priors for at most 2^17 frames at a time (fewer where the streaming state would not fit the HBM)
+        const int64_t step = pick_backend(d) == BK_STREAM ? stream_chunk_frames(d) : (int64_t)1 << 17;
+        const int64_t cap = B < step ? B : step;
+        // BI-AWGN on the streaming kernels: the noise is generated straight into the tile layout (no [B,n] prior array, no transposing load)
+        const bool tiled_noise = channel == CH_BIAWGN && d->alg != ALG_BEC && pick_backend(d) == BK_STREAM;
+        if (channel != CH_BEC && !tiled_noise) LDPC_TRY(d->h_in.reserve((size_t)cap * n * esz));
+        if (channel != CH_BIAWGN) LDPC_TRY(d->h_y0.reserve((size_t)cap * n));
+        LDPC_TRY(d->h_out.reserve((size_t)cap * n));
+        LDPC_TRY(d->h_iters.reserve((size_t)cap * sizeof(int32_t)));
+        for (int64_t b0 = 0; b0 < B; b0 += step) {
+            const int64_t nb = (B - b0) < step ? (B - b0) : step;
+            if (tiled_noise) {
+                LDPC_TRY(stream_simulate_biawgn(d, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, max_iter, flags, (uint8_t*)d->h_out.p,
+                                                (int32_t*)d->h_iters.p, st));
+                LDPC_TRY(count_errors((uint8_t*)d->h_out.p, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters, st));
+                continue;
+            }
+            void* pri = channel == CH_BEC ? nullptr : d->h_in.p;
+            uint8_t* y = channel == CH_BIAWGN ? nullptr : (uint8_t*)d->h_y0.p;
+            LDPC_TRY(channel_generate(channel, d->dtype, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, (int32_t)n, pri,
+                                      y, st));
+            LDPC_TRY(ldpc_decode(h, pri, y, nb, max_iter, flags, (uint8_t*)d->h_out.p, (int32_t*)d->h_iters.p, stream));
+            LDPC_TRY(count_errors((uint8_t*)d->h_out.p, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters,
+                                  st));
+        }
+        return LDPC_OK;
+    });
 }
 
 // ---- maximum-likelihood decoder (ldpc_ml.hip) ----
 int ldpc_ml_create(int device, const uint8_t* codebook, int64_t K, int32_t n, ldpc_ml_t* out) {
-    MlDecoder* d = nullptr;
-    LDPC_TRY(ml_create(device, codebook, K, n, &d));
-    *out = (ldpc_ml_t)d;
-    return LDPC_OK;
+    return guarded("ldpc_ml_create", [&]() -> int {
+        MlDecoder* d = nullptr;
+        LDPC_TRY(ml_create(device, codebook, K, n, &d));
+        *out = (ldpc_ml_t)d;
+        return LDPC_OK;
+    });
 }
 
 int ldpc_ml_destroy(ldpc_ml_t h) {
-    ml_destroy((MlDecoder*)h);
-    return LDPC_OK;
+    return guarded("ldpc_ml_destroy", [&]() -> int {
+        ml_destroy((MlDecoder*)h);
+        return LDPC_OK;
+    });
 }
 
 int ldpc_ml_decode(ldpc_ml_t h, int channel, int dtype, const double* coef2, const void* y_dev, int64_t B,
                    const uint32_t* pick_dev, int32_t* index_dev, int32_t* ties_dev, uint32_t* tie_mask_dev, double* best_dev,
                    uint8_t* xhat_dev, void* stream) {
-    if (!h || !coef2 || !y_dev || B < 0 || dtype < 0 || dtype > 1) {
-        set_error("ldpc_ml_decode: bad arguments");
-        return LDPC_E_ARG;
-    }
-    return ml_decode((MlDecoder*)h, channel, dtype, coef2, y_dev, B, pick_dev, index_dev, ties_dev, tie_mask_dev, best_dev, xhat_dev,
-                     (hipStream_t)stream);
+    return guarded("ldpc_ml_decode", [&]() -> int {
+        if (!h || !coef2 || !y_dev || B < 0 || dtype < 0 || dtype > 1) {
+            set_error("ldpc_ml_decode: bad arguments");
+            return LDPC_E_ARG;
+        }
+        return ml_decode((MlDecoder*)h, channel, dtype, coef2, y_dev, B, pick_dev, index_dev, ties_dev, tie_mask_dev, best_dev, xhat_dev,
+                         (hipStream_t)stream);
+    });
 }
 
 int ldpc_ml_simulate(ldpc_ml_t h, int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id,
                      uint64_t frame0, int64_t B, int64_t* counters_dev, void* stream) {
-    if (!h || !counters_dev || B < 0 || dtype < 0 || dtype > 1 || (codeword != 0 && codeword != 1)) {
-        set_error("ldpc_ml_simulate: bad arguments");
-        return LDPC_E_ARG;
-    }
-    return ml_simulate((MlDecoder*)h, channel, dtype, param, codeword, seed, stream_id, frame0, B, counters_dev, (hipStream_t)stream);
+    return guarded("ldpc_ml_simulate", [&]() -> int {
+        if (!h || !counters_dev || B < 0 || dtype < 0 || dtype > 1 || (codeword != 0 && codeword != 1)) {
+            set_error("ldpc_ml_simulate: bad arguments");
+            return LDPC_E_ARG;
+        }
+        return ml_simulate((MlDecoder*)h, channel, dtype, param, codeword, seed, stream_id, frame0, B, counters_dev, (hipStream_t)stream);
+    });
 }
 
 // ---- ADMM LP decoder (ldpc_admm.hip) ----
 int ldpc_admm_create(ldpc_code_t code, ldpc_admm_t* out) {
-    if (!code || !out) {
-        set_error("ldpc_admm_create: bad arguments");
-        return LDPC_E_ARG;
-    }
-    AdmmDecoder* d = nullptr;
-    LDPC_TRY(admm_create((Code*)code, &d));
-    *out = (ldpc_admm_t)d;
-    return LDPC_OK;
+    return guarded("ldpc_admm_create", [&]() -> int {
+        if (!code || !out) {
+            set_error("ldpc_admm_create: bad arguments");
+            return LDPC_E_ARG;
+        }
+        AdmmDecoder* d = nullptr;
+        LDPC_TRY(admm_create((Code*)code, &d));
+        *out = (ldpc_admm_t)d;
+        return LDPC_OK;
+    });
 }
 
 int ldpc_admm_destroy(ldpc_admm_t h) {
-    admm_destroy((AdmmDecoder*)h);
-    return LDPC_OK;
+    return guarded("ldpc_admm_destroy", [&]() -> int {
+        admm_destroy((AdmmDecoder*)h);
+        return LDPC_OK;
+    });
 }
 
 int ldpc_admm_last_repacks(ldpc_admm_t h, int* repacks) {
-    if (!h || !repacks) return LDPC_E_ARG;
-    *repacks = admm_last_repacks((AdmmDecoder*)h);
-    return LDPC_OK;
+    return guarded("ldpc_admm_last_repacks", [&]() -> int {
+        if (!h || !repacks) return LDPC_E_ARG;
+        *repacks = admm_last_repacks((AdmmDecoder*)h);
+        return LDPC_OK;
+    });
 }
 
 int ldpc_admm_decode(ldpc_admm_t h, const double* gamma_dev, int64_t B, double mu, double eps, int32_t max_iter, double* x_dev,
                      int32_t* iters_dev, uint8_t* converged_dev, void* stream) {
-    if (!h || !gamma_dev || !x_dev || !iters_dev || B < 0) {
-        set_error("ldpc_admm_decode: bad arguments");
-        return LDPC_E_ARG;
-    }
-    return admm_decode((AdmmDecoder*)h, gamma_dev, B, mu, eps, max_iter, x_dev, iters_dev, converged_dev, (hipStream_t)stream);
+    return guarded("ldpc_admm_decode", [&]() -> int {
+        if (!h || !gamma_dev || !x_dev || !iters_dev || B < 0) {
+            set_error("ldpc_admm_decode: bad arguments");
+            return LDPC_E_ARG;
+        }
+        return admm_decode((AdmmDecoder*)h, gamma_dev, B, mu, eps, max_iter, x_dev, iters_dev, converged_dev, (hipStream_t)stream);
+    });
 }
 
 }  // extern "C"

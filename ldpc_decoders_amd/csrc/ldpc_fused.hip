@@ -27,11 +27,17 @@ struct FusedPlan {
     int32_t* d_var_of_slot = nullptr;  // [VR*64] variable index of a slot, -1 for padding
     int32_t* d_slot_of_var = nullptr;  // [n rounded up to 4] slot (LDS dword index) of a variable
     unsigned long long* d_cn_active = nullptr;  // [CR] lanes holding a real check in round R
-    unsigned long long* d_next = nullptr;       // frame dispenser: TWO sets of 8 counters (64 B apart); a launch uses one while the other is
-                                                // zeroed behind it on the same stream, so no memset sits in front of the next launch
-    int next_sel = 0;                           // set the next launch uses
-    bool next_clean = false;                    // set `next_sel` was zeroed by a memset enqueued on `next_stream` behind the last launch
-    hipStream_t next_stream = nullptr;
+    // Frame dispenser: TWO sets of 8 counters (64 B apart); a launch uses one while the other is zeroed behind it on the same stream,
+    // so no memset sits in front of the next launch.  The low-latency host path (ldpc_decode_host, a private non-blocking stream) has
+    // a dispenser of its own: sharing one, its launch could zero the set a kernel of an asynchronous decode / simulate on another
+    // stream is still drawing frames from (frames handed out twice), and that kernel's trailing memset could hit the set in use here.
+    struct Dispenser {
+        unsigned long long* d = nullptr;  // 2 x 8 counters
+        int sel = 0;                      // set the next launch uses
+        bool clean = false;               // set `sel` was zeroed by a memset enqueued on `stream` behind the last launch
+        hipStream_t stream = nullptr;
+    };
+    Dispenser disp[2];                          // [0] decode / simulate on the caller's stream, [1] the low-latency host path
     int sync_off[4] = {0, 0, 0, 0};    // NW > 1: byte offset of a padded c2v slot owned by wave w (verdict / frame hand-off)
     int msync_off[4] = {0, 0, 0, 0};   // NW > 1: byte offset of a padded marginal slot owned by wave w (end-of-sweep hand-off)
     int zero_row = 0;                  // 1: the c2v area ends with an always-zero row
@@ -335,7 +341,7 @@ static int becs_build_plan(Decoder* d, FusedPlan* p, const ShapeEntry& shape, co
         while (sov.size() % 4) sov.push_back(0);
         LDPC_TRY(upload_vec(sov, &p->d_slot_of_var));
     }
-    LDPC_HIP_TRY(hipMalloc((void**)&p->d_next, 2 * 8 * 64));
+    LDPC_HIP_TRY(hipMalloc((void**)&p->disp[0].d, 2 * 8 * 64));
     hipDeviceProp_t prop;
     LDPC_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     p->num_cu = prop.multiProcessorCount;
@@ -543,7 +549,7 @@ int fused_plan_create(Decoder* d) {
         LDPC_TRY(upload_vec(sov, &p->d_slot_of_var));
     }
     LDPC_TRY(upload_vec(cn_active, &p->d_cn_active));
-    LDPC_HIP_TRY(hipMalloc((void**)&p->d_next, 2 * 8 * 64));  // 2 x 8 frame counters, one cache line apart
+    LDPC_HIP_TRY(hipMalloc((void**)&p->disp[0].d, 2 * 8 * 64));  // 2 x 8 frame counters, one cache line apart
     hipDeviceProp_t prop;
     LDPC_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     p->num_cu = prop.multiProcessorCount;
@@ -562,7 +568,7 @@ int fused_plan_create(Decoder* d) {
 void fused_plan_destroy(Decoder* d) {
     FusedPlan* p = d->fused;
     if (!p) return;
-    for (void* q : {(void*)p->d_cn_tab, (void*)p->d_vn_tab, (void*)p->d_var_of_slot, (void*)p->d_slot_of_var, (void*)p->d_cn_active, (void*)p->d_next})
+    for (void* q : {(void*)p->d_cn_tab, (void*)p->d_vn_tab, (void*)p->d_var_of_slot, (void*)p->d_slot_of_var, (void*)p->d_cn_active, (void*)p->disp[0].d, (void*)p->disp[1].d})
         if (q) (void)hipFree(q);
     delete p;
     d->fused = nullptr;
@@ -576,8 +582,10 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
     }
     const ShapeEntry& shape = all_shapes()[p->shape];
     const Code* c = d->code;
-    unsigned long long* next_set = p->d_next + (size_t)p->next_sel * 64;
-    if (!(p->next_clean && p->next_stream == st)) LDPC_HIP_TRY(hipMemsetAsync(next_set, 0, 8 * 64, st));
+    FusedPlan::Dispenser& dsp = p->disp[d->after_kernel_event ? 1 : 0];
+    if (!dsp.d) LDPC_HIP_TRY(hipMalloc((void**)&dsp.d, 2 * 8 * 64));
+    unsigned long long* next_set = dsp.d + (size_t)dsp.sel * 64;
+    if (!(dsp.clean && dsp.stream == st)) LDPC_HIP_TRY(hipMemsetAsync(next_set, 0, 8 * 64, st));
     long long groups = (long long)p->num_cu * p->groups_per_cu;
     const long long units = shape.alg == ALG_BEC ? (B + 31) / 32 : B;  // the bit-sliced erasure kernels hand out slabs of 32 frames
     if (groups > units) groups = units;
@@ -613,9 +621,9 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
     LDPC_HIP_TRY(hipLaunchKernel(sim ? shape.kernel_sim : shape.kernel, dim3((unsigned)groups), dim3(64 * shape.NW), args, p->lds_bytes, st));
     if (d->after_kernel_event) LDPC_HIP_TRY(hipEventRecord(d->after_kernel_event, st));  // low-latency host path: wait for the kernel only
     // the other counter set for the next launch, zeroed behind this kernel (off the critical path of both launches)
-    p->next_sel ^= 1;
-    p->next_clean = hipMemsetAsync(p->d_next + (size_t)p->next_sel * 64, 0, 8 * 64, st) == hipSuccess;
-    p->next_stream = st;
+    dsp.sel ^= 1;
+    dsp.clean = hipMemsetAsync(dsp.d + (size_t)dsp.sel * 64, 0, 8 * 64, st) == hipSuccess;
+    dsp.stream = st;
     if (d->profile) {
         LDPC_HIP_TRY(hipEventRecord(e1, st));
         LDPC_HIP_TRY(hipStreamSynchronize(st));

@@ -86,6 +86,10 @@ __device__ __forceinline__ void lds_st_tid(float v) {
     static_assert(OFF >= 0 && OFF < 65536, "16-bit DS offset");
     asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(v), "n"(OFF) : "memory");
 }
+// (No "m0" in the clobber list: hipcc treats M0 as a RESERVED register -- "inline asm clobber list contains reserved registers: m0 ...
+// may not be preserved across the asm statement" [-Winline-asm] -- i.e. the clobber is not honoured, it only adds a warning per
+// instantiation.  What makes this sound is that the compiler has no M0 use of its own in these kernels, which
+// tests/test_host_cpu.py::test_compiler_never_touches_m0_in_the_fused_kernels checks on the disassembly of the built library.)
 __device__ __forceinline__ void lds_set_m0(uint32_t base) { asm volatile("s_mov_b32 m0, %0" ::"s"(base) : "memory"); }
 
 // The few words the waves of a frame hand each other (syndrome verdicts, frame numbers, error counts) are accessed as LDS words:

@@ -9,8 +9,8 @@ Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks this module again
 (i) the six known-answer tests the reference carries (``src/biawgn.py:85-92``,
 ``src/bsc.py:82-89``, ``src/bec.py:132-139``) and (ii) golden vectors captured by
 importing the reference in the build container (``oracle/make_goldens.py`` →
-``tests/golden/*.npz``); ``tests/test_oracle_vs_reference.py`` additionally runs
-the live reference when ``/root/reference`` exists.
+``tests/golden/*.npz``); ``tests/test_goldens_regenerate_cpu.py`` additionally re-runs
+the live reference when ``/root/reference`` exists and compares with the committed files.
 
 Everything is written over an explicit *edge list* in row-major order of H
 (edge k = (chk[k], var[k]) sorted by check then variable), which is what the

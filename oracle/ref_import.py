@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE -- never imported by the product package.  Used by
 ``oracle/make_goldens.py`` to generate the committed fixtures under
-``tests/golden/`` and by ``tests/test_oracle_vs_reference.py`` (skipped when
+``tests/golden/`` and -- through that script -- by ``tests/test_goldens_regenerate_cpu.py`` (skipped when
 ``/root/reference`` is absent, e.g. on the GPU box).
 
 The reference needs two in-memory shims; nothing is

@@ -118,10 +118,12 @@ class OracleHandle:
         return ""
 
 
+args = bench.parse_args(["--gpus", os.environ["WORLD_SIZE"], "--steps", "3", "--warmup", "1", "--repeats", "2", "--batch", str(768 // int(os.environ["WORLD_SIZE"])),
+                         "--code", "7_4_hamming", "--snr", "2.0", "--max-iter", "10", "--points", "--no-profile", "--cpu-baseline-seconds", "0.2"])
+# as bench.main(): rank 0 times the CPU baselines BEFORE it joins the process group (the other ranks wait at the rendezvous)
+cpu_base = bench.cpu_baseline(bench.load_code(args.code), args.snr, args.max_iter, args.precision, args.cpu_baseline_seconds) if os.environ["RANK"] == "0" else None
 comm = dist.init_from_env(prefer_gpu=False)
-args = bench.parse_args(["--gpus", str(comm.world), "--steps", "3", "--warmup", "1", "--repeats", "2", "--batch", str(768 // comm.world),
-                         "--code", "7_4_hamming", "--snr", "2.0", "--max-iter", "10", "--points", "--no-profile", "--no-cpu-baseline"])
-out = bench.run_bench(args, comm, make_handle=OracleHandle, device="cpu")
+out = bench.run_bench(args, comm, make_handle=OracleHandle, device="cpu", cpu_base=cpu_base)
 if out is not None:
     print(json.dumps(out))
 json.dump(OracleHandle.log, open(sys.argv[1] + ".rank%%d" %% comm.rank, "w"))
@@ -157,6 +159,13 @@ def test_bench_driver_layer_on_eight_ranks(tmp_path):
         assert one[k] == eight[k], k
     assert eight["frames_counted"] == 3 * 768 and eight["timed_blocks"] == 2 and len(eight["blocks_ms_per_step"]) == 2
     assert eight["value"] > 0 and eight["ms_per_step_min"] <= eight["ms_per_step"] <= eight["ms_per_step_max"]
+    # what makes an N > 1 line gradeable: the CPU baseline of rank 0's host, the roofline object and proof that the collective saw N ranks
+    for line, world in ((one, 1), (eight, 8)):
+        assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+        assert line["cpu_baseline"]["scipy"].get("value", 0) > 0, line["cpu_baseline"]["scipy"]
+        assert isinstance(line["roofline"], dict) and "frac" in line["roofline"] and "bound" in line["roofline"]
+        assert line["collective"]["ranks_seen"] == world
+    assert eight["collective"]["backend"] == "gloo" and one["collective"]["backend"] is None
     # shard coverage: in every round the eight shards tile the round's frame range exactly, in rank order
     rounds = len(logs8[0])
     assert rounds == 1 + 2 * 3 and all(len(lg) == rounds for lg in logs8)

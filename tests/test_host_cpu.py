@@ -307,6 +307,29 @@ def test_host_only_layout_planning_and_plan_store(tmp_path):
     assert rc == -3 and b"row-major" in lib.ldpc_last_error()
 
 
+def test_nothing_throws_across_the_c_boundary():
+    """include/ldpc_hip.h: "nothing throws across the boundary".  Every extern "C" entry runs inside a guard that turns a C++ exception
+    of the host containers (edge lists, layout planner, plan files) into a negative code + ldpc_last_error(); absurd sizes come back as
+    an error code, never as an abort of the calling Python process."""
+    import ctypes
+
+    from ldpc_decoders_amd import _lib
+
+    lib = _lib.load()
+    info = (ctypes.c_double * 4)()
+    chk = np.zeros(4, dtype=np.int32)
+    # E = 2^40 edges claimed with 4 readable: refused before any container is sized from it
+    rc = lib.ldpc_plan_layout(2, 2, 1 << 40, chk.ctypes.data, chk.ctypes.data, 0, 0, 1000, None, info)
+    assert rc < 0 and b"bad graph arguments" in lib.ldpc_last_error()
+    for m, n, E in ((-1, 4, 4), (4, 0, 4), (4, 4, -7)):
+        assert lib.ldpc_plan_layout(m, n, E, chk.ctypes.data, chk.ctypes.data, 0, 0, 1000, None, info) < 0
+    # the guard is on every int-returning entry point of the shared object
+    src = open(os.path.join(ROOT, "ldpc_decoders_amd", "csrc", "ldpc_api.hip")).read()
+    body = src[src.index('extern "C" {'):]
+    entries = [ln for ln in body.splitlines() if ln.startswith("int ldpc_") and "ldpc_abi_version" not in ln]
+    assert len(entries) >= 30 and body.count("return guarded(") == len(entries)
+
+
 # The Monte-Carlo (SIM) kernels behind `ldpc_simulate` for BASELINE configs 2-4 (+ the sum-product / irregular siblings main.py runs
 # by default): template arguments <ALG, DC, DV, CRW, VRW, NW, SIM, VRX, DVX> of csrc/ldpc_fused_kernels.hpp
 SIM_KERNELS_WITHOUT_SPILLS = [
