@@ -76,9 +76,15 @@ int upload(const std::vector<T>& h, T** d) {
 // Frames per pass through the streaming kernels: at most 2^17, and no more than fit -- with the second state set of the frame repack
 // (three quarters of the first) -- into 80 % of the memory that is free now.  n = 64 800 in fp32 is 1.3 MB of state per frame: 2^17
 // frames would want 297 GB with the repack set; 98 304 take 223 GB.
-int64_t stream_chunk_frames(const Decoder* d) {
+int64_t stream_chunk_frames(Decoder* d) {
+    // decided once per decoder (a driver query per call, and a chunking that followed the allocator state of the moment):
+    // the workspaces a decoder reserved stay reserved, so the first answer remains valid for its lifetime
+    if (d->stream_chunk > 0) return d->stream_chunk;
     const size_t esz = d->alg == ALG_BEC ? 1 : (d->dtype == DT_F64 ? 8 : 4);
-    const double per_frame = 1.75 * (double)esz * ((double)d->code->E + 2.0 * d->code->n) + 3.0 * d->code->n;  // + staged decisions / priors
+    const double n = (double)d->code->n, E = (double)d->code->E;
+    // per frame: messages + marginals + priors, the second state set of the frame repack (three quarters of the first), the decision /
+    // erasure bit planes of both sets (n / 8 bytes each), the frame maps (4 B), and the staged priors / decisions / iteration counts
+    const double per_frame = 1.75 * (double)esz * (E + 2.0 * n) + 1.75 * 2.0 * n / 8.0 + 8.0 + (double)esz * n + 2.0 * n + 4.0;
     size_t free_b = 0, total_b = 0;
     int64_t step = (int64_t)1 << 17;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
@@ -88,6 +94,7 @@ int64_t stream_chunk_frames(const Decoder* d) {
         const int64_t fit = (int64_t)(budget / per_frame) / 64 * 64;
         if (fit < step) step = fit < 64 ? 64 : fit;
     }
+    d->stream_chunk = step;
     return step;
 }
 

@@ -30,16 +30,12 @@
 // Exits are per FRAME as upstream (src/bec.py:96-97,120): a mask of live frames gates the decision update, so a frame that has left
 // keeps the word it left with while the rest of its slab goes on; a slab is finished when its last frame has left.
 #pragma once
+#include "ldpc_bec_planes.hpp"
 #include "ldpc_fused_kernels.hpp"
 
 namespace ldpc {
 namespace {
 
-constexpr int BEC_SLAB = 32;  // frames per slab == bits of a plane word
-
-struct P2 {
-    uint32_t k, v;
-};
 // LDS byte address of the kernel's dynamic shared array, taken through an address-space-3 pointer: spelled via the generic pointer
 // ((uint32_t)(uintptr_t)smem) every constant offset becomes "truncate(addrspacecast(@smem) + c)", whose lowering failed to compile for
 // the 84 KB shape ("V_CMP_NE_U32_e32 0, $src_shared_base")
@@ -60,67 +56,6 @@ __device__ __forceinline__ void lds_st2(uint32_t vaddr, uint32_t k, uint32_t v) 
 __device__ __forceinline__ void lds_st2_dyn(uint32_t vaddr, uint32_t k, uint32_t v) {
     const u64 pair = ((u64)v << 32) | k;
     asm volatile("ds_write_b64 %0, %1" ::"v"(vaddr), "v"(pair) : "memory");
-}
-
-// Any boolean function of three planes is ONE instruction (v_bitop3_b32); its 8-bit truth table is the function applied to the constants
-// 0xF0, 0xCC, 0xAA (first, second, third operand).  B3(a, b, c, expression in X0, X1, X2) spells it where the compiler's own matching
-// of and/or/not trees was measured to fall short (9 instructions for the 4 of an edge's message rebuild).
-#define B3(a, b, c, EXPR) \
-    __builtin_amdgcn_bitop3_b32((a), (b), (c), (unsigned)([] { constexpr unsigned X0 = 0xF0u, X1 = 0xCCu, X2 = 0xAAu; (void)X0; (void)X1; (void)X2; return (EXPR) & 0xFFu; }()))
-// v[LANE] = s (a wave-uniform value): one v_writelane_b32
-template <int LANE>
-__device__ __forceinline__ void write_lane(uint32_t& v, uint32_t s) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(s)), "n"(LANE));
-}
-__device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { return B3(a, b, c, (X0 & X1) | (X2 & (X0 | X1))); }
-__device__ __forceinline__ uint32_t mux(uint32_t s, uint32_t a, uint32_t b) { return B3(s, a, b, (X0 & X1) | (~X0 & X2)); }  // s ? a : b, bitwise
-
-// bits needed for a count in [0, N]
-template <int N>
-struct BitsFor {
-    static constexpr int value = (N < 2) ? 1 : (N < 4) ? 2 : (N < 8) ? 3 : (N < 16) ? 4 : (N < 32) ? 5 : 6;
-};
-// S = number of set planes among in[0..N), as bit planes S[0] (weight 1) ... -- column compression: full adders (x^y^z, majority) take
-// three planes of one weight to one plane of that weight and one of the next, half adders two.  Every index is a compile-time constant
-// after unrolling (checked on the ISA: no scratch, 14 instructions for N = 8).
-template <int N>
-__device__ __forceinline__ void plane_count(const uint32_t (&in)[N], uint32_t (&S)[BitsFor<N>::value]) {
-    constexpr int NB = BitsFor<N>::value;
-    uint32_t col[NB][2 * N];
-    int head[NB], tail[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) head[b] = tail[b] = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) col[0][tail[0]++] = in[i];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#pragma unroll
-        for (int step = 0; step < N; ++step) {
-            const int len = tail[b] - head[b];
-            if (len >= 3) {
-                const uint32_t x = col[b][head[b]], y = col[b][head[b] + 1], z = col[b][head[b] + 2];
-                head[b] += 3;
-                col[b][tail[b]++] = xor3(x, y, z);
-                if (b + 1 < NB) col[b + 1][tail[b + 1]++] = maj3(x, y, z);
-            } else if (len == 2) {
-                const uint32_t x = col[b][head[b]], y = col[b][head[b] + 1];
-                head[b] += 2;
-                col[b][tail[b]++] = x ^ y;
-                if (b + 1 < NB) col[b + 1][tail[b + 1]++] = x & y;
-            }
-        }
-        S[b] = (tail[b] - head[b]) ? col[b][head[b]] : 0u;
-    }
-}
-// plane of [S >= c], c a compile-time constant after inlining: from the low bit up, ge = c_b ? (S_b & ge) : (S_b | ge)
-template <int NB>
-__device__ __forceinline__ uint32_t plane_ge(const uint32_t (&S)[NB], int c) {
-    if (c <= 0) return ~0u;
-    if (c >= (1 << NB)) return 0u;
-    uint32_t ge = ~0u;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) ge = ((c >> b) & 1) ? (S[b] & ge) : (S[b] | ge);
-    return ge;
 }
 
 // OR over the 64 lanes of a wave, result wave-uniform: four DPP steps inside each row of 16 lanes, then the four rows by v_readlane

@@ -1,0 +1,331 @@
+// Bit-sliced erasure decoder, streaming backend: the message state of codes that do not fit the LDS lives in HBM.
+//
+// Same decoder as ldpc_bec_kernels.hpp (src/bec.py:83-122; the rules and their bit-plane form are described there): a message is two
+// bits, one lane word holds them for 32 frames.  A SUPERTILE is 64 lanes x 32 frames = 2048 frames; frame f of a batch sits in
+// supertile f / 2048, lane (f % 2048) / 32, bit f % 32.  Per supertile, lines of 64 eight-byte elements {k plane, v plane}:
+//     v2c  [E]  variable -> check messages in VARIABLE-major order (line p = position p of the CSC edge list): written as a stream by
+//               the variable pass, each line gathered exactly once by the check that owns the edge;
+//     sum  [m]  one summary element per check: A = exactly one incoming message erased, B = none erased | (A & parity of the +1s) --
+//               the check's whole answer; the variable rebuilds its incoming message from (A, B) and its own last outgoing message;
+//     prior[n], xhat[n]  received word and current decisions {erased plane, value plane}.
+// HBM bytes per frame-sweep: check pass reads E lines, writes m; variable pass reads E (summaries, each re-used dc times on chip) + E
+// (its own messages) + 2n, writes E + n: (4E + m + 3n) / 4 bytes -- 4 650 B at n = 1200 against the 14 400 B of the int8 lines this
+// replaces and the 62 400 B of SURVEY 8(d)'s fp32 model.
+//
+// Exits are per frame (src/bec.py:96-97,120): `live` holds one word per lane; a frame that has left keeps its decisions (the update
+// of xhat is gated by the live word), a supertile without a live frame is skipped by both passes.
+#include <cstdlib>
+
+#include "ldpc_bec_planes.hpp"
+#include "ldpc_common.hpp"
+
+namespace ldpc {
+
+namespace {
+
+using u64 = unsigned long long;
+constexpr int SUPER = 64 * BEC_SLAB;  // frames per supertile
+
+__device__ __forceinline__ P2 ld2(const uint2* p) {
+    const uint2 t = *p;
+    return P2{t.x, t.y};
+}
+__device__ __forceinline__ P2 ld2_nt(const uint2* p) {
+    const u64 t = __builtin_nontemporal_load(reinterpret_cast<const u64*>(p));
+    return P2{(uint32_t)t, (uint32_t)(t >> 32)};
+}
+__device__ __forceinline__ void st2_nt(uint2* p, uint32_t k, uint32_t v) {
+    __builtin_nontemporal_store(((u64)v << 32) | k, reinterpret_cast<u64*>(p));
+}
+
+// received symbols [B, n] bytes {0, 1, 2 = erased} -> prior / xhat planes; one thread per variable (coalesced along v), the 2048
+// frames of the supertile in turn.  Frames beyond the batch are a known 0 (never erased: they leave before the first sweep).
+__global__ __launch_bounds__(256) void k_becs_load(const uint8_t* __restrict__ y, int64_t B, int n, uint2* __restrict__ prior,
+                                                   uint2* __restrict__ xhat, uint32_t* __restrict__ live, uint32_t* __restrict__ flags) {
+    const int T = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int64_t f0 = (int64_t)T * SUPER;
+    if (v < n) {
+        for (int lane = 0; lane < 64; ++lane) {
+            uint32_t kk = ~0u, vv = 0u;
+            const int64_t fl = f0 + (int64_t)lane * 32;
+            if (fl < B) {
+                kk = 0u;
+                const int nb = (int)((B - fl) < 32 ? (B - fl) : 32);
+                for (int b = 0; b < nb; ++b) {
+                    const uint32_t s = y[(fl + b) * n + v];
+                    kk |= (s != 2u ? 1u : 0u) << b;
+                    vv |= (s == 1u ? 1u : 0u) << b;
+                }
+                if (nb < 32) kk |= ~0u << nb;
+            }
+            const size_t at = ((size_t)T * n + v) * 64 + lane;
+            prior[at] = make_uint2(kk, vv);
+            xhat[at] = make_uint2(~kk, vv);  // x_hat starts as the received word (src/bec.py:89): {erased, value}
+            if (~kk) atomicOr(&flags[((size_t)T * 2 + 1) * 64 + lane], ~kk);  // frames that hold an erasure
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        const int64_t fl = f0 + (int64_t)threadIdx.x * 32;
+        const int64_t rem = B - fl;
+        live[(size_t)T * 64 + threadIdx.x] = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+    }
+}
+
+// v2c = prior on every edge (src/bec.py:86): line p of the variable-major order belongs to variable var_of_pos[p]
+__global__ __launch_bounds__(256) void k_becs_init(const int32_t* __restrict__ var_of_pos, const uint2* __restrict__ prior, uint2* __restrict__ v2c,
+                                                   int n, int64_t E) {
+    const int T = blockIdx.y, lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= E) return;
+    v2c[((size_t)T * E + p) * 64 + lane] = prior[((size_t)T * n + var_of_pos[p]) * 64 + lane];
+}
+
+// Frames leave (src/bec.py:96-97,120): before the first sweep those without an erasure, afterwards those whose last sweep changed
+// nothing or left nothing erased.  flags[T][0] = changed, flags[T][1] = erased, per lane; both are cleared for the next sweep.
+__global__ __launch_bounds__(64) void k_becs_check(uint32_t* __restrict__ flags, uint32_t* __restrict__ live, int32_t* __restrict__ iters,
+                                                   int* __restrict__ live_tiles, int64_t B, int sweeps) {
+    const int T = blockIdx.x, lane = threadIdx.x;
+    const uint32_t lv = live[(size_t)T * 64 + lane];
+    const uint32_t chg = sweeps == 0 ? ~0u : flags[((size_t)T * 2) * 64 + lane];
+    const uint32_t era = flags[((size_t)T * 2 + 1) * 64 + lane];
+    const uint32_t stay = lv & chg & era;
+    uint32_t leave = lv & ~stay;
+    live[(size_t)T * 64 + lane] = stay;
+    flags[((size_t)T * 2) * 64 + lane] = 0u;
+    flags[((size_t)T * 2 + 1) * 64 + lane] = 0u;
+    const int64_t fl = (int64_t)T * SUPER + (int64_t)lane * 32;
+    while (leave) {
+        const int b = __builtin_ctz(leave);
+        leave &= leave - 1u;
+        if (fl + b < B) iters[fl + b] = sweeps;
+    }
+    if (__ballot(stay != 0u) != 0ull && lane == 0) atomicAdd(live_tiles, 1);
+}
+
+__global__ __launch_bounds__(64) void k_becs_finish(const uint32_t* __restrict__ live, int32_t* __restrict__ iters, int64_t B, int sweeps) {
+    const int T = blockIdx.x, lane = threadIdx.x;
+    uint32_t lv = live[(size_t)T * 64 + lane];
+    const int64_t fl = (int64_t)T * SUPER + (int64_t)lane * 32;
+    while (lv) {
+        const int b = __builtin_ctz(lv);
+        lv &= lv - 1u;
+        if (fl + b < B) iters[fl + b] = sweeps;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Check pass: one wave = (supertile, run of checks).  A check reads the v2c line of each of its edges (each line exactly once in a
+// sweep: non-temporal) and writes ONE summary line.
+__global__ __launch_bounds__(256) void k_becs_cn(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_vpos,
+                                                 const uint2* __restrict__ v2c, uint2* __restrict__ sum, const uint32_t* __restrict__ live,
+                                                 int m, int64_t E, int tiles, int chunks, int cpw) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int T = __builtin_amdgcn_readfirstlane(task / chunks), chunk = __builtin_amdgcn_readfirstlane(task - (task / chunks) * chunks);
+    if (T >= tiles) return;
+    if (__ballot(live[(size_t)T * 64 + lane] != 0u) == 0ull) return;  // nobody left in this supertile
+    const uint2* vt = v2c + (size_t)T * E * 64 + lane;
+    uint2* st = sum + (size_t)T * m * 64 + lane;
+    const int c_end = min(m, (chunk + 1) * cpw);
+    for (int c = chunk * cpw; c < c_end; ++c) {
+        const int k0 = row_ptr[c], k1 = row_ptr[c + 1];
+        uint32_t all = ~0u, two = 0u, par = 0u;  // every incoming message known so far; at least two erased; parity of the +1s
+        for (int k = k0; k < k1; k += 4) {
+            P2 e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = (k + j < k1) ? ld2_nt(vt + (size_t)edge_vpos[k + j] * 64) : P2{~0u, 0u};  // a known 0 is neutral
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                two = B3(two, all, e[j].k, X0 | (~X1 & ~X2));
+                all &= e[j].k;
+                par ^= e[j].v;
+            }
+        }
+        const uint32_t sa = B3(all, two, two, ~X0 & ~X1);    // exactly one erased
+        const uint32_t sb = B3(all, sa, par, X0 | (X1 & X2));  // none erased, or the parity the erased edge learns
+        st[(size_t)c * 64] = make_uint2(sa, sb);
+    }
+}
+
+// Variable pass: one wave = (supertile, run of variables).  Per variable: gather the summaries of its checks, stream its own last
+// messages in and the new ones out (variable-major lines: contiguous), update the decisions of the live frames.
+// DVMAX <= 16: the messages of a variable stay in registers between the counting pass and the output pass.
+template <int DVMAX>
+__global__ __launch_bounds__(256) void k_becs_vn(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ chk_of_pos,
+                                                 const uint2* __restrict__ sum, uint2* __restrict__ v2c, const uint2* __restrict__ prior,
+                                                 uint2* __restrict__ xhat, const uint32_t* __restrict__ live, uint32_t* __restrict__ flags,
+                                                 int n, int m, int64_t E, int tiles, int chunks, int vpw) {
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int T = __builtin_amdgcn_readfirstlane(task / chunks), chunk = __builtin_amdgcn_readfirstlane(task - (task / chunks) * chunks);
+    if (T >= tiles) return;
+    const uint32_t L = live[(size_t)T * 64 + lane];
+    if (__ballot(L != 0u) == 0ull) return;
+    const uint2* st = sum + (size_t)T * m * 64 + lane;
+    uint2* vt = v2c + (size_t)T * E * 64 + lane;
+    const uint2* pt = prior + (size_t)T * n * 64 + lane;
+    uint2* xt = xhat + (size_t)T * n * 64 + lane;
+    uint32_t chg = 0u, era = 0u;
+    const int v_end = min(n, (chunk + 1) * vpw);
+    for (int v = chunk * vpw; v < v_end; ++v) {
+        const int p0 = col_ptr[v], deg = col_ptr[v + 1] - p0;
+        const P2 pr = ld2(pt + (size_t)v * 64);
+        const P2 xo = ld2(xt + (size_t)v * 64);
+        uint32_t ck[DVMAX], cv[DVMAX], in[2 * (DVMAX + 1)];
+        in[0] = pr.v;
+        in[1] = B3(pr.k, pr.v, pr.v, ~X0 | X1);  // [prior >= 0]
+        P2 s[DVMAX], o[DVMAX];
+#pragma unroll
+        for (int j = 0; j < DVMAX; ++j) {
+            if (j < deg) {
+                s[j] = ld2(st + (size_t)chk_of_pos[p0 + j] * 64);
+                o[j] = ld2_nt(vt + (size_t)(p0 + j) * 64);
+            } else {
+                s[j] = P2{0u, 0u};  // a missing edge: "no message"
+                o[j] = P2{0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DVMAX; ++j) {
+            ck[j] = B3(s[j].k, s[j].v, o[j].k, (X1 & ~X0) | (X0 & ~X2));       // echo of a known message, or the one erased edge of its check
+            cv[j] = s[j].v & B3(s[j].k, o[j].k, o[j].v, (X0 & ~X1) | (~X0 & X2));
+            in[2 + 2 * j] = cv[j];
+            in[3 + 2 * j] = B3(ck[j], cv[j], cv[j], ~X0 | X1);
+        }
+        uint32_t S[BitsFor<2 * (DVMAX + 1)>::value];
+        plane_count<2 * (DVMAX + 1)>(in, S);  // S = marginal + DVMAX + 1
+        const uint32_t ge0 = plane_ge(S, DVMAX + 1), ge1 = plane_ge(S, DVMAX + 2), ge2 = plane_ge(S, DVMAX + 3), gem1 = plane_ge(S, DVMAX);
+        const uint32_t ne = B3(ge0, ge1, ge1, X0 & ~X1), nv = ge1;  // sign(marginal) -> erased / 1 / 0 (src/bec.py:119)
+        const uint32_t xe = mux(L, ne, xo.k), xv = mux(L, nv, xo.v);
+        chg |= (xe ^ xo.k) | (xv ^ xo.v);
+        era |= xe & L;
+        xt[(size_t)v * 64] = make_uint2(xe, xv);
+#pragma unroll
+        for (int j = 0; j < DVMAX; ++j) {
+            if (j < deg) {
+                const uint32_t pos = mux(ck[j], mux(cv[j], ge2, ge0), ge1);  // v2c_j = sign(marginal - c_j) (src/bec.py:116)
+                const uint32_t neg = B3(ck[j], B3(cv[j], ge1, gem1, (X0 & ~X1) | (~X0 & ~X2)), ge0, (X0 & X1) | (~X0 & ~X2));
+                st2_nt(vt + (size_t)(p0 + j) * 64, pos | neg, pos);
+            }
+        }
+    }
+    if (chg) atomicOr(&flags[((size_t)T * 2) * 64 + lane], chg);
+    if (era) atomicOr(&flags[((size_t)T * 2 + 1) * 64 + lane], era);
+}
+
+// decisions -> [B, n] bytes {0, 1, 2 = still erased}; one thread per variable (coalesced along v)
+__global__ __launch_bounds__(256) void k_becs_unpack(const uint2* __restrict__ xhat, uint8_t* __restrict__ out, int64_t B, int n) {
+    const int T = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const int64_t f0 = (int64_t)T * SUPER;
+    for (int lane = 0; lane < 64; ++lane) {
+        const int64_t fl = f0 + (int64_t)lane * 32;
+        if (fl >= B) break;
+        const uint2 w = xhat[((size_t)T * n + v) * 64 + lane];
+        const int nb = (int)((B - fl) < 32 ? (B - fl) : 32);
+        for (int b = 0; b < nb; ++b) out[(fl + b) * n + v] = ((w.x >> b) & 1u) ? (uint8_t)2 : (uint8_t)((w.y >> b) & 1u);
+    }
+}
+
+template <typename T>
+int upload_i32(const std::vector<T>& h, DevBuf* buf) {
+    LDPC_TRY(buf->reserve(h.size() * sizeof(T) + 16));
+    LDPC_HIP_TRY(hipMemcpy(buf->p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return LDPC_OK;
+}
+
+}  // namespace
+
+// Batched bec.SPA.decode (src/bec.py:83-122) on the streaming kernels.  y0 [B, n] symbols, xhat [B, n], iters [B] -- device buffers.
+int becs_stream_decode(Decoder* d, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags_in, uint8_t* xhat, int32_t* iters,
+                       hipStream_t st) {
+    const Code* c = d->code;
+    const int n = c->n, m = c->m;
+    const int64_t E = c->E;
+    if (c->max_dv > 64) {
+        set_error("streaming erasure decoder supports variable degrees up to 64 (max_dv=%d)", c->max_dv);
+        return LDPC_E_UNSUPPORTED;
+    }
+    const bool early = !(flags_in & FLAG_NO_EARLY_EXIT);
+    const int tiles = (int)((B + SUPER - 1) / SUPER);
+    // graph in variable-major order, once per decoder: edge_vpos[k] = position of row-major edge k in the CSC list, chk_of_pos / var_of_pos
+    if (!d->scratch.p) {
+        std::vector<int32_t> idx((size_t)3 * E);
+        for (int v = 0; v < n; ++v)
+            for (int p = c->col_ptr[v]; p < c->col_ptr[v + 1]; ++p) {
+                const int k = c->col_edge[p];
+                idx[(size_t)k] = p;                        // edge_vpos
+                idx[(size_t)E + p] = c->edge_chk[k];       // chk_of_pos
+                idx[(size_t)2 * E + p] = v;                // var_of_pos
+            }
+        LDPC_TRY(upload_i32(idx, &d->scratch));
+    }
+    const int32_t* edge_vpos = (const int32_t*)d->scratch.p;
+    const int32_t* chk_of_pos = edge_vpos + E;
+    const int32_t* var_of_pos = edge_vpos + 2 * E;
+    LDPC_TRY(d->msg.reserve((size_t)tiles * E * 64 * 8));
+    LDPC_TRY(d->marg.reserve((size_t)tiles * m * 64 * 8));
+    LDPC_TRY(d->prior.reserve((size_t)tiles * n * 64 * 8));
+    LDPC_TRY(d->xbits.reserve((size_t)tiles * n * 64 * 8));
+    LDPC_TRY(d->live.reserve((size_t)tiles * 64 * 4));
+    LDPC_TRY(d->flags.reserve((size_t)tiles * 2 * 64 * 4 + 64));
+    uint2* v2c = (uint2*)d->msg.p;
+    uint2* sum = (uint2*)d->marg.p;
+    uint2* prior = (uint2*)d->prior.p;
+    uint2* xh = (uint2*)d->xbits.p;
+    uint32_t* live = (uint32_t*)d->live.p;
+    uint32_t* tflags = (uint32_t*)d->flags.p;
+    int* live_tiles = (int*)((char*)d->flags.p + (size_t)tiles * 2 * 64 * 4);
+    volatile int* poll_host = (volatile int*)d->pinned;
+
+    LDPC_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)tiles * 2 * 64 * 4 + 64, st));
+    LDPC_HIP_TRY(hipMemsetAsync(iters, 0, (size_t)B * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_becs_load, dim3((n + 255) / 256, tiles), dim3(256), 0, st, y0, B, n, prior, xh, live, tflags);
+    hipLaunchKernelGGL(k_becs_init, dim3((unsigned)((E + 3) / 4), tiles), dim3(256), 0, st, var_of_pos, prior, v2c, n, E);
+
+    const int cpw = 4, vpw = 8;  // nodes per wave task: short runs keep a supertile's summary lines on chip between the two passes
+    const int cn_chunks = (m + cpw - 1) / cpw, vn_chunks = (n + vpw - 1) / vpw;
+    const int cap = max_iter > 0 ? max_iter : 100000;  // max_iter <= 0 == unlimited upstream (src/bec.py:96); bounded here
+    const int poll_every = 4;
+    int sweeps = 0;
+    bool all_left = false;
+    for (int it = 0; it < cap && !all_left; ++it) {
+        if (early) {
+            const bool poll = (it % poll_every) == 0;
+            if (poll) LDPC_HIP_TRY(hipMemsetAsync(live_tiles, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_becs_check, dim3(tiles), dim3(64), 0, st, tflags, live, iters, live_tiles, B, sweeps);
+            if (poll) {
+                LDPC_HIP_TRY(hipMemcpyAsync((void*)poll_host, live_tiles, sizeof(int), hipMemcpyDeviceToHost, st));
+                LDPC_HIP_TRY(hipStreamSynchronize(st));
+                if (poll_host[0] == 0) {
+                    all_left = true;
+                    break;
+                }
+            }
+        }
+        hipLaunchKernelGGL(k_becs_cn, dim3((unsigned)(((int64_t)tiles * cn_chunks + 3) / 4)), dim3(256), 0, st, c->d_row_ptr, edge_vpos, v2c, sum, live,
+                           m, E, tiles, cn_chunks, cpw);
+        const dim3 vgrid((unsigned)(((int64_t)tiles * vn_chunks + 3) / 4));
+#define LDPC_BECS_VN(DVM) \
+    hipLaunchKernelGGL((k_becs_vn<DVM>), vgrid, dim3(256), 0, st, c->d_col_ptr, chk_of_pos, sum, v2c, prior, xh, live, tflags, n, m, E, tiles, vn_chunks, vpw)
+        if (c->max_dv <= 3) LDPC_BECS_VN(3);
+        else if (c->max_dv <= 4) LDPC_BECS_VN(4);
+        else if (c->max_dv <= 8) LDPC_BECS_VN(8);
+        else if (c->max_dv <= 16) LDPC_BECS_VN(16);
+        else if (c->max_dv <= 32) LDPC_BECS_VN(32);
+        else LDPC_BECS_VN(64);
+#undef LDPC_BECS_VN
+        ++sweeps;
+    }
+    hipLaunchKernelGGL(k_becs_finish, dim3(tiles), dim3(64), 0, st, live, iters, B, sweeps);
+    hipLaunchKernelGGL(k_becs_unpack, dim3((n + 255) / 256, tiles), dim3(256), 0, st, xh, xhat, B, n);
+    LDPC_HIP_TRY(hipGetLastError());
+    d->last_repacks = 0;
+    d->last_sweeps = sweeps;
+    d->last_backend = BK_STREAM;
+    return LDPC_OK;
+}
+
+}  // namespace ldpc

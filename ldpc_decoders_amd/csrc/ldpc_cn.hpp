@@ -5,7 +5,7 @@
 //
 //   min-sum      reference src/bpa.py:86-102 (+ src/math_utils.py:10,38-43,78-94)
 //   sum-product  reference src/bpa.py:71-75  (+ src/math_utils.py:47-60)
-//   erasure      reference src/bec.py:100-112
+//   (erasure decoder, src/bec.py:100-112: bit-sliced, ldpc_bec_planes.hpp / ldpc_bec_kernels.hpp / ldpc_bec_stream.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -245,35 +245,13 @@ __device__ __forceinline__ void cn_spa(float (&v)[DCMAX], int deg) {
     }
 }
 
-// ---- erasure channel (ternary messages in int8) -------------------------------------------------
-template <int DCMAX>
-__device__ __forceinline__ void cn_bec(int8_t (&v)[DCMAX], int deg) {
-    int erased = 0, ones = 0;
-#pragma unroll
-    for (int j = 0; j < DCMAX; ++j) {
-        if (j < deg) {
-            erased += (v[j] == 0);
-            ones += (v[j] > 0);
-        }
-    }
-    const int8_t fill = (int8_t)(2 * (ones & 1) - 1);
-#pragma unroll
-    for (int j = 0; j < DCMAX; ++j) {
-        if (j < deg) {
-            // 0 erasures: echo ; >1: nothing known ; exactly 1: the erased edge learns the parity of the others
-            v[j] = erased == 0 ? v[j] : (erased > 1 ? (int8_t)0 : (v[j] == 0 ? fill : (int8_t)0));
-        }
-    }
-}
-
 template <typename T, int ALG, int DCMAX>
 __device__ __forceinline__ void cn_rule(T (&v)[DCMAX], int deg) {
     if constexpr (ALG == 0) {
         cn_msa<T, DCMAX>(v, deg);
-    } else if constexpr (ALG == 1) {
-        cn_spa<DCMAX>(v, deg);
     } else {
-        cn_bec<DCMAX>(v, deg);
+        static_assert(ALG == 1, "min-sum or sum-product (the erasure decoder is bit-sliced: ldpc_bec_planes.hpp)");
+        cn_spa<DCMAX>(v, deg);
     }
 }
 

@@ -108,6 +108,7 @@ struct Decoder {
     int last_sweeps = 0;
     int last_backend = BK_STREAM;
     int last_repacks = 0;  // frame repacks of the last streaming decode
+    int64_t stream_chunk = 0;  // frames per pass through the streaming kernels (0: not decided yet; ldpc_api.hip stream_chunk_frames)
 };
 
 // event-pair bookkeeping used when Decoder::profile is set
@@ -121,6 +122,9 @@ int prof_collect(Decoder* d, const std::vector<ProfSpan>& spans);
 // ---- backends (each returns an LDPC_* code) -------------------------------------------------------
 int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
                   uint8_t* xhat, int32_t* iters, void* soft_out, hipStream_t st);
+
+// bit-sliced erasure decoder on the streaming kernels (ldpc_bec_stream.hip)
+int becs_stream_decode(Decoder* d, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags, uint8_t* xhat, int32_t* iters, hipStream_t st);
 
 int stream_simulate_biawgn(Decoder* d, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
                            int32_t max_iter, uint32_t flags, uint8_t* xhat, int32_t* iters, hipStream_t st);

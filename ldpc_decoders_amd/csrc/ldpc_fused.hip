@@ -2,6 +2,7 @@
 // gather tables and launches.  The kernels are in ldpc_fused_kernels.hpp, instantiated by the ldpc_fused_shapes_*.hip units.
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -236,15 +237,30 @@ bool obtain_layout(const Code* c, const ShapeChoice& ch, bool use_store, long mo
         if (stat(lock.c_str(), &sb) == 0 && time(nullptr) - sb.st_mtime > 600) (void)unlink(lock.c_str());
         const int fd = open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0600);
         if (fd >= 0) {
+            char pidbuf[32];
+            const int len = snprintf(pidbuf, sizeof(pidbuf), "%ld\n", (long)getpid());
+            if (write(fd, pidbuf, (size_t)len) != len) { /* the lock works without the pid; waiters then fall back to its age */ }
             (void)close(fd);
         } else if (errno == EEXIST) {
             owner = false;
             const double wait_s = 30.0 + (double)moves / 1.0e6;  // the owner needs about moves / 1.7e6 seconds
             for (double waited = 0; waited < wait_s; waited += 0.05) {
                 if (layout_load(save_dir + "/" + name, key, *c, shape.DC, CR, ch.vr, L)) return true;
-                if (stat(lock.c_str(), &sb) != 0) break;  // the owner is gone without a file: anneal here
+                if (stat(lock.c_str(), &sb) != 0) break;  // the lock is gone: published in between (checked below), or the owner died
+                // the owner wrote its pid into the lock: a dead owner is not waited for (it would hold every newcomer for the full wait)
+                long pid = 0;
+                if (FILE* lf = fopen(lock.c_str(), "r")) {
+                    if (fscanf(lf, "%ld", &pid) != 1) pid = 0;
+                    fclose(lf);
+                }
+                if (pid > 0 && kill((pid_t)pid, 0) != 0 && errno == ESRCH) {
+                    (void)unlink(lock.c_str());
+                    break;
+                }
                 usleep(50000);
             }
+            // the owner may have renamed the plan into place and removed the lock between the load and the stat above
+            if (layout_load(save_dir + "/" + name, key, *c, shape.DC, CR, ch.vr, L)) return true;
             lock.clear();  // not ours to remove
         } else {
             lock.clear();  // read-only or missing directory: anneal without publishing
@@ -272,8 +288,7 @@ int fused_plan_host(const Code* c, int alg, int dtype, long moves, const char* o
     FusedLayout L;
     // moves < 0: exactly what ldpc_decoder_create does -- plan store first, otherwise ONE process per node anneals the default run
     const bool found = obtain_layout(c, ch, moves < 0, moves, out_dir ? std::string(out_dir) : (moves < 0 ? plan_save_dir() : std::string()), &L);
-    if (info4) info4[0] = found ? -1.0 : 0.0;
-    info4[0] = (info4[0] < 0 ? -1.0 : 1.0) * all_shapes()[ch.si].NW;  // negative: the plan came out of the store (moves < 0 only)
+    info4[0] = (found ? -1.0 : 1.0) * all_shapes()[ch.si].NW;  // negative: the plan came out of the store (moves < 0 only)
     info4[1] = L.base_cycles;
     info4[2] = L.extra_cycles_identity;
     info4[3] = L.extra_cycles_planned;

@@ -199,13 +199,12 @@ constexpr int sim_opaque_vn(int, int, int) { return LDPC_SIM_OPAQUE_VN_WORDS; }
 #else
 constexpr int sim_opaque_cn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_MSA ? 0 : 15;           // one frame per CU (16 waves): min-sum by the compiler's own allocation (see MAD in the kernel)
-    if (vrx == 0) return alg == ALG_MSA ? 0 : (alg == ALG_BEC ? 0 : 15);  // regular shapes: min-sum 0 + 2, sum-product all; erasure: the compiler's own
-                                                                          // allocation (9 spilled registers, 1.488 against 1.568 ms spill-free)
-    return alg == ALG_BEC ? 8 : 15;                       // irregular shapes (wide variable rounds)
+    if (vrx == 0) return alg == ALG_MSA ? 0 : 15;         // regular shapes: min-sum 0 + 2, sum-product all
+    return 15;                                            // irregular shapes (wide variable rounds)
 }
 constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
-    if (nw > 4) return alg == ALG_SPA ? 15 : 0;           // (the 16-wave erasure kernel streams its variable table anyway)
-    if (vrx == 0) return alg == ALG_SPA ? 15 : (alg == ALG_BEC ? 0 : 2);
+    if (nw > 4) return alg == ALG_SPA ? 15 : 0;
+    if (vrx == 0) return alg == ALG_SPA ? 15 : 2;
     return alg == ALG_MSA ? 8 : 15;
 }
 #endif
@@ -245,7 +244,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
     constexpr int CR = CRW * NW, VR = VRW * NW;
     constexpr int NPAD = VR * 64;
     constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
-    constexpr int VG_BEC = NW > 4 ? 1 : 2;  // variable rounds per pipeline stage of the erasure decoder
     constexpr int VRN = VRW - VRX;  // narrow variable rounds (DV gathers); they follow the VRX wide rounds
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -268,18 +266,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
 #pragma unroll
         for (int q = 0; q < VRW; ++q) vmap_reg[q] = vslot[q * 64 + lane];
     }
-    // BIG: 128 VGPRs per wave do not hold both gather tables next to the messages and priors; the compiler spills part of the
-    // variable-phase table and reloads it after the barrier that ends the check phase.  Measured alternatives (n = 10 000,
-    // 16 384 frames x 48.7 sweeps): re-reading the whole table from L2 every sweep, issued BEFORE that barrier, removes every
-    // spill but is slower for min-sum (11.3 vs 10.0 ms) and sum-product (no change); it wins for the erasure decoder
-    // (14.0 vs 15.4 ms), which keeps it.
-    constexpr int VN_STREAM = (BIG && ALG == ALG_BEC) ? VNW : 0;
-    auto stream_vn = [&]() {
-        if constexpr (VN_STREAM > 0) {
-#pragma unroll
-            for (int i = VNW - VN_STREAM; i < VNW; ++i) vn_idx[i] = __builtin_nontemporal_load(A.vn_tab + (w * VNW + i) * 64 + lane);
-        }
-    };
+    // (BIG: 128 VGPRs per wave do not hold both gather tables next to the messages and priors; the compiler spills part of the
+    // variable-phase table and reloads it after the barrier that ends the check phase.  Re-reading the whole table from L2 every sweep,
+    // issued BEFORE that barrier, removes every spill but measured slower for min-sum -- 11.3 vs 10.0 ms per 16 384 frames x 48.7 sweeps
+    // at n = 10 000 -- and no different for sum-product.)
     auto opaque_tables = [&]() {  // see sim_opaque_cn
         if constexpr (SIM) {
 #pragma unroll
@@ -318,7 +308,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
     unsigned accv = 0;  // sim_count / sim_flush
     int acc_frames = 0;
     unsigned dummy = 0;  // bit q: slot (q, lane) is the "certain" slot that pads short check rows (var_of_slot == -2)
-    if constexpr (SIM || ALG == ALG_BEC || VRX > 0) {
+    if constexpr (SIM || VRX > 0) {
 #pragma unroll
         for (int q = 0; q < VRW; ++q) {
             valid |= (vslot[q * 64 + lane] >= 0) ? (1u << q) : 0u;
@@ -359,34 +349,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
         }
     };
 
-    // second hand-off channel: values produced at the END of a variable phase (or after the last sweep) travel through a
-    // padded MARGINAL slot each wave owns -- those are next written in the following variable phase, i.e. behind a
-    // barrier, whereas the c2v hand-off words are overwritten by the very next check phase.
-    auto exchange_or = [&](uint32_t mine) -> uint32_t {  // OR of the words of all waves (contains one barrier)
-        if constexpr (NW == 1) {
-            return mine;
-        } else if constexpr (SYS) {
-            if (lane == 0) *sysw(16 + w) = mine;
-            wg_barrier();
-            const uint32_t v = *sysw(16 + (lane & (NW - 1)));
-            return (__ballot((v & 1u) != 0u) != 0 ? 1u : 0u) | (__ballot((v & 2u) != 0u) != 0 ? 2u : 0u);
-        } else {
-            if (lane == 0) *lds_word(smem + my_msync) = mine;
-            wg_barrier();
-            uint32_t v = 0;
-#pragma unroll
-            for (int i = 0; i < NW; ++i) v |= *lds_word(smem + A.msync_off[i]);
-            return v;
-        }
-    };
-    // frame error counts after the last sweep: through whichever pair of hand-off words the sweep loop did NOT just use for
-    // its exit verdict (the other wave may still be reading that one): marginal slots for the LLR decoders, c2v slots for
-    // the erasure decoder
+    // frame error counts after the last sweep: through the pair of hand-off words the sweep loop did NOT just use for its exit
+    // verdict (the other wave may still be reading that one): the marginal slots
     auto exchange_add = [&](int mine) -> int {
         if constexpr (NW == 1) {
             return mine;
         } else if constexpr (SYS) {
-            constexpr int CH = ALG == ALG_BEC ? 0 : 16;  // the channel the sweep loop did not just use
+            constexpr int CH = 16;  // the channel the sweep loop did not just use
             if (lane == 0) *sysw(CH + w) = (uint32_t)mine;
             wg_barrier();
             int sum = lane < NW ? (int)*sysw(CH + (lane & (NW - 1))) : 0;
@@ -394,12 +363,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             for (int o = NW / 2; o; o >>= 1) sum += __shfl_xor(sum, o);
             return __builtin_amdgcn_readfirstlane(sum);
         } else {
-            const uint32_t mine_off = ALG == ALG_BEC ? my_sync : my_msync;
+            const uint32_t mine_off = my_msync;
             if (lane == 0) *lds_word(smem + mine_off) = (uint32_t)mine;
             wg_barrier();
             int sum = 0;
 #pragma unroll
-            for (int i = 0; i < NW; ++i) sum += (int)*lds_word(smem + (ALG == ALG_BEC ? A.sync_off[i] : A.msync_off[i]));
+            for (int i = 0; i < NW; ++i) sum += (int)*lds_word(smem + A.msync_off[i]);
             return sum;
         }
     };
@@ -462,15 +431,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                     box_muller<float>(ph.w[2], ph.w[3], z[2], z[3]);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) pri4[t] = -(A.sim_k * (A.sim_mean + A.sim_sigma * z[t]));
-                } else if (A.sim_channel == CH_BSC) {  // same integer threshold and the same LLR expression as k_discrete
+                } else {  // CH_BSC: same integer threshold and the same LLR expression as k_discrete
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int y = A.codeword ^ ((u64)ph.w[t] < A.bsc_thr ? 1 : 0);
                         pri4[t] = A.bsc_llr * (float)(1 - 2 * y);
                     }
-                } else {  // BEC: erased where the word is below the threshold; ternary message {-1 (bit 0), +1 (bit 1), 0 (erased)}
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) pri4[t] = (u64)ph.w[t] < A.bsc_thr ? 0.0f : (A.codeword ? 1.0f : -1.0f);
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -482,14 +448,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 prior[q] = lds_marg[q * 64 + lane];  // padded slots: stale words, never used
                 if (A.sim_channel == CH_BSC) xb |= (__float_as_uint(prior[q]) >> 31) << q;  // x_hat starts as the received word
             }
-        } else if constexpr (ALG == ALG_BEC) {
-            const uint8_t* yf = A.y0 + fr * n;  // received symbols {0,1,2}; message {-1,+1,0}[y] (src/bec.py:76,85)
-#pragma unroll
-            for (int q = 0; q < VRW; ++q) {
-                const int v = vmap_of(q);
-                const int y = v >= 0 ? (int)yf[v] : 2;
-                prior[q] = y == 0 ? -1.0f : (y == 1 ? 1.0f : 0.0f);
-            }
         } else {
             const float* pf = reinterpret_cast<const float*>(A.priors) + fr * n;
 #pragma unroll
@@ -499,11 +457,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             }
         }
         if constexpr (VRX > 0) {
-            // the padding slot of short check rows is a variable known with certainty: +inf LLR (bit 0) for the LLR decoders --
-            // it never wins a minimum, adds nothing to a join and has sign 0 -- and -inf (a known 0) for the erasure decoder
+            // the padding slot of short check rows is a variable known with certainty: +inf LLR (bit 0) -- it never wins a minimum, adds
+            // nothing to a join and has sign 0
 #pragma unroll
             for (int q = 0; q < VRW; ++q)
-                if ((dummy >> q) & 1u) prior[q] = ALG == ALG_BEC ? -__builtin_huge_valf() : __builtin_huge_valf();
+                if ((dummy >> q) & 1u) prior[q] = __builtin_huge_valf();
         }
 #pragma unroll
         for (int r = 0; r < CRW; ++r)
@@ -513,134 +471,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
         int it = 0;
         bool left_at_0 = false;
 
-        unsigned xe = 0;  // erasure decoder: bit q = variable slot (q, lane) still erased (xb then holds the known ones)
-        if constexpr (ALG == ALG_BEC) {
-            // Ternary message passing with the reference's two exits (src/bec.py:96-97,120): "no erasure left" before a
-            // sweep, "x_hat did not change" after it.  `it` counts executed sweeps (the one that finds no change included).
-#pragma unroll
-            for (int q = 0; q < VRW; ++q) {
-                if (q < VRW - 1 || own_last) lds_marg[q * 64 + lane] = prior[q];
-                xb |= (prior[q] > 0.0f) ? (1u << q) : 0u;
-                xe |= (prior[q] == 0.0f) ? (1u << q) : 0u;
-            }
-            xe &= valid;
-            bool erased_any = exchange_or(__ballot(xe != 0u) != 0 ? 1u : 0u) != 0u;  // NW > 1: the barrier also publishes marg
-            if constexpr (NW == 1) __builtin_amdgcn_wave_barrier();
-            int updates = 0;  // the reference's iter_count: sweeps that changed x_hat
-            for (;;) {
-                if (max_iter > 0 && updates >= max_iter) break;
-                if (early && !erased_any) break;
-                lds_set_m0(m0_c2v);
-                opaque_tables();
-                float mg[2][DC];
-#pragma unroll
-                for (int j = 0; j < DC; ++j) mg[0][j] = gat_tab<BIG, CRW * DC, MAD>(smem, cn_idx, j);
-                static_for<0, CRW>([&](auto R_) {
-                    constexpr int r = decltype(R_)::value;
-                    if constexpr (r + 1 < CRW) {
-#pragma unroll
-                        for (int j = 0; j < DC; ++j) mg[(r + 1) & 1][j] = gat_tab<BIG, CRW * DC, MAD>(smem, cn_idx, (r + 1) * DC + j);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // Everything is a small integer held in a float, so the rule is arithmetic, not compares (round 3: 15 -> 7 VALU
-                    // instructions per edge; the erasure kernel was VALU-bound): sign = clamp to [-1, 1] (v_med3_f32); known = sum |sign|,
-                    // ones = (known + sum sign) / 2.
-                    float sgn[DC];
-                    float known = 0.0f, ssum = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < DC; ++j) {
-                        const float dlt = mg[r & 1][j] - c2v_old[r][j];           // v2c = sign(marginal - c2v)  (src/bec.py:116)
-                        sgn[j] = __builtin_amdgcn_fmed3f(dlt, -1.0f, 1.0f);
-                        known += __builtin_fabsf(sgn[j]);
-                        ssum += sgn[j];
-                    }
-                    const float fill = ((int)(0.5f * (known + ssum)) & 1) ? 1.0f : -1.0f;  // parity of the known ones (src/bec.py:110-112)
-                    // 0 erasures: echo; > 1: nothing known; exactly 1: the erased edge learns the parity of the others
-                    const float echo = known == (float)DC ? 1.0f : 0.0f, learn = known == (float)(DC - 1) ? 1.0f : 0.0f;
-                    static_for<0, DC>([&](auto J_) {
-                        constexpr int j = decltype(J_)::value;
-                        const float t = __builtin_fmaf(-__builtin_fabsf(sgn[j]), fill, fill);  // fill on the erased edge, 0 on a known one
-                        const float c = __builtin_fmaf(echo, sgn[j], learn * t);
-                        c2v_old[r][j] = c;
-                        if constexpr (!BIG) lds_st_tid<(r * DC + j) * 256>(c);
-                    });
-                    if constexpr (BIG) {
-                        static_assert(!BIG || DC % 2 == 0, "paired row stores");
-                        static_for<0, DC / 2>([&](auto P_) {
-                            constexpr int pj = 2 * decltype(P_)::value;
-                            lds_st2_rows<r * DC + pj, r * DC + pj + 1>(c2v_vaddr, c2v_old[r][pj], c2v_old[r][pj + 1]);
-                        });
-                    }
-                });
-                stream_vn();
-                if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
-                lds_set_m0(m0_marg);
-                unsigned nb = 0, ne = 0;
-                auto finish_var = [&](auto Q_, float sm) {
-                    constexpr int q = decltype(Q_)::value;
-                    const float m1 = prior[q] + sm;  // small integers: exact
-                    if (q < VRW - 1 || own_last) lds_st_tid<q * 256>(m1);
-                    nb |= (m1 > 0.0f) ? (1u << q) : 0u;
-                    ne |= (m1 == 0.0f) ? (1u << q) : 0u;
-                };
-                if constexpr (VRX > 0) {
-                    float cw[2][DVX];
-#pragma unroll
-                    for (int j = 0; j < DVX; ++j) cw[0][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, j);
-                    static_for<0, VRX>([&](auto Q_) {
-                        constexpr int q = decltype(Q_)::value;
-                        if constexpr (q + 1 < VRX) {
-#pragma unroll
-                            for (int j = 0; j < DVX; ++j) cw[(q + 1) & 1][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, (q + 1) * DVX + j);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        float sw = cw[q & 1][0];
-#pragma unroll
-                        for (int j = 1; j < DVX; ++j) sw += cw[q & 1][j];
-                        finish_var(Q_, sw);
-                    });
-                }
-                float cv[2][VG_BEC][DV];
-#pragma unroll
-                for (int u = 0; u < VG_BEC; ++u)
-#pragma unroll
-                    for (int j = 0; j < DV; ++j)
-                        if (u < VRN) cv[0][u][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, VN0 + u * DV + j);
-                static_for<0, (VRN + VG_BEC - 1) / VG_BEC>([&](auto G_) {
-                    constexpr int g = decltype(G_)::value;
-                    if constexpr (g + 1 < (VRN + VG_BEC - 1) / VG_BEC) {
-#pragma unroll
-                        for (int u = 0; u < VG_BEC; ++u)
-#pragma unroll
-                            for (int j = 0; j < DV; ++j)
-                                if ((g + 1) * VG_BEC + u < VRN)
-                                    cv[(g + 1) & 1][u][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, VN0 + ((g + 1) * VG_BEC + u) * DV + j);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    static_for<0, VG_BEC>([&](auto U_) {
-                        constexpr int u = decltype(U_)::value;
-                        if constexpr (g * VG_BEC + u < VRN) {
-                            float sm = cv[g & 1][u][0];
-#pragma unroll
-                            for (int j = 1; j < DV; ++j) sm += cv[g & 1][u][j];
-                            finish_var(std::integral_constant<int, VRX + g * VG_BEC + u>{}, sm);
-                        }
-                    });
-                });
-                ++it;
-                const unsigned chg = ((nb ^ xb) | (ne ^ xe)) & valid;
-                ne &= valid;
-                // bit 0: some decision changed, bit 1: some variable is still erased (barrier inside for NW > 1)
-                const uint32_t verdict = exchange_or((__ballot(chg != 0u) != 0 ? 1u : 0u) | (__ballot(ne != 0u) != 0 ? 2u : 0u));
-                if constexpr (NW == 1) __builtin_amdgcn_wave_barrier();
-                if (early && !(verdict & 1u)) break;  // stopping set: x_hat stays (it equals the new word anyway)
-                xb = nb;
-                xe = ne;
-                erased_any = (verdict & 2u) != 0u;
-                ++updates;
-            }
-        }
-        if (ALG != ALG_BEC && !SIM && A.y0 != nullptr) {
+        if (!SIM && A.y0 != nullptr) {
             // iteration-0 test of the received hard word (src/bpa.py:20,29): park it in the marg area as -+1
             const uint8_t* yf = A.y0 + fr * n;
 #pragma unroll
@@ -662,7 +493,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
             left_at_0 = early && !any_unsat(unsat != 0);
             if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
         }
-        if (ALG != ALG_BEC && !left_at_0) {
+        if (!left_at_0) {
 #pragma unroll
             for (int q = 0; q < VRW; ++q) if (q < VRW - 1 || own_last) lds_marg[q * 64 + lane] = prior[q];
             if constexpr (NW > 1) wg_barrier(); else __builtin_amdgcn_wave_barrier();
@@ -776,7 +607,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                         });
                     }
                 });
-                stream_vn();
                 const bool unsat = any_unsat(__ballot((synd & 0x80000000u) != 0u) != 0);  // NW > 1: contains the barrier
                 // it == 0: only the BSC checks the received word itself (src/bpa.py:20,29); in SIM mode marg holds +-llr there
                 if (early && (it > 0 || (SIM && A.sim_channel == CH_BSC)) && !unsat) break;
@@ -845,7 +675,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
         }
         if constexpr (SIM) {
             // errors against the all-`codeword` word (src/main.py:41-45), counted from the decision bits
-            const unsigned wrong = ((A.codeword ? ~xb : xb) | xe) & valid;  // an unresolved erasure counts as a bit error
+            const unsigned wrong = (A.codeword ? ~xb : xb) & valid;
             int err = 0;
 #pragma unroll
             for (int q = 0; q < VRW; ++q) err += __popcll(__ballot((wrong >> q) & 1u));
@@ -863,18 +693,16 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
 #pragma unroll
             for (int q = 0; q < VRW; ++q) {
                 const int v = vmap_of(q);
-                if (v >= 0) xf[v] = ((xe >> q) & 1u) ? (uint8_t)2 : (uint8_t)((xb >> q) & 1u);
+                if (v >= 0) xf[v] = (uint8_t)((xb >> q) & 1u);
             }
-            if constexpr (ALG != ALG_BEC) {
-                // soft output: the marginal rows this wave wrote in its last variable phase are still in the LDS (the check phase
-                // that found the syndrome satisfied, or the sweep cap, does not touch them)
-                if (A.soft != nullptr) {
-                    float* sf = reinterpret_cast<float*>(A.soft) + fr * n;
+            // soft output: the marginal rows this wave wrote in its last variable phase are still in the LDS (the check phase
+            // that found the syndrome satisfied, or the sweep cap, does not touch them)
+            if (A.soft != nullptr) {
+                float* sf = reinterpret_cast<float*>(A.soft) + fr * n;
 #pragma unroll
-                    for (int q = 0; q < VRW; ++q) {
-                        const int v = vmap_of(q);
-                        if (v >= 0) sf[v] = it > 0 ? lds_marg[q * 64 + lane] : 0.0f;
-                    }
+                for (int q = 0; q < VRW; ++q) {
+                    const int v = vmap_of(q);
+                    if (v >= 0) sf[v] = it > 0 ? lds_marg[q * 64 + lane] : 0.0f;
                 }
             }
         }

@@ -6,7 +6,6 @@
 //     prior[tile][n][64]   T
 //     xbits[tile/8][n][8]  u64   hard decision of variable v for the 64 frames of a tile (bit f == frame f); the words of EIGHT
 //                                consecutive tiles sit in one 64-byte sector, which is what the syndrome kernel fetches per variable
-//     xera [tile/8][n][8]  u64   (erasure decoder only) "still erased" plane
 //     live [tile]          u64   frames that are still iterating
 // Every H index is wave-uniform (scalar loads); every message access is one contiguous 64-element line.
 //
@@ -25,7 +24,7 @@
 //   flooding loop, max_iter and syndrome exits, x_hat = (marginal < 0) ...... src/bpa.py:17-63
 //   iteration-0 check of the received word (BSC) ............................ src/bpa.py:20,29
 //   variable update: prior + (((0 + c_a) + c_b) + ...) in ascending edge order  src/bpa.py:35, src/math_utils.py:7
-//   erasure decoder incl. "no change" (stopping set) exit .................... src/bec.py:83-122
+// (The erasure decoder of src/bec.py:83-122 has its own bit-sliced streaming kernels: ldpc_bec_stream.hip.)
 #include <cstdlib>
 
 #include "ldpc_cn.hpp"
@@ -99,11 +98,9 @@ __host__ inline size_t plane_words(int tiles, int n) { return (size_t)((tiles + 
 
 // ---------------------------------------------------------------------------------------------------
 // priors [B,n] (frame-major, as numpy hands them over) -> prior tile [n][64]; optional hard word y0 -> planes.
-// BEC: the "prior" is the ternary message {-1,+1,0}[y] (src/bec.py:76,85) and y itself seeds both planes.
-template <typename T, int ALG>
+template <typename T>
 __global__ __launch_bounds__(256) void k_load_tile(const T* __restrict__ priors, const uint8_t* __restrict__ y0, int64_t B,
-                                                   int n, T* __restrict__ prior_t, u64* __restrict__ xbits,
-                                                   u64* __restrict__ xera, u64* __restrict__ flags) {
+                                                   int n, T* __restrict__ prior_t, u64* __restrict__ xbits) {
     __shared__ T sp[64][65];
     __shared__ uint8_t sy[64][68];
     const int tile = blockIdx.y, v0 = blockIdx.x * 64;
@@ -115,37 +112,21 @@ __global__ __launch_bounds__(256) void k_load_tile(const T* __restrict__ priors,
         uint8_t yy = 0;
         if (fr < B && v < n) {
             if (y0) yy = y0[fr * n + v];
-            if constexpr (ALG == ALG_BEC) {
-                val = (T)(yy == 0 ? -1 : (yy == 1 ? 1 : 0));
-            } else {
-                val = priors[fr * n + v];
-            }
+            val = priors[fr * n + v];
         }
         sp[f][tx] = val;
         sy[f][tx] = yy;
     }
     __syncthreads();
-    u64 era_any = 0;
     for (int vv = ty; vv < 64; vv += 4) {
         const int v = v0 + vv;
         if (v < n) {
             prior_t[((int64_t)tile * n + v) * 64 + tx] = sp[tx][vv];
-            const uint8_t s = sy[tx][vv];
-            if constexpr (ALG == ALG_BEC) {
-                const u64 one = __ballot(s == 1), era = __ballot(s >= 2);
-                if (tx == 0) {
-                    xbits[plane_at(tile, v, n)] = one;
-                    xera[plane_at(tile, v, n)] = era;
-                }
-                era_any |= era;
-            } else if (y0) {
-                const u64 one = __ballot(s != 0);
+            if (y0) {
+                const u64 one = __ballot(sy[tx][vv] != 0);
                 if (tx == 0) xbits[plane_at(tile, v, n)] = one;
             }
         }
-    }
-    if constexpr (ALG == ALG_BEC) {
-        if (tx == 0 && era_any) atomicOr(&flags[2 * tile + 1], era_any);
     }
 }
 
@@ -192,12 +173,7 @@ __global__ void k_init_live(u64* __restrict__ live, int64_t B, int tiles) {
 // the reference's v2c is the prior itself (src/bpa.py:19) and there is no old message to subtract.
 template <typename T, int ALG>
 __device__ __forceinline__ T v2c_of(T marg, T c_old) {
-    if constexpr (ALG == ALG_BEC) {
-        const int d = (int)marg - (int)c_old;  // src/bec.py:116-118: the sign of what the other checks say
-        return (T)((d > 0) - (d < 0));
-    } else {
-        return marg - c_old;  // src/bpa.py:37
-    }
+    return marg - c_old;  // src/bpa.py:37
 }
 
 template <typename T, int ALG, int DCMAX, int FIXED_DC, int UNR>
@@ -283,8 +259,8 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
 template <typename T, int ALG, int DVMAX, int UNR, int FIXED_DV>
 __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ col_edge,
                                             const T* __restrict__ c2v, const T* __restrict__ prior_t, T* __restrict__ marg_t,
-                                            const u64* __restrict__ live, u64* __restrict__ xbits, u64* __restrict__ xera,
-                                            u64* __restrict__ flags, int n, int64_t E, int tiles, int chunks, int vpw, int xcd_aware) {
+                                            const u64* __restrict__ live, u64* __restrict__ xbits,
+                                            int n, int64_t E, int tiles, int chunks, int vpw, int xcd_aware) {
     const int lane = threadIdx.x;
     int tile, chunk;
     if (!task_of(tiles, chunks, xcd_aware, &tile, &chunk)) return;
@@ -295,8 +271,6 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
     const T* pt = prior_t + (int64_t)tile * n * 64 + lane;
     T* mt = marg_t + (int64_t)tile * n * 64 + lane;
     u64* xb = xbits + plane_at(tile, 0, n);  // word of variable v at xb[8 * v]
-    u64* xe = (ALG == ALG_BEC) ? xera + plane_at(tile, 0, n) : nullptr;
-    u64 chg = 0, era_any = 0;
     const int v_end = min(n, (chunk + 1) * vpw);
     for (int vbase = chunk * vpw; vbase < v_end; vbase += UNR) {
         T c[UNR][DVMAX];
@@ -336,50 +310,21 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
         for (int u = 0; u < UNR; ++u) {
             if (deg[u] < 0) continue;  // wave-uniform
             const int du = FIXED_DV > 0 ? FIXED_DV : deg[u];
-            bool b_one = false, b_era = false;
+            bool b_one = false;
             if (on) {
-                if constexpr (ALG == ALG_BEC) {
-                    int s = 0;
+                T s = T(0);
 #pragma unroll
-                    for (int j = 0; j < DVMAX; ++j)
-                        if (j < du) s += c[u][j];
-                    const int marg = (int)pr[u] + s;  // |marg| <= 1 + dv <= 65: fits the int8 line
-                    mt[(int64_t)(vbase + u) * 64] = (T)marg;
-                    b_one = marg > 0;
-                    b_era = marg == 0;
-                } else {
-                    T s = T(0);
-#pragma unroll
-                    for (int j = 0; j < DVMAX; ++j)
-                        if (j < du) s += c[u][j];
-                    const T marg = pr[u] + s;
-                    msg_st<LDPC_VN_NTS != 0>(mt + (int64_t)(vbase + u) * 64, marg);
-                    b_one = marg < T(0);  // NaN marginal -> 0 (src/bpa.py:38,62)
-                }
+                for (int j = 0; j < DVMAX; ++j)
+                    if (j < du) s += c[u][j];
+                const T marg = pr[u] + s;
+                msg_st<LDPC_VN_NTS != 0>(mt + (int64_t)(vbase + u) * 64, marg);
+                b_one = marg < T(0);  // NaN marginal -> 0 (src/bpa.py:38,62)
             }
             const u64 one = __ballot(b_one);
             const int vv = vbase + u;
-            if constexpr (ALG == ALG_BEC) {
-                const u64 era = __ballot(b_era);
-                const u64 old1 = xb[8 * vv], olde = xe[8 * vv];
-                const u64 new1 = (old1 & ~lv) | (one & lv), newe = (olde & ~lv) | (era & lv);
-                chg |= (old1 ^ new1) | (olde ^ newe);
-                era_any |= newe & lv;
-                if (lane == 0) {
-                    xb[8 * vv] = new1;
-                    xe[8 * vv] = newe;
-                }
-            } else {
-                u64 merged = one;
-                if (lv != ~0ull) merged = (xb[8 * vv] & ~lv) | (one & lv);
-                if (lane == 0) xb[8 * vv] = merged;
-            }
-        }
-    }
-    if constexpr (ALG == ALG_BEC) {
-        if (lane == 0) {
-            if (chg) atomicOr(&flags[2 * tile], chg);
-            if (era_any) atomicOr(&flags[2 * tile + 1], era_any);
+            u64 merged = one;
+            if (lv != ~0ull) merged = (xb[8 * vv] & ~lv) | (one & lv);
+            if (lane == 0) xb[8 * vv] = merged;
         }
     }
 }
@@ -490,29 +435,7 @@ __global__ __launch_bounds__(256) void k_repack(const T* __restrict__ msg_src, T
     }
 }
 
-// Erasure decoder exit test (src/bec.py:97,120): keep iterating only while erasures remain AND the last sweep changed x_hat.
-__global__ void k_bec_check(u64* __restrict__ flags, u64* __restrict__ live, int32_t* __restrict__ iters,
-                            int* __restrict__ live_tiles, int64_t B, int tiles, int sweeps) {
-    const int tile = blockIdx.x, t = threadIdx.x;
-    const u64 lv = live[tile];
-    if (lv == 0) return;
-    const u64 chg = sweeps == 0 ? ~0ull : flags[2 * tile];
-    const u64 era = flags[2 * tile + 1];
-    const u64 stay = lv & chg & era, leave = lv & ~stay;
-    __syncthreads();
-    if (t == 0) {
-        live[tile] = stay;
-        flags[2 * tile] = 0;
-        flags[2 * tile + 1] = 0;
-        if (stay && live_tiles) atomicAdd(live_tiles, 1);
-    }
-    if ((leave >> t) & 1ull) {
-        const int64_t fr = (int64_t)tile * 64 + t;
-        if (fr < B) iters[fr] = sweeps;
-    }
-}
-
-// Frames that hit max_iter: iters = sweeps ; then planes -> x_hat bytes [B,n] in {0,1} ({0,1,2} for BEC).
+// Frames that hit max_iter: iters = sweeps ; then planes -> x_hat bytes [B,n] in {0,1}.
 __global__ void k_finish_iters(const u64* __restrict__ live, int32_t* __restrict__ iters, int64_t B, int sweeps,
                                const int32_t* __restrict__ frame_of) {
     const int tile = blockIdx.x, t = threadIdx.x;
@@ -530,15 +453,12 @@ __global__ void k_soft_out(const T* __restrict__ soft_t, T* __restrict__ out, in
     if (v < n && fr < B) out[fr * n + v] = soft_t[((int64_t)tile * n + v) * 64 + lane];
 }
 
-template <int ALG>
-__global__ __launch_bounds__(256) void k_unpack(const u64* __restrict__ xbits, const u64* __restrict__ xera,
-                                                uint8_t* __restrict__ xhat, int64_t B, int n, const int32_t* __restrict__ frame_of) {
+__global__ __launch_bounds__(256) void k_unpack(const u64* __restrict__ xbits, uint8_t* __restrict__ xhat, int64_t B, int n,
+                                                const int32_t* __restrict__ frame_of) {
     const int tile = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= n) return;
     const u64 one = xbits[plane_at(tile, v, n)];
-    u64 era = 0;
-    if constexpr (ALG == ALG_BEC) era = xera[plane_at(tile, v, n)];
     const int64_t f0 = (int64_t)tile * 64;
     if (frame_of) {  // repacked tiles: lane f holds frame frame_of[tile][f] (-1: none)
         for (int f = 0; f < 64; ++f) {
@@ -548,11 +468,7 @@ __global__ __launch_bounds__(256) void k_unpack(const u64* __restrict__ xbits, c
         return;
     }
     const int fmax = (int)min((int64_t)64, B - f0);
-    for (int f = 0; f < fmax; ++f) {
-        uint8_t s = (uint8_t)((one >> f) & 1ull);
-        if constexpr (ALG == ALG_BEC) s = ((era >> f) & 1ull) ? (uint8_t)2 : s;
-        xhat[(f0 + f) * n + v] = s;
-    }
+    for (int f = 0; f < fmax; ++f) xhat[(f0 + f) * n + v] = (uint8_t)((one >> f) & 1ull);
 }
 
 int pick_pow2_ge(int x, int lo, int hi) {
@@ -586,11 +502,10 @@ void launch_cn(const Code* c, T* c2v, const T* src, const u64* live, const Geome
 }
 
 template <typename T, int ALG, int DVMAX, int FIXED_DV = 0>
-void launch_vn(const Code* c, const T* c2v, const T* prior, T* marg, const u64* live, u64* xbits, u64* xera, u64* flags,
-               const Geometry& g, hipStream_t st) {
+void launch_vn(const Code* c, const T* c2v, const T* prior, T* marg, const u64* live, u64* xbits, const Geometry& g, hipStream_t st) {
     constexpr int UNR = unroll_for((DVMAX + 1) * (int)sizeof(T));
     hipLaunchKernelGGL((k_vn<T, ALG, DVMAX, UNR, FIXED_DV>), dim3(task_blocks(g.tiles, g.vn_chunks, g.xcd_aware)), dim3(64, 4), 0, st, c->d_col_ptr, c->d_col_edge,
-                       c2v, prior, marg, live, xbits, xera, flags, c->n, c->E, g.tiles, g.vn_chunks, g.vpw, g.xcd_aware);
+                       c2v, prior, marg, live, xbits, c->n, c->E, g.tiles, g.vn_chunks, g.vpw, g.xcd_aware);
 }
 
 template <typename T, int ALG>
@@ -615,22 +530,21 @@ int dispatch_cn(const Code* c, T* c2v, const T* src, const u64* live, const Geom
 }
 
 template <typename T, int ALG>
-int dispatch_vn(const Code* c, const T* c2v, const T* prior, T* marg, const u64* live, u64* xbits, u64* xera, u64* flags,
-                const Geometry& g, hipStream_t st) {
+int dispatch_vn(const Code* c, const T* c2v, const T* prior, T* marg, const u64* live, u64* xbits, const Geometry& g, hipStream_t st) {
     if (c->min_dv == c->max_dv && c->max_dv == 3) {  // (3, r)-regular codes
-        launch_vn<T, ALG, 3, 3>(c, c2v, prior, marg, live, xbits, xera, flags, g, st);
+        launch_vn<T, ALG, 3, 3>(c, c2v, prior, marg, live, xbits, g, st);
         return 0;
     }
     if (c->min_dv == c->max_dv && c->max_dv == 4) {
-        launch_vn<T, ALG, 4, 4>(c, c2v, prior, marg, live, xbits, xera, flags, g, st);
+        launch_vn<T, ALG, 4, 4>(c, c2v, prior, marg, live, xbits, g, st);
         return 0;
     }
     switch (pick_pow2_ge(c->max_dv, 4, 64)) {
-        case 4: launch_vn<T, ALG, 4>(c, c2v, prior, marg, live, xbits, xera, flags, g, st); break;
-        case 8: launch_vn<T, ALG, 8>(c, c2v, prior, marg, live, xbits, xera, flags, g, st); break;
-        case 16: launch_vn<T, ALG, 16>(c, c2v, prior, marg, live, xbits, xera, flags, g, st); break;
-        case 32: launch_vn<T, ALG, 32>(c, c2v, prior, marg, live, xbits, xera, flags, g, st); break;
-        default: launch_vn<T, ALG, 64>(c, c2v, prior, marg, live, xbits, xera, flags, g, st); break;
+        case 4: launch_vn<T, ALG, 4>(c, c2v, prior, marg, live, xbits, g, st); break;
+        case 8: launch_vn<T, ALG, 8>(c, c2v, prior, marg, live, xbits, g, st); break;
+        case 16: launch_vn<T, ALG, 16>(c, c2v, prior, marg, live, xbits, g, st); break;
+        case 32: launch_vn<T, ALG, 32>(c, c2v, prior, marg, live, xbits, g, st); break;
+        default: launch_vn<T, ALG, 64>(c, c2v, prior, marg, live, xbits, g, st); break;
     }
     return 0;
 }
@@ -664,7 +578,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     // Frame repack (see k_repack): LLR decoders without soft output.  Policy: at a poll, when the live frames would fill less than
     // `fill` of the tiles that still hold one, gather them into dense tiles -- a repack moves (E + 2n) lines per tile once, a sweep
     // moves about (3E + 3n), so it pays as soon as about one more sweep follows.
-    bool repack_ok = early && ALG != ALG_BEC && soft_out == nullptr && tiles >= 2;
+    bool repack_ok = early && soft_out == nullptr && tiles >= 2;
     double repack_fill = 0.75;
     if (const char* e = std::getenv("LDPC_STREAM_REPACK")) repack_ok = repack_ok && atoi(e) != 0;
     if (const char* e = std::getenv("LDPC_STREAM_REPACK_FILL")) repack_fill = atof(e);
@@ -677,7 +591,6 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     LDPC_TRY(d->xbits.reserve(plane_words(tiles, n) * 8));
     LDPC_TRY(d->live.reserve((size_t)tiles * 8));
     LDPC_TRY(d->flags.reserve((size_t)tiles * 16 + 64 + POLL_RING * 16));
-    if (ALG == ALG_BEC) LDPC_TRY(d->xera.reserve(plane_words(tiles, n) * 8));
     if (repack_ok) {
         // second state set: the first repack fires at <= fill * 64 live frames per tile, later ones only shrink
         const size_t nt = (size_t)(repack_fill * tiles) + 2;
@@ -691,7 +604,6 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     T* marg = (T*)d->marg.p;
     T* prior = (T*)d->prior.p;
     u64* xbits = (u64*)d->xbits.p;
-    u64* xera = (u64*)d->xera.p;
     u64* live = (u64*)d->live.p;
     u64* tflags = (u64*)d->flags.p;                                        // [tiles][2]
     int* poll_dev = (int*)((char*)d->flags.p + (size_t)tiles * 16 + 64);  // [POLL_RING][4] ints: live tiles, live frames
@@ -732,15 +644,12 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     LDPC_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)tiles * 16 + 64 + POLL_RING * 16, st));
     LDPC_HIP_TRY(hipMemsetAsync(iters, 0, (size_t)B * sizeof(int32_t), st));
     if (soft_out) LDPC_HIP_TRY(hipMemsetAsync(marg, 0, (size_t)tiles * n * 64 * sizeof(T), st));  // frames that never sweep report 0
-    if constexpr (ALG != ALG_BEC) {
-        if (sim) {  // device Monte-Carlo over BI-AWGN: the noise goes straight into the tile layout
-            const int bpf = (n + 3) / 4, bpw = 16;
-            hipLaunchKernelGGL((k_biawgn_tile<T>), dim3(((bpf + bpw - 1) / bpw + 3) / 4, tiles), dim3(64, 4), 0, st, *sim, B, n, bpf, bpw, prior);
-        }
+    if (sim) {  // device Monte-Carlo over BI-AWGN: the noise goes straight into the tile layout
+        const int bpf = (n + 3) / 4, bpw = 16;
+        hipLaunchKernelGGL((k_biawgn_tile<T>), dim3(((bpf + bpw - 1) / bpw + 3) / 4, tiles), dim3(64, 4), 0, st, *sim, B, n, bpf, bpw, prior);
     }
     if (!sim)
-        hipLaunchKernelGGL((k_load_tile<T, ALG>), dim3((n + 63) / 64, tiles), dim3(256), 0, st, (const T*)priors_v, y0, B, n,
-                           prior, xbits, xera, tflags);
+        hipLaunchKernelGGL((k_load_tile<T>), dim3((n + 63) / 64, tiles), dim3(256), 0, st, (const T*)priors_v, y0, B, n, prior, xbits);
     hipLaunchKernelGGL(k_init_live, dim3((tiles + 255) / 256), dim3(256), 0, st, live, B, tiles);
 
     const int cap = max_iter > 0 ? max_iter : 100000;  // max_iter <= 0 == unlimited upstream (src/bpa.py:28); bounded here
@@ -764,7 +673,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     std::vector<ProfSpan> spans;
     bool all_left = false;
     for (int it = 0; it < cap && !all_left; ++it) {
-        const bool check = early && (ALG == ALG_BEC || it > 0 || y0 != nullptr);
+        const bool check = early && (it > 0 || y0 != nullptr);
         if (check) {
             const bool poll = (it % poll_every) == 0 || max_iter <= 0;
             int* slot_dev = nullptr;
@@ -774,9 +683,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                 slot_dev = poll_dev + 4 * slot;
                 LDPC_HIP_TRY(hipMemsetAsync(slot_dev, 0, 2 * sizeof(int), st));
             }
-            if (ALG == ALG_BEC) {
-                hipLaunchKernelGGL(k_bec_check, dim3(cur_tiles), dim3(64), 0, st, tflags, live, iters, slot_dev, B, cur_tiles, sweeps);
-            } else {
+            {
                 // groups of eight tiles x chunks of the checks: enough blocks to fill the chip (about 4 per CU), at least 1024 checks each
                 const int groups = (cur_tiles + 7) / 8;
                 int sblocks = (1024 + groups - 1) / groups;
@@ -809,7 +716,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                         const int nt = (lf + 63) / 64;
                         const int nx = 1 - cur;
                         // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs later)
-                        hipLaunchKernelGGL((k_unpack<ALG>), dim3((n + 255) / 256, cur_tiles), dim3(256), 0, st, xbits, xera, xhat, B, n, fmap);
+                        hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256, cur_tiles), dim3(256), 0, st, xbits, xhat, B, n, fmap);
                         hipLaunchKernelGGL(k_repack_plan, dim3(1), dim3(1024), 0, st, live, cur_tiles, (int32_t*)d->rbase.p);
                         const int rows_per_wave = 128;
                         const int chunks = (int)((E + n + rows_per_wave - 1) / rows_per_wave);
@@ -842,7 +749,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
         }
         dispatch_cn<T, ALG>(c, msg, it == 0 ? prior : marg, live, g, it == 0 ? 1 : 0, st);
         if (d->profile) LDPC_HIP_TRY(hipEventRecord(e1, st));
-        dispatch_vn<T, ALG>(c, msg, prior, marg, live, xbits, xera, tflags, g, st);
+        dispatch_vn<T, ALG>(c, msg, prior, marg, live, xbits, g, st);
         if (d->profile) {
             LDPC_HIP_TRY(hipEventRecord(e2, st));
             spans.push_back({0, e0, e1});
@@ -851,8 +758,8 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
         ++sweeps;
     }
     hipLaunchKernelGGL(k_finish_iters, dim3(cur_tiles), dim3(64), 0, st, live, iters, B, sweeps, fmap);
-    hipLaunchKernelGGL((k_unpack<ALG>), dim3((n + 255) / 256, cur_tiles), dim3(256), 0, st, xbits, xera, xhat, B, n, fmap);
-    if (soft_out && ALG != ALG_BEC)
+    hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256, cur_tiles), dim3(256), 0, st, xbits, xhat, B, n, fmap);
+    if (soft_out)
         hipLaunchKernelGGL(k_soft_out<T>, dim3((n + 3) / 4, tiles), dim3(256), 0, st, marg, (T*)soft_out, B, n);
     LDPC_HIP_TRY(hipGetLastError());
     // polls still in flight copy into the pinned ring; the next decode of this handle may run on another stream and reuse the slots:
@@ -904,7 +811,7 @@ int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, 
             set_error("erasure decoder needs the received symbols (y0)");
             return LDPC_E_ARG;
         }
-        return run<int8_t, ALG_BEC>(d, nullptr, y0, B, max_iter, flags, xhat, iters, nullptr, st);
+        return becs_stream_decode(d, y0, B, max_iter, flags, xhat, iters, st);  // bit-sliced: ldpc_bec_stream.hip
     }
     if (!priors) {
         set_error("priors pointer is null");

@@ -110,7 +110,10 @@ def test_spa_fp64_vs_reference(path, backend):
     allowed = SPA_F64_ALLOWED_FLIPS.get((case_id(path), backend), set())
     differing = set(int(f) for f in keep[~same])
     assert differing <= allowed, "frames %s differ from the reference (allowed: %s)" % (sorted(differing - allowed), sorted(allowed))
-    assert it_same.all() or differing, "iteration counts of converging frames differ: %s" % np.flatnonzero(~it_same)
+    # iteration counts of every converging frame that is not on the allow-list (one allow-listed flip must not switch the
+    # check off for all the others)
+    checked = ~np.isin(keep[conv], sorted(allowed))
+    assert it_same[checked].all(), "iteration counts of converging frames differ: %s" % keep[conv][checked][~it_same[checked]]
 
 
 SPA_TRACE_CASES = [p for p in decode_cases("*_SPA_*") if "bec_" not in p]

@@ -14,6 +14,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SQ1="SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS GRBM_GUI_ACTIVE"
 SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES GRBM_GUI_ACTIVE"
+# LDS instruction split + queue counters (which unit of the LDS path binds: the array, or the address / data transfer of the stores)
+SQ4="SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INSTS_LDS_ATOMIC SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
 # VALU instruction mix (issue-cycle model of the VALU-bound kernels): only the counters this rocprofv3 knows
 SQ3=""
 LIST=$(rocprofv3 -L 2>/dev/null)
@@ -44,6 +46,7 @@ for C in "${CASES[@]}"; do
   if [[ $PASSES == *sq* ]]; then
     rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $OUT/$NAME/sq1 -o p -- python3 $R/tools/sim_driver.py $ARGS --info $OUT/$NAME/sq1.info.json > $OUT/$NAME.sq1.log 2>&1
     rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $OUT/$NAME/sq2 -o p -- python3 $R/tools/sim_driver.py $ARGS --info $OUT/$NAME/sq2.info.json > $OUT/$NAME.sq2.log 2>&1
+    rocprofv3 --pmc $SQ4 --kernel-trace --output-format csv -d $OUT/$NAME/sq4 -o p -- python3 $R/tools/sim_driver.py $ARGS --info $OUT/$NAME/sq4.info.json > $OUT/$NAME.sq4.log 2>&1
     if [ -n "$SQ3" ]; then
       rocprofv3 --pmc $SQ3 --kernel-trace --output-format csv -d $OUT/$NAME/sq3 -o p -- python3 $R/tools/sim_driver.py $ARGS --info $OUT/$NAME/sq3.info.json > $OUT/$NAME.sq3.log 2>&1
     fi
