@@ -303,7 +303,18 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
         f32_res = run_point(sim3, h3, comm, args.snr, args.steps, 1, args.batch, 0, torch, True, 3)
         f32_res["backend"] = h3.last_stats()[0]
         f32_res["kernel"] = h3.kernel_name(True) if f32_res["backend"] == "fused" else ""
-        del sim3, h3
+        del sim3
+        # exact-in-fp32 mode: the same fp32 kernel family on priors rounded to multiples of 2^-8, under the exactness guard; frames beyond
+        # it are decoded again in fp64 -- every counted frame is what the fp64 reference returns for those priors (never `value`)
+        exact_res = None
+        try:
+            sim4 = DeviceSimulator(h3, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=min(args.max_iter + 1, 60), prior_grid=8)
+            exact_res = run_point(sim4, h3, comm, args.snr, max(4, args.steps // 4), 1, args.batch, 0, torch, False, 1)
+            exact_res["redone"], exact_res["steps"] = sim4.redone, max(4, args.steps // 4)
+            del sim4
+        except Exception as e:  # a side leg must not cost the benchmark line
+            exact_res = {"error": repr(e)}
+        del h3
 
     def kernel_ms(r):
         return None if not r.get("profile") else sum(r["profile"][k][0] for k in KERNEL_CLASSES)
@@ -423,6 +434,18 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
         if fp and fp["fused_decode"][1] > 0:
             f32["roofline"] = fused_roofline(f32_res["kernel"], int(f32_res["counters"][3]) / (fp["fused_decode"][0] * 1e-3), cus)
         out["fp32_mode"] = f32
+        if exact_res is not None and "error" not in exact_res:
+            ec = exact_res["counters"]
+            out["exact_fp32_mode"] = {
+                "frames_per_s": round(int(ec[0]) / exact_res["seconds"], 1), "ms_per_step": round(1e3 * exact_res["seconds"] / exact_res["steps"], 4),
+                "prior_grid": "2^-8", "frames": int(ec[0]), "frames_redone_in_fp64": int(exact_res["redone"]),
+                "mean_sweeps": round(int(ec[3]) / max(int(ec[0]), 1), 3), "wer": round(int(ec[1]) / max(int(ec[0]), 1), 6),
+                "note": "fp32 LDS kernel (k_fused_bp_grid) on LLRs rounded to multiples of 2^-8 with the in-kernel exactness guard; frames whose "
+                        "messages leave the exact range are decoded again in fp64: decisions, iteration counts and counters equal the fp64 "
+                        "reference's on the same priors for EVERY frame (tests/test_gpu_exact_fp32.py).  Synchronous rounds (the redo list is "
+                        "read after each).  Not `value`: the priors differ from the unquantised workload's."}
+        elif exact_res is not None:
+            out["exact_fp32_mode"] = exact_res
     if stream_res is not None:
         sp, sc = stream_res["profile"], stream_res["counters"]
         it_sum = int(sc[3])

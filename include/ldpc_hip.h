@@ -35,6 +35,16 @@ enum { LDPC_BACKEND_AUTO = 0, LDPC_BACKEND_STREAM = 1, LDPC_BACKEND_FUSED = 2 };
 enum { LDPC_CH_BIAWGN = 0, LDPC_CH_BSC = 1, LDPC_CH_BEC = 2 };       /* channel selector: src/models.py:3               */
 enum { LDPC_CH_RAW_OBSERVATION = 0x100 };  /* or-ed into LDPC_CH_BIAWGN for ldpc_channel: write y itself, not -2y/sigma^2 */
 enum { LDPC_FLAG_NO_EARLY_EXIT = 1 };                                /* NOT reference behaviour: run exactly max_iter   */
+/* Exact-in-fp32 min-sum (no upstream counterpart; the injection point is BPA.decode(y, priors), src/bpa.py:17): priors rounded to
+ * multiples of 2^-k.  Min-sum only adds, subtracts and compares, so on such priors fp32 arithmetic reproduces the fp64 reference BIT FOR
+ * BIT for as long as every message stays below 2^(24-k) / 8; the LDS-resident fp32 kernels check exactly that and count the frames
+ * that do not (ldpc_decoder_grid_violations -- a run is exact iff the count is 0).  k = 0..23.
+ *   ldpc_simulate / ldpc_decode: flags | LDPC_FLAG_PRIOR_GRID(k)   (simulate: quantises the generated priors AND arms the guard; decode: arms the guard)
+ *   ldpc_channel:                channel | LDPC_CH_PRIOR_GRID(k)   (quantises the LLRs it writes; any dtype) */
+#define LDPC_FLAG_PRIOR_GRID(k) ((((uint32_t)(k)) + 1u) << 8)
+#define LDPC_FLAG_PRIOR_GRID_OF(flags) ((int)(((flags) >> 8) & 0x1fu) - 1) /* -1: off */
+#define LDPC_CH_PRIOR_GRID(k) ((((int)(k)) + 1) << 12)
+#define LDPC_CH_PRIOR_GRID_OF(channel) ((((channel) >> 12) & 0x1f) - 1)
 enum { LDPC_E_ARG = -1, LDPC_E_HIP = -2, LDPC_E_GRAPH = -3, LDPC_E_UNSUPPORTED = -4, LDPC_E_NOMEM = -5 };
 
 /* counters written by ldpc_count_errors / ldpc_simulate (int64 each) */
@@ -61,6 +71,12 @@ int ldpc_decoder_last_stats(ldpc_decoder_t dec, int* backend, int* sweeps);
 /* streaming backend: how often the last decode gathered its live frames into dense tiles (per-frame early termination,
  * src/bpa.py:28-29: a frame that has left costs nothing; tiles of 64 frames are re-formed from the live ones) */
 int ldpc_decoder_last_repacks(ldpc_decoder_t dec, int* repacks);
+/* exact-in-fp32 mode: frames in which a message left the range where fp32 sums of grid multiples are exact (a frame caught in a
+ * trapping set: its min-sum messages grow geometrically; about 1 in 10^4 at 2 dB), since the last reset.  Such a frame is NOT counted
+ * by ldpc_simulate, and ldpc_decode marks it with iters = -1 - sweeps; its global frame index (frame0 + position) is listed in
+ * frames[0 .. min(count, cap, 4095)) so that the caller decodes it again in fp64 on the same priors (ldpc_decoders_amd/_device.py does).
+ * Synchronises the device. */
+int ldpc_decoder_grid_violations(ldpc_decoder_t dec, int64_t* count, int64_t* frames, int64_t cap, int reset);
 
 /* Fused-backend plan of this decoder: out8 = {wavefronts per frame (0 = fused backend unavailable), conflict-free LDS gather cycles per sweep, extra bank-conflict
  * cycles with the trivial placement, extra cycles with the planned placement, resident waves per CU, LDS bytes per

@@ -133,8 +133,9 @@ class DecoderHandle:
                                                 flags, xhat.data_ptr(), iters.data_ptr(), marg.data_ptr(), st))
         return xhat, iters, marg
 
-    def channel_device(self, channel, param, codeword, seed, stream_id, frame0, B):
-        """Device channel + LLR kernels only: returns (priors or None, y or None) CUDA tensors for frames [frame0, frame0+B)."""
+    def channel_device(self, channel, param, codeword, seed, stream_id, frame0, B, prior_grid=None):
+        """Device channel + LLR kernels only: returns (priors or None, y or None) CUDA tensors for frames [frame0, frame0+B).
+        ``prior_grid`` = k: the LLRs are rounded to multiples of 2^-k (exact-in-fp32 mode)."""
         import torch
 
         n = self.code.n
@@ -142,7 +143,7 @@ class DecoderHandle:
         pri = None if channel == "bec" else torch.empty((B, n), dtype=dt, device="cuda")
         y = None if channel == "biawgn" else torch.empty((B, n), dtype=torch.uint8, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.load().ldpc_channel(_lib.CHANNEL[channel], _lib.DTYPE[self.precision], float(param), int(codeword), int(seed),
+        _lib.check(_lib.load().ldpc_channel(_lib.CHANNEL[channel] | _lib.ch_prior_grid(prior_grid), _lib.DTYPE[self.precision], float(param), int(codeword), int(seed),
                                             int(stream_id), int(frame0), int(B), n, None if pri is None else pri.data_ptr(),
                                             None if y is None else y.data_ptr(), st))
         return pri, y
@@ -210,6 +211,50 @@ class DecoderHandle:
         b, s = ctypes.c_int(0), ctypes.c_int(0)
         _lib.check(_lib.load().ldpc_decoder_last_stats(self.h, ctypes.byref(b), ctypes.byref(s)))
         return _lib.BACKEND_NAME.get(b.value, "?"), s.value
+
+    def grid_violations(self, reset=True):
+        """Exact-in-fp32 mode: (count, global frame indices) of the frames set aside by the exactness guard since the last reset."""
+        c = ctypes.c_int64(0)
+        frames = np.zeros(4095, dtype=np.int64)
+        _lib.check(_lib.load().ldpc_decoder_grid_violations(self.h, ctypes.byref(c), frames.ctypes.data, len(frames), 1 if reset else 0))
+        return c.value, frames[:min(c.value, len(frames))].copy()
+
+    def _fp64_sibling(self):
+        """The same decoder in the reference's own arithmetic: re-decodes the few frames the exactness guard sets aside."""
+        if getattr(self, "_sib64", None) is None:
+            self._sib64 = DecoderHandle(self.code, self.alg, "f64", "auto", self.code_handle.device)
+        return self._sib64
+
+    def decode_device_exact_fp32(self, priors, max_iter, k):
+        """fp32 min-sum on priors that lie on the 2^-k grid (``channel_device(..., prior_grid=k)``), guaranteed to return what the fp64
+        reference returns for the same priors: frames whose messages left the range where fp32 sums are exact -- the kernel marks them
+        -- are decoded again in fp64.  -> (xhat, iters, frames_redone)"""
+        xh, it = self.decode_device(priors, None, max_iter, flags=_lib.flag_prior_grid(k))
+        self.grid_violations()
+        bad = (it < 0).nonzero().flatten()
+        if len(bad):
+            x64, i64 = self._fp64_sibling().decode_device(priors[bad].double().contiguous(), None, max_iter)
+            xh[bad], it[bad] = x64, i64
+        return xh, it, int(len(bad))
+
+    def simulate_exact_fp32(self, param, codeword, seed, stream_id, frame0, B, max_iter, counters, k, hist_bins=0):
+        """``simulate`` over BI-AWGN in the exact-in-fp32 mode: the LDS-resident fp32 kernel draws priors on the 2^-k grid and counts every
+        frame its guard vouches for; the others (listed by the kernel) are generated again, decoded in fp64 and added to ``counters``
+        here.  The counters are then those of the fp64 reference on those priors, frame for frame.  -> frames redone in fp64"""
+        import torch
+
+        self.simulate("biawgn", param, codeword, seed, stream_id, frame0, B, max_iter, counters, flags=_lib.flag_prior_grid(k), hist_bins=hist_bins)
+        cnt, frames = self.grid_violations()
+        if cnt > len(frames):
+            raise _lib.LdpcHipError("prior grid 2^-%d: %d frames beyond the exactness guard in one call -- the grid is too fine for this operating point" % (k, cnt))
+        if cnt:
+            h64 = self._fp64_sibling()
+            pri = torch.cat([self.channel_device("biawgn", param, codeword, seed, stream_id, int(f), 1, prior_grid=k)[0] for f in frames])
+            xh, it = h64.decode_device(pri.double().contiguous(), None, max_iter)
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.load().ldpc_count_errors(xh.data_ptr(), None, int(codeword), it.data_ptr(), len(frames), self.code.n, hist_bins,
+                                                     counters.data_ptr(), st))
+        return int(cnt)
 
     def last_repacks(self):
         """Streaming backend: how often the last decode re-formed its tiles from the live frames."""

@@ -17,6 +17,18 @@ BACKEND_NAME = {v: k for k, v in BACKEND.items()}
 CHANNEL = {"biawgn": 0, "bsc": 1, "bec": 2}
 CH_RAW_OBSERVATION = 0x100
 FLAG_NO_EARLY_EXIT = 1
+
+
+def flag_prior_grid(k):
+    """LDPC_FLAG_PRIOR_GRID(k) of include/ldpc_hip.h: exact-in-fp32 min-sum on priors rounded to multiples of 2^-k (None: off)."""
+    return 0 if k is None else (int(k) + 1) << 8
+
+
+def ch_prior_grid(k):
+    """LDPC_CH_PRIOR_GRID(k): the channel kernel rounds the LLRs it writes to multiples of 2^-k (None: off)."""
+    return 0 if k is None else (int(k) + 1) << 12
+
+
 CNT_TOT, CNT_WEC, CNT_BEC, CNT_ITER_SUM, CNT_HIST0 = 0, 1, 2, 3, 4
 
 _c = ctypes
@@ -33,6 +45,7 @@ SIGNATURES = {
     "ldpc_decoder_destroy": (_c.c_int, [_P]),
     "ldpc_decoder_last_stats": (_c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
     "ldpc_decoder_last_repacks": (_c.c_int, [_P, _c.POINTER(_c.c_int)]),
+    "ldpc_decoder_grid_violations": (_c.c_int, [_P, _c.POINTER(_c.c_int64), _P, _c.c_int64, _c.c_int]),
     "ldpc_decoder_fused_info": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),
     "ldpc_plan_layout": (_c.c_int, [_c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_char_p,
                                     _c.POINTER(_c.c_double)]),

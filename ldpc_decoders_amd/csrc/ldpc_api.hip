@@ -181,7 +181,7 @@ static int guarded(const char* who, F&& f) noexcept {
 extern "C" {
 
 const char* ldpc_last_error(void) { return last_error(); }
-int ldpc_abi_version(void) { return 2; }
+int ldpc_abi_version(void) { return 3; }
 
 int ldpc_device_count(int* count) {
     return guarded("ldpc_device_count", [&]() -> int {
@@ -302,7 +302,7 @@ int ldpc_decoder_destroy(ldpc_decoder_t h) {
         if (!d) return LDPC_OK;
         (void)hipSetDevice(d->code->device);
         fused_plan_destroy(d);
-        for (DevBuf* b : {&d->msg, &d->marg, &d->marg2, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->msg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap, &d->fmap2, &d->rbase, &d->h_in, &d->h_y0, &d->h_out,
+        for (DevBuf* b : {&d->msg, &d->marg, &d->marg2, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->gridviol, &d->msg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap, &d->fmap2, &d->rbase, &d->h_in, &d->h_y0, &d->h_out,
                           &d->h_iters})
             b->release();
         if (d->pinned) (void)hipHostFree(d->pinned);
@@ -320,6 +320,23 @@ int ldpc_decoder_last_repacks(ldpc_decoder_t h, int* repacks) {
         Decoder* d = (Decoder*)h;
         if (!d || !repacks) return LDPC_E_ARG;
         *repacks = d->last_backend == BK_STREAM ? d->last_repacks : 0;
+        return LDPC_OK;
+    });
+}
+
+int ldpc_decoder_grid_violations(ldpc_decoder_t h, int64_t* count, int64_t* frames, int64_t cap, int reset) {
+    return guarded("ldpc_decoder_grid_violations", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !count || cap < 0 || (cap > 0 && !frames)) return LDPC_E_ARG;
+        *count = 0;
+        if (!d->gridviol.p) return LDPC_OK;  // no call with LDPC_FLAG_PRIOR_GRID yet
+        LDPC_HIP_TRY(hipSetDevice(d->code->device));
+        LDPC_HIP_TRY(hipDeviceSynchronize());
+        LDPC_HIP_TRY(hipMemcpy(count, d->gridviol.p, 8, hipMemcpyDeviceToHost));
+        const int64_t listed = *count < 4095 ? *count : 4095;  // GRID_REDO_CAP of the kernels
+        const int64_t take = listed < cap ? listed : cap;
+        if (take > 0) LDPC_HIP_TRY(hipMemcpy(frames, (const char*)d->gridviol.p + 8, (size_t)take * 8, hipMemcpyDeviceToHost));
+        if (reset) LDPC_HIP_TRY(hipMemset(d->gridviol.p, 0, 8));
         return LDPC_OK;
     });
 }
@@ -568,13 +585,20 @@ int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uin
             set_error("device channel kernels send the all-zero (0) or all-one (1) word; got codeword=%d", codeword);
             return LDPC_E_ARG;
         }
-        if (d->backend != BK_STREAM && fused_simulate_supported(d, channel, param, hist_bins))
+        const int grid_k = LDPC_FLAG_PRIOR_GRID_OF(flags);
+        // (fp64 decoders with a prior grid take the composed path below: quantised priors from the channel kernel, no guard needed)
+        if (d->backend != BK_STREAM && fused_simulate_supported(d, channel, param, hist_bins) && !(grid_k >= 0 && d->dtype == DT_F64 && d->alg != ALG_BEC))
             return fused_simulate(d, channel, param, codeword, seed, stream_id, frame0, B, max_iter, flags, hist_bins, counters, st);
+        if (grid_k >= 0 && (d->dtype != DT_F64 || channel == CH_BEC)) {
+            set_error("prior grid: the exactness guard lives in the LDS-resident fp32 min-sum kernels; this decoder runs on the streaming kernels");
+            return LDPC_E_UNSUPPORTED;
+        }
+        const int ch_grid = grid_k >= 0 ? LDPC_CH_PRIOR_GRID(grid_k) : 0;  // fp64 decoders: quantised priors, no guard needed
         // bounded staging: priors for at most 2^17 frames at a time (fewer where the streaming state would not fit the HBM)
         const int64_t step = pick_backend(d) == BK_STREAM ? stream_chunk_frames(d) : (int64_t)1 << 17;
         const int64_t cap = B < step ? B : step;
         // BI-AWGN on the streaming kernels: the noise is generated straight into the tile layout (no [B,n] prior array, no transposing load)
-        const bool tiled_noise = channel == CH_BIAWGN && d->alg != ALG_BEC && pick_backend(d) == BK_STREAM;
+        const bool tiled_noise = channel == CH_BIAWGN && d->alg != ALG_BEC && pick_backend(d) == BK_STREAM && grid_k < 0;
         if (channel != CH_BEC && !tiled_noise) LDPC_TRY(d->h_in.reserve((size_t)cap * n * esz));
         if (channel != CH_BIAWGN) LDPC_TRY(d->h_y0.reserve((size_t)cap * n));
         LDPC_TRY(d->h_out.reserve((size_t)cap * n));
@@ -589,7 +613,7 @@ int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uin
             }
             void* pri = channel == CH_BEC ? nullptr : d->h_in.p;
             uint8_t* y = channel == CH_BIAWGN ? nullptr : (uint8_t*)d->h_y0.p;
-            LDPC_TRY(channel_generate(channel, d->dtype, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, (int32_t)n, pri,
+            LDPC_TRY(channel_generate(channel | ch_grid, d->dtype, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, (int32_t)n, pri,
                                       y, st));
             LDPC_TRY(ldpc_decode(h, pri, y, nb, max_iter, flags, (uint8_t*)d->h_out.p, (int32_t*)d->h_iters.p, stream));
             LDPC_TRY(count_errors((uint8_t*)d->h_out.p, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters,

@@ -28,7 +28,8 @@ __device__ __forceinline__ int64_t word_of_frame(const WordBook& wb, uint64_t se
 // one thread = 4 consecutive variables of one frame (one Philox block)
 template <typename T, bool WORDS>
 __global__ __launch_bounds__(256) void k_biawgn(double sigma, double inv_var2, int codeword, uint64_t seed, uint32_t stream,
-                                                uint64_t frame0, int64_t B, int n, int blocks_per_frame, T* __restrict__ priors, WordBook wb) {
+                                                uint64_t frame0, int64_t B, int n, int blocks_per_frame, T* __restrict__ priors, WordBook wb,
+                                                double grid_scale) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t f = gid / blocks_per_frame;
     const int j = (int)(gid - f * blocks_per_frame);
@@ -56,6 +57,8 @@ __global__ __launch_bounds__(256) void k_biawgn(double sigma, double inv_var2, i
     for (int q = 0; q < 4; ++q) {
         const T y = mean4[q] + sg * z[q];
         out[q] = -(k * y);  // -2y/sigma^2 with k = 2/sigma^2
+        // exact-in-fp32 mode (LDPC_CH_PRIOR_GRID): the LLR rounded to a multiple of 2^-k; both scalings are exact (powers of two)
+        if (grid_scale != 0.0) out[q] = __builtin_rint(out[q] * (T)grid_scale) * (T)(1.0 / grid_scale);
     }
     T* dst = priors + f * n + 4 * j;
     if ((n & 3) == 0) {
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void k_biawgn(double sigma, double inv_var2, i
 template <typename T, int CH, bool WORDS>
 __global__ __launch_bounds__(256) void k_discrete(uint64_t thr, double llr, int codeword, uint64_t seed, uint32_t stream,
                                                   uint64_t frame0, int64_t B, int n, int blocks_per_frame,
-                                                  T* __restrict__ priors, uint8_t* __restrict__ y, WordBook wb) {
+                                                  T* __restrict__ priors, uint8_t* __restrict__ y, WordBook wb, double grid_scale) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t f = gid / blocks_per_frame;
     const int j = (int)(gid - f * blocks_per_frame);
@@ -97,7 +100,10 @@ __global__ __launch_bounds__(256) void k_discrete(uint64_t thr, double llr, int 
             uint8_t s;
             if constexpr (CH == CH_BSC) {
                 s = (uint8_t)(bit ^ (hit ? 1 : 0));
-                if (priors) priors[f * n + v] = (T)llr * (T)(1 - 2 * (int)s);
+                if (priors) {
+                    const T l = grid_scale != 0.0 ? (T)(__builtin_rint((T)llr * (T)grid_scale) * (T)(1.0 / grid_scale)) : (T)llr;
+                    priors[f * n + v] = l * (T)(1 - 2 * (int)s);
+                }
             } else {
                 s = hit ? (uint8_t)2 : (uint8_t)bit;
             }
@@ -183,7 +189,13 @@ int channel_generate_words(int channel, int dtype, double param, int codeword, c
     }
     const WordBook wb{codebook, K, sent};
     const bool raw = (channel & CH_RAW_OBSERVATION) != 0;
-    channel &= ~CH_RAW_OBSERVATION;
+    const int grid_k = LDPC_CH_PRIOR_GRID_OF(channel);  // -1: off
+    const double gs = grid_k >= 0 ? ldexp(1.0, grid_k) : 0.0;
+    channel &= ~(CH_RAW_OBSERVATION | (0x1f << 12));
+    if (grid_k > 23 || (grid_k >= 0 && raw)) {
+        set_error("prior grid: k = 0..23, LLR output only");
+        return LDPC_E_ARG;
+    }
     if (raw && channel != CH_BIAWGN) {
         set_error("the raw-observation flag applies to the BI-AWGN channel only");
         return LDPC_E_ARG;
@@ -199,11 +211,11 @@ int channel_generate_words(int channel, int dtype, double param, int codeword, c
         const double var = pow(10.0, -param / 10.0);  // src/biawgn.py:10
         const double sigma = sqrt(var), k = raw ? -1.0 : 2.0 / var;  // the kernel writes -(k*y): k = -1 hands over y itself
         if (dtype == DT_F64) {
-            if (words) hipLaunchKernelGGL((k_biawgn<double, true>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, wb);
-            else hipLaunchKernelGGL((k_biawgn<double, false>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, wb);
+            if (words) hipLaunchKernelGGL((k_biawgn<double, true>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, wb, gs);
+            else hipLaunchKernelGGL((k_biawgn<double, false>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, wb, gs);
         } else {
-            if (words) hipLaunchKernelGGL((k_biawgn<float, true>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, wb);
-            else hipLaunchKernelGGL((k_biawgn<float, false>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, wb);
+            if (words) hipLaunchKernelGGL((k_biawgn<float, true>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, wb, gs);
+            else hipLaunchKernelGGL((k_biawgn<float, false>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, wb, gs);
         }
     } else if (channel == CH_BSC || channel == CH_BEC) {
         if (!y) {
@@ -221,15 +233,15 @@ int channel_generate_words(int channel, int dtype, double param, int codeword, c
         const double llr = log(1.0 - param) - log(param);  // src/bsc.py:21
         if (channel == CH_BSC) {
             if (dtype == DT_F64) {
-                if (words) hipLaunchKernelGGL((k_discrete<double, CH_BSC, true>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, y, wb);
-                else hipLaunchKernelGGL((k_discrete<double, CH_BSC, false>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, y, wb);
+                if (words) hipLaunchKernelGGL((k_discrete<double, CH_BSC, true>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, y, wb, gs);
+                else hipLaunchKernelGGL((k_discrete<double, CH_BSC, false>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, y, wb, gs);
             } else {
-                if (words) hipLaunchKernelGGL((k_discrete<float, CH_BSC, true>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, y, wb);
-                else hipLaunchKernelGGL((k_discrete<float, CH_BSC, false>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, y, wb);
+                if (words) hipLaunchKernelGGL((k_discrete<float, CH_BSC, true>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, y, wb, gs);
+                else hipLaunchKernelGGL((k_discrete<float, CH_BSC, false>), grid, block, 0, st, thr, llr, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, y, wb, gs);
             }
         } else {
-            if (words) hipLaunchKernelGGL((k_discrete<float, CH_BEC, true>), grid, block, 0, st, thr, 0.0, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)nullptr, y, wb);
-            else hipLaunchKernelGGL((k_discrete<float, CH_BEC, false>), grid, block, 0, st, thr, 0.0, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)nullptr, y, wb);
+            if (words) hipLaunchKernelGGL((k_discrete<float, CH_BEC, true>), grid, block, 0, st, thr, 0.0, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)nullptr, y, wb, 0.0);
+            else hipLaunchKernelGGL((k_discrete<float, CH_BEC, false>), grid, block, 0, st, thr, 0.0, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)nullptr, y, wb, 0.0);
         }
     } else {
         set_error("unknown channel id %d", channel);

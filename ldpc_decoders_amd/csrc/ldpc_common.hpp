@@ -108,6 +108,8 @@ struct Decoder {
     int last_sweeps = 0;
     int last_backend = BK_STREAM;
     int last_repacks = 0;  // frame repacks of the last streaming decode
+    // exact-in-fp32 mode: device counter of guard events (LDPC_FLAG_PRIOR_GRID, ldpc_decoder_grid_violations)
+    DevBuf gridviol;
     int64_t stream_chunk = 0;  // frames per pass through the streaming kernels (0: not decided yet; ldpc_api.hip stream_chunk_frames)
 };
 

@@ -576,6 +576,8 @@ int fused_plan_create(Decoder* d) {
     p->groups_per_cu = by_lds < cap ? by_lds : cap;
     LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
     if (shape.kernel_sim) LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel_sim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    for (const void* kg : {shape.kernel_grid, shape.kernel_sim_grid})
+        if (kg) LDPC_HIP_TRY(hipFuncSetAttribute(kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
     p->ok = p->groups_per_cu >= 1;
     return LDPC_OK;
 }
@@ -626,6 +628,32 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
         long long fe = ((long long)1 << 31) / (per_frame > 0 ? per_frame : 1);
         a.flush_every = (int)(fe < 1 ? 1 : (fe > 4096 ? 4096 : fe));
     }
+    // exact-in-fp32 mode: the guarded variant of the kernel, its grid constants and the violation counter
+    const int grid_k = LDPC_FLAG_PRIOR_GRID_OF(flags);
+    const void* kern = sim ? shape.kernel_sim : shape.kernel;
+    if (grid_k >= 0) {
+        if (shape.esz == 8) {
+            // fp64 arithmetic needs no guard; the Monte-Carlo kernels of the fp64 / erasure decoders draw their noise unquantised
+            if (sim) {
+                set_error("prior grid: ldpc_simulate quantises in the fp32 min-sum kernels; fp64 decoders take grid priors through ldpc_channel + ldpc_decode");
+                return LDPC_E_UNSUPPORTED;
+            }
+        } else {
+            kern = sim ? shape.kernel_sim_grid : shape.kernel_grid;
+            if (!kern || grid_k > 23) {
+                set_error("prior grid: no guarded kernel for this (code, algorithm) -- fp32 min-sum shapes of n = 1200 and n = 10 000 have one");
+                return LDPC_E_UNSUPPORTED;
+            }
+            if (!d->gridviol.p) {
+                LDPC_TRY(d->gridviol.reserve((size_t)(1 + GRID_REDO_CAP) * 8));
+                LDPC_HIP_TRY(hipMemsetAsync(d->gridviol.p, 0, (size_t)(1 + GRID_REDO_CAP) * 8, st));
+            }
+            a.grid_scale = (float)ldexp(1.0, grid_k);
+            a.grid_inv = (float)ldexp(1.0, -grid_k);
+            a.grid_limit = (float)ldexp(1.0, 24 - grid_k - 3);  // partial sums of up to 8 messages stay below 2^(24-k)
+            a.grid_viol = (unsigned long long*)d->gridviol.p;
+        }
+    }
     void* args[] = {&a};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (d->profile) {
@@ -633,7 +661,7 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
         LDPC_TRY(prof_event(d, 1, &e1));
         LDPC_HIP_TRY(hipEventRecord(e0, st));
     }
-    LDPC_HIP_TRY(hipLaunchKernel(sim ? shape.kernel_sim : shape.kernel, dim3((unsigned)groups), dim3(64 * shape.NW), args, p->lds_bytes, st));
+    LDPC_HIP_TRY(hipLaunchKernel(kern, dim3((unsigned)groups), dim3(64 * shape.NW), args, p->lds_bytes, st));
     if (d->after_kernel_event) LDPC_HIP_TRY(hipEventRecord(d->after_kernel_event, st));  // low-latency host path: wait for the kernel only
     // the other counter set for the next launch, zeroed behind this kernel (off the critical path of both launches)
     dsp.sel ^= 1;

@@ -41,6 +41,10 @@ struct ShapeEntry {
     const void* kernel;      // decode: priors in, decisions out
     const void* kernel_sim;  // simulate: noise in the kernel, counters out (null: decode only)
     int esz = 4;             // bytes per LDS element: 4 (fp32 kernels), 8 (fp64 kernels)
+    // exact-in-fp32 mode (fp32 min-sum on priors quantised to a 2^-k grid, LDPC_FLAG_PRIOR_GRID): the same kernels with the exactness
+    // guard compiled in; null where no such variant is built
+    const void* kernel_grid = nullptr;
+    const void* kernel_sim_grid = nullptr;
 };
 // Rows of 64 check slots a frame holds in the LDS.  Normally CRW per wave.  The fp64 shapes of four and more waves for regular codes
 // keep only the rows a code can fill -- E = m DC <= n DV, hence m <= VR 64 DV / DC -- and the last wave(s) run fewer rows: the (3,6)
@@ -181,7 +185,12 @@ struct FusedArgs {
     uint32_t certain_entry;         // gather-table entry of the "certain" variable slot that pads short check rows (0xffffffff: none)
     unsigned long long* counters;   // [4 + hist_bins] tot, wec, bec, iter_sum, histogram of sweeps
     int flush_every;                // SIM: frames a workgroup counts in 32-bit lanes before adding them to `counters`
+    // exact-in-fp32 mode: priors are rounded to multiples of 1 / grid_scale (SIM: in the kernel; decode: by the channel kernel); a frame
+    // in which some |v2c|, |marginal| reaches grid_limit -- beyond it an fp32 sum of grid multiples may round -- is counted in grid_viol
+    float grid_scale, grid_inv, grid_limit;
+    unsigned long long* grid_viol;  // [0] frames beyond the guard since the last reset, [1 .. GRID_REDO_CAP] their global indices (redo list)
 };
+constexpr int GRID_REDO_CAP = 4095;
 
 // Monte-Carlo counters of a workgroup (SIM kernels) in ONE register: lanes [0, hist_bins) hold the histogram of executed sweeps,
 // lanes 60..63 tot / wec / bec / iter_sum (src/main.py:41-45) as 32-bit partial sums, added to the global 64-bit counters every
@@ -230,8 +239,10 @@ __device__ __forceinline__ void sim_flush(unsigned& accv, int lane, int hist_bin
     accv = 0;
 }
 
-template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 || DVX > 8 || (NW == 2 && DC >= 7)) ? 3 : 4)) void k_fused_bp(const FusedArgs A) {
+// (the body of k_fused_bp / k_fused_bp_grid: the kernels themselves follow it)
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX, bool GRID>
+__device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
+    static_assert(!GRID || ALG == ALG_MSA, "the exactness guard belongs to min-sum: only add / subtract / compare");
     // BIG: a frame takes the whole LDS of a CU (160 KB) and a 16-wave workgroup.  Table entries are dword indices, c2v stores
     // use an address register, and the LAST marginal row is a system row that no sweep writes: dwords [0,16) hand-off
     // channel A (one word per wave), [16,32) channel B, [32] frame hand-out, [33] always zero (target of missing edges).
@@ -430,12 +441,15 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                     box_muller<float>(ph.w[0], ph.w[1], z[0], z[1]);
                     box_muller<float>(ph.w[2], ph.w[3], z[2], z[3]);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) pri4[t] = -(A.sim_k * (A.sim_mean + A.sim_sigma * z[t]));
+                    for (int t = 0; t < 4; ++t) {
+                        pri4[t] = -(A.sim_k * (A.sim_mean + A.sim_sigma * z[t]));
+                        if constexpr (GRID) pri4[t] = __builtin_rintf(pri4[t] * A.grid_scale) * A.grid_inv;  // both scalings are exact (powers of two)
+                    }
                 } else {  // CH_BSC: same integer threshold and the same LLR expression as k_discrete
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int y = A.codeword ^ ((u64)ph.w[t] < A.bsc_thr ? 1 : 0);
-                        pri4[t] = A.bsc_llr * (float)(1 - 2 * y);
+                        pri4[t] = (GRID ? __builtin_rintf(A.bsc_llr * A.grid_scale) * A.grid_inv : A.bsc_llr) * (float)(1 - 2 * y);
                     }
                 }
 #pragma unroll
@@ -470,6 +484,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
 
         int it = 0;
         bool left_at_0 = false;
+        float gmax = 0.0f;  // GRID: largest |v2c| / |marginal| of this lane in this frame
 
         if (!SIM && A.y0 != nullptr) {
             // iteration-0 test of the received hard word (src/bpa.py:20,29): park it in the marg area as -+1
@@ -530,6 +545,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                     for (int j = 0; j < DC; ++j) v[j] = mg[r & 1][j] - c2v_old[r][j];
 #pragma unroll
                     for (int j = 0; j < DC; ++j) a[j] = __builtin_fabsf(v[j]);
+
                     // XOR of the raw words, three inputs per instruction (v_bitop3_b32, truth table 0x96)
 #pragma unroll
                     for (int j = 0; j + 2 < DC; j += 3) {
@@ -593,6 +609,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                         constexpr int j = decltype(J_)::value;
                         float mag;
                         if constexpr (ALG == ALG_MSA) mag = fminf(pre[j], suf[j]); else mag = spa_llr_of_eo(pre[j], preo[j], suf[j], sufo[j]);
+                        // GRID: the guard watches the outgoing magnitudes and the marginals.  Both below L = 2^(21-k) keeps every sum of the
+                        // sweep exact: v2c = marg - c2v_old stays below 2L, a partial sum of up to 8 messages below 8L = 2^(24-k).  (The
+                        // incoming |v2c| themselves are not watched: a short row's padding position is +inf by construction.)
+                        if constexpr (GRID) gmax = fmaxf(gmax, mag);
                         float c;  // mag | ((vx ^ v[j]) & sign bit)
                         if constexpr (ALG == ALG_MSA) asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(c) : "v"(vx ^ __float_as_uint(v[j])), "s"(sign_mask), "v"(mag));
                         else c = __uint_as_float(__float_as_uint(mag) | ((vx ^ __float_as_uint(v[j])) & 0x80000000u));
@@ -619,6 +639,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 auto finish_var = [&](auto Q_, float s) {
                     constexpr int q = decltype(Q_)::value;
                     const float m1 = prior[q] + s;
+                    if constexpr (GRID) {
+                        // (not watched: SIM's padded slots -- stale words -- and the "certain" slot that pads short check rows: +inf by design)
+                        const bool watched = (!SIM || ((valid >> q) & 1u)) && !(VRX > 0 && ((dummy >> q) & 1u));
+                        gmax = fmaxf(gmax, watched ? __builtin_fabsf(m1) : 0.0f);
+                    }
                     if (q < VRW - 1 || own_last) lds_st_tid<q * 256>(m1);
                     // decision: (m1 < 0); for min-sum the sign bit itself (m1 is never -0.0 and never NaN for finite priors)
                     if constexpr (ALG == ALG_MSA) xr = __builtin_amdgcn_alignbit(xr, __float_as_uint(m1), 31);  // (xr << 1) | sign: rows come in ascending q
@@ -673,22 +698,41 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
                 ++it;
             }
         }
+        // GRID: beyond grid_limit an fp32 sum of grid multiples may round -- the frame is no longer KNOWN to equal the fp64 computation.
+        // Such a frame (min-sum messages of a frame caught in a trapping set grow geometrically: about one frame in 10^4 at 2 dB) is
+        // not counted / is marked, and its index goes onto the decoder's redo list: the host decodes it again in fp64.
+        int wave_viol = 0;
+        if constexpr (GRID) wave_viol = __ballot(gmax >= A.grid_limit) != 0ull ? 1 : 0;
+        auto grid_redo = [&]() {
+            if (w == 0 && lane == 0) {
+                const u64 idx = atomicAdd(A.grid_viol, 1ull);
+                if (idx < (u64)GRID_REDO_CAP) A.grid_viol[1 + idx] = A.frame0 + fr;
+            }
+        };
         if constexpr (SIM) {
             // errors against the all-`codeword` word (src/main.py:41-45), counted from the decision bits
             const unsigned wrong = (A.codeword ? ~xb : xb) & valid;
             int err = 0;
 #pragma unroll
             for (int q = 0; q < VRW; ++q) err += __popcll(__ballot((wrong >> q) & 1u));
-            err = exchange_add(err);
+            err = exchange_add(err + (wave_viol << 20));  // (err <= n < 2^20: the waves' guard verdicts ride on the same hand-off)
             err = __builtin_amdgcn_readfirstlane(err);  // wave-uniform: keep the accumulators in scalar registers
-            sim_count(accv, lane, err, it, A.hist_bins);
+            if (GRID && (err >> 20) != 0) grid_redo();
+            else sim_count(accv, lane, err, it, A.hist_bins);
             if (++acc_frames >= A.flush_every) {
                 if (w == 0) sim_flush(accv, lane, A.hist_bins, A.counters);
                 accv = 0;
                 acc_frames = 0;
             }
         } else {
-            if (w == 0 && lane == 0) A.iters[fr] = it;
+            int it_out = it;
+            if constexpr (GRID) {
+                if (__builtin_amdgcn_readfirstlane(exchange_add(wave_viol)) != 0) {
+                    grid_redo();
+                    it_out = -1 - it;  // marked: decisions of this frame are not known to be the fp64 reference's
+                }
+            }
+            if (w == 0 && lane == 0) A.iters[fr] = it_out;
             uint8_t* xf = A.xhat + fr * n;
 #pragma unroll
             for (int q = 0; q < VRW; ++q) {
@@ -710,6 +754,17 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 |
     if constexpr (SIM) {
         if (w == 0) sim_flush(accv, lane, A.hist_bins, A.counters);
     }
+}
+
+#define LDPC_FUSED_BP_BOUNDS __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 || DVX > 8 || (NW == 2 && DC >= 7)) ? 3 : 4))
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
+__global__ LDPC_FUSED_BP_BOUNDS void k_fused_bp(const FusedArgs A) {
+    fused_bp_body<ALG, DC, DV, CRW, VRW, NW, SIM, VRX, DVX, false>(A);
+}
+// exact-in-fp32 variant (LDPC_FLAG_PRIOR_GRID): fp32 min-sum with priors on a 2^-k grid and the exactness guard compiled in
+template <int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
+__global__ LDPC_FUSED_BP_BOUNDS void k_fused_bp_grid(const FusedArgs A) {
+    fused_bp_body<ALG_MSA, DC, DV, CRW, VRW, NW, SIM, VRX, DVX, true>(A);
 }
 
 
@@ -1165,6 +1220,14 @@ template <int ALG, int DC, int DV, int CRW, int VRW, int NW, int VRX = 0, int DV
 constexpr ShapeEntry shape_entry() {
     return ShapeEntry{ALG, DC, DV, CRW, VRW, NW, VRX, DVX, (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW, false, VRX, DVX>,
                       (const void*)k_fused_bp<ALG, DC, DV, CRW, VRW, NW, true, VRX, DVX>};
+}
+// the same shape with the exact-in-fp32 variants (min-sum only)
+template <int DC, int DV, int CRW, int VRW, int NW, int VRX = 0, int DVX = DV>
+constexpr ShapeEntry shape_entry_grid() {
+    ShapeEntry e = shape_entry<ALG_MSA, DC, DV, CRW, VRW, NW, VRX, DVX>();
+    e.kernel_grid = (const void*)k_fused_bp_grid<DC, DV, CRW, VRW, NW, false, VRX, DVX>;
+    e.kernel_sim_grid = (const void*)k_fused_bp_grid<DC, DV, CRW, VRW, NW, true, VRX, DVX>;
+    return e;
 }
 
 }  // namespace

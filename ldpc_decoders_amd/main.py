@@ -102,12 +102,17 @@ def test(args, comm=None):
             if own_hist:
                 handle.on_iters = None
                 state["hist_into"] = (inner.iter, bins)  # intermediate result files then carry a real histogram, not zeros
-            sim = DeviceSimulator(handle, args.channel, args.max_iter, args.codeword, args.seed, comm, hist_bins=bins)
+            grid = getattr(args, "prior_grid", None)
+            if grid is not None and (args.decoder != "MSA" or args.channel != "biawgn" or kwargs["precision"] != "f32"):
+                raise SystemExit("--prior-grid: fp32 min-sum over BI-AWGN (biawgn <code> MSA, without --precision f64)")
+            sim = DeviceSimulator(handle, args.channel, args.max_iter, args.codeword, args.seed, comm, hist_bins=bins, prior_grid=grid)
             c = sim.run_point(param, stream_id=pi, min_wec=args.min_wec, batch_per_rank=args.batch, on_progress=progress,
                               max_frames=(args.max_frames or None))
             if own_hist:
                 inner.iter[:] = 0
                 inner.iter[:bins] = c["hist"]
+            if grid is not None and comm.is_root:
+                log.info("prior grid 2^-%d: %d of %d frames were beyond the fp32 exactness guard and decoded again in fp64" % (grid, sim.redone, c["tot"]))
         results[param] = log_status(c, final=True)
     log.info("Done!")
     return results

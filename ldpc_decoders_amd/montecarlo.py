@@ -63,7 +63,7 @@ class DeviceSimulator:
 
     DEPTH = 2  # rounds in flight in run_point / bench.py
 
-    def __init__(self, handle, channel, max_iter, codeword=0, seed=0x5EED1200, comm=None, hist_bins=0, device="cuda"):
+    def __init__(self, handle, channel, max_iter, codeword=0, seed=0x5EED1200, comm=None, hist_bins=0, device="cuda", prior_grid=None):
         """``device``: where the counters live -- "cuda" always in the product (the handle is a HIP decoder); "cpu" lets the N > 1 driver
         layer (sharding, pipelining, collective, stopping rule) be exercised on gloo ranks with a stand-in handle (tests/test_dist_cpu.py)."""
         import torch
@@ -72,6 +72,11 @@ class DeviceSimulator:
         self.h, self.channel, self.max_iter, self.codeword = handle, channel, int(max_iter), int(codeword)
         self.seed, self.comm, self.hist_bins = int(seed), comm or Comm(), int(hist_bins)
         self.device = device
+        # exact-in-fp32 mode (include/ldpc_hip.h LDPC_FLAG_PRIOR_GRID): priors on a 2^-k grid, fp32 kernels under the exactness guard, the
+        # frames beyond it redone in fp64 by the handle; `redone` counts them
+        self.prior_grid, self.redone = prior_grid, 0
+        if prior_grid is not None and (channel != "biawgn" or int(codeword) not in (0, 1)):
+            raise ValueError("--prior-grid: min-sum over BI-AWGN with the all-zero / all-one word")
         k = 4 + self.hist_bins
         on_gpu = device == "cuda"
         self._slots = [dict(dev=torch.zeros(k, dtype=torch.int64, device=device),
@@ -87,7 +92,10 @@ class DeviceSimulator:
         self._next = (self._next + 1) % len(self._slots)
         start, cnt = self.comm.shard(frame0, frames_total)
         slot["dev"].zero_()
-        if cnt > 0:
+        if cnt > 0 and self.prior_grid is not None:
+            self.redone += self.h.simulate_exact_fp32(param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
+                                                      self.prior_grid, hist_bins=self.hist_bins)  # (reads its redo list: synchronous)
+        elif cnt > 0:
             self.h.simulate(self.channel, param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
                             flags=flags, hist_bins=self.hist_bins)
         self.comm.all_reduce_sum(slot["dev"], async_on_stream=True)
@@ -113,7 +121,7 @@ class DeviceSimulator:
         streaming kernels, the ADMM composition and ``--codeword -1`` poll / synchronise inside ``simulate``, so a second round in
         flight buys them nothing and would only be decoded for the bin when the stopping rule fires."""
         h = self.h
-        if self.codeword == -1 or not hasattr(h, "last_stats"):
+        if self.codeword == -1 or not hasattr(h, "last_stats") or self.prior_grid is not None:
             return 1
         return self.DEPTH if h.last_stats()[0] == "fused" else 1
 

@@ -61,6 +61,10 @@ def setup_parser(code_names, channel_names, decoder_names):
     g.add_argument("--exact", action="store_true",
                    help="reference-exact mode: host numpy noise (np.random global stream), fp64 messages, sequential stopping rule")
     g.add_argument("--np-seed", type=int, default=None, help="np.random.seed() for --exact runs (upstream runs unseeded)")
+    g.add_argument("--prior-grid", type=int, default=None, metavar="K",
+                   help="exact-in-fp32 min-sum over BI-AWGN: LLRs rounded to multiples of 2^-K, decoded by the fp32 LDS kernels under an exactness "
+                        "guard; the few frames beyond it are decoded again in fp64 -- every counted frame is what the fp64 reference returns "
+                        "for those priors")
     return bind_parser_common(p)
 
 
