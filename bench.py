@@ -255,6 +255,9 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
     sim = DeviceSimulator(handle, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=min(args.max_iter + 1, 60), device=device)
     s = 8 if args.precision == "f64" else 4
     bytes_per_frame_iter = s * (4 * code.E + code.n)
+    f16 = args.precision == "f16"
+    if f16:  # fp16 storage, two-array sweep: 2-byte messages, 4-byte priors -- 2 (4E) + 4n (8(d) prices an all-fp16 path at 2 (4E + n))
+        bytes_per_frame_iter = 8 * code.E + 4 * code.n
     side_legs = not args.no_profile and comm.world == 1 and device == "cuda"
     kernel_pass = not args.no_profile and device == "cuda"
 
@@ -315,6 +318,15 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
         except Exception as e:  # a side leg must not cost the benchmark line
             exact_res = {"error": repr(e)}
         del h3
+
+    # fp16 STORAGE mode of the streaming kernels (2-byte messages, fp32 arithmetic): the same workload, where the headline runs on the
+    # streaming kernels in fp32 (codes that do not fit the LDS: config 5).  A tolerance mode -- its own block, never `value`.
+    f16_res = None
+    if backend_used == "stream" and args.precision == "f32" and side_legs:
+        h5 = make_handle(code, "MSA", "f16", "stream")
+        sim5 = DeviceSimulator(h5, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=min(args.max_iter + 1, 60))
+        f16_res = run_point(sim5, h5, comm, args.snr, args.steps, 1, args.batch, 0, torch, True, 1)
+        del sim5, h5
 
     def kernel_ms(r):
         return None if not r.get("profile") else sum(r["profile"][k][0] for k in KERNEL_CLASSES)
@@ -382,6 +394,8 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
             else:
                 # streaming kernels: each pass priced with its own compulsory bytes; the sweep with the section-8(d) model
                 share = {"stream_check_pass": (2 * code.E + code.n) * s, "stream_variable_pass": (code.E + 2 * code.n) * s}
+                if f16:
+                    share = {"stream_check_pass": 4 * code.E, "stream_variable_pass": 4 * code.E + 4 * code.n}
                 legs = {}
                 for kname in ("stream_check_pass", "stream_variable_pass"):
                     kms, kl = prof[kname]
@@ -410,7 +424,7 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
         "ms_per_step": head["ms_per_step"], "ms_per_step_min": head["ms_per_step_min"], "ms_per_step_max": head["ms_per_step_max"],
         "timed_blocks": head["timed_blocks"], "blocks_ms_per_step": [round(1e3 * b / args.steps, 4) for b in res["blocks"]],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.precision, "data": "synthetic",
+        "dtype": "f32 arithmetic, f16 message storage" if f16 else args.precision, "data": "synthetic",
         "config": {"workload": "%s MSA over BI-AWGN, max_iter=%d, batch=%d frames/GPU, %.1f dB (mean %.2f sweeps/frame), "
                                "all-zero word + Philox noise on device" % (args.code, args.max_iter, args.batch, args.snr, head["mean_sweeps"]),
                    "code": args.code, "n": code.n, "m": code.m, "E": code.E, "decoder": "MSA", "channel": "biawgn", "snr_db": args.snr,
@@ -446,6 +460,22 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
                         "read after each).  Not `value`: the priors differ from the unquantised workload's."}
         elif exact_res is not None:
             out["exact_fp32_mode"] = exact_res
+    if f16_res is not None:
+        fc, fp = f16_res["counters"], f16_res["profile"]
+        b16 = 8 * code.E + 4 * code.n
+        pair_ms = fp["stream_check_pass"][0] + fp["stream_variable_pass"][0]
+        out["fp16_storage_mode"] = {
+            "frames_per_s": round(int(fc[0]) / f16_res["seconds"], 1), "ms_per_step": round(1e3 * f16_res["seconds"] / args.steps, 4),
+            "speedup_over_fp32": round(int(fc[0]) / f16_res["seconds"] / head["frames_per_s"], 3),
+            "mean_sweeps": round(int(fc[3]) / max(int(fc[0]), 1), 3), "wer": round(int(fc[1]) / max(int(fc[0]), 1), 6),
+            "bytes_per_frame_sweep": b16, "sweep_achieved_GBps": round(int(fc[3]) * b16 / (pair_ms * 1e-3) / 1e9, 1),
+            "sweep_frac_of_hbm_peak": round(int(fc[3]) * b16 / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "check_pass_ms": round(fp["stream_check_pass"][0] / max(fp["stream_check_pass"][1], 1), 4),
+            "variable_pass_ms": round(fp["stream_variable_pass"][0] / max(fp["stream_variable_pass"][1], 1), 4),
+            "note": "LDPC_DTYPE_F16: check <-> variable messages stored as fp16 (two-array sweep: every E-sized line moved once per pass, "
+                    "8E + 4n bytes per frame-sweep), arithmetic, priors and marginals fp32.  Tolerance mode: marginals within 1e-2 (1 + |fp32|) "
+                    "over three sweeps, published WER points within 4 sigma, identical-noise WER equal to fp32's within counting noise "
+                    "(tests/test_gpu_f16_storage.py).  Never `value`."}
     if stream_res is not None:
         sp, sc = stream_res["profile"], stream_res["counters"]
         it_sum = int(sc[3])
@@ -478,8 +508,9 @@ def parse_args(argv=None):
     ap.add_argument("--snr", type=float, default=1.0)
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--code", default="1200_3_6_rand_ldpc_1")
-    ap.add_argument("--precision", default="f64", choices=["f32", "f64"],
-                    help="message arithmetic; f64 is the reference's own (hard decisions bit-identical to it), f32 the throughput mode")
+    ap.add_argument("--precision", default="f64", choices=["f32", "f64", "f16"],
+                    help="message arithmetic; f64 is the reference's own (hard decisions bit-identical to it), f32 the throughput mode, f16 = fp16 "
+                         "STORAGE of the streaming messages with fp32 arithmetic (codes whose state lives in HBM; a tolerance mode)")
     ap.add_argument("--backend", default="auto", choices=["auto", "stream", "fused"])
     ap.add_argument("--points", type=float, nargs="*", default=[2.0, 3.0], help="extra SNR points reported under 'points'")
     ap.add_argument("--no-cpu-baseline", action="store_true")

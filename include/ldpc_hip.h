@@ -30,7 +30,10 @@ typedef struct ldpc_code_s* ldpc_code_t;
 typedef struct ldpc_decoder_s* ldpc_decoder_t;
 
 enum { LDPC_ALG_MSA = 0, LDPC_ALG_SPA = 1, LDPC_ALG_BEC = 2 };      /* decoder selector: src/utils.py:16, main.py:12 */
-enum { LDPC_DTYPE_F32 = 0, LDPC_DTYPE_F64 = 1 };                     /* message arithmetic                             */
+enum { LDPC_DTYPE_F32 = 0, LDPC_DTYPE_F64 = 1,                       /* message arithmetic                             */
+       LDPC_DTYPE_F16 = 2 };  /* fp16 STORAGE of the check messages on the streaming kernels, fp32 arithmetic, fp32 priors / channel output:
+                               * a throughput mode for codes whose state lives in HBM (the E-sized traffic halves); held to a
+                               * stated tolerance, never the parity mode.  ldpc_decoder_create only. */
 enum { LDPC_BACKEND_AUTO = 0, LDPC_BACKEND_STREAM = 1, LDPC_BACKEND_FUSED = 2 };
 enum { LDPC_CH_BIAWGN = 0, LDPC_CH_BSC = 1, LDPC_CH_BEC = 2 };       /* channel selector: src/models.py:3               */
 enum { LDPC_CH_RAW_OBSERVATION = 0x100 };  /* or-ed into LDPC_CH_BIAWGN for ldpc_channel: write y itself, not -2y/sigma^2 */

@@ -143,7 +143,7 @@ class DecoderHandle:
         pri = None if channel == "bec" else torch.empty((B, n), dtype=dt, device="cuda")
         y = None if channel == "biawgn" else torch.empty((B, n), dtype=torch.uint8, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.load().ldpc_channel(_lib.CHANNEL[channel] | _lib.ch_prior_grid(prior_grid), _lib.DTYPE[self.precision], float(param), int(codeword), int(seed),
+        _lib.check(_lib.load().ldpc_channel(_lib.CHANNEL[channel] | _lib.ch_prior_grid(prior_grid), _lib.IO_DTYPE[self.precision], float(param), int(codeword), int(seed),
                                             int(stream_id), int(frame0), int(B), n, None if pri is None else pri.data_ptr(),
                                             None if y is None else y.data_ptr(), st))
         return pri, y

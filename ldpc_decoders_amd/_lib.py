@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LDPC_LIB_PATH") or os.path.join(_HERE, "csrc", "libldpc_hip.so")  # override: A/B builds of the same ABI
 
 ALG = {"MSA": 0, "SPA": 1, "BEC": 2}
-DTYPE = {"f32": 0, "f64": 1}
+DTYPE = {"f32": 0, "f64": 1, "f16": 2}  # f16: fp16 storage of the streaming messages, fp32 arithmetic / priors (decoders only)
+IO_DTYPE = {"f32": 0, "f64": 1, "f16": 0}  # what the channel kernels write / the decoders read for each decoder precision
 BACKEND = {"auto": 0, "stream": 1, "fused": 2}
 BACKEND_NAME = {v: k for k, v in BACKEND.items()}
 CHANNEL = {"biawgn": 0, "bsc": 1, "bec": 2}

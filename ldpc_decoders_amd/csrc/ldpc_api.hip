@@ -258,7 +258,8 @@ int ldpc_plan_layout(int32_t m, int32_t n, int64_t E, const int32_t* chk, const 
 
 int ldpc_decoder_create(ldpc_code_t code, int alg, int dtype, int backend, ldpc_decoder_t* out) {
     return guarded("ldpc_decoder_create", [&]() -> int {
-        if (!code || !out || alg < 0 || alg > 2 || dtype < 0 || dtype > 1 || backend < 0 || backend > 2) {
+        if (!code || !out || alg < 0 || alg > 2 || dtype < 0 || dtype > 2 || (dtype == DT_F16 && (alg == ALG_BEC || backend == BK_FUSED)) ||
+            backend < 0 || backend > 2) {
             set_error("ldpc_decoder_create: bad arguments (alg=%d dtype=%d backend=%d)", alg, dtype, backend);
             return LDPC_E_ARG;
         }
@@ -613,7 +614,7 @@ int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uin
             }
             void* pri = channel == CH_BEC ? nullptr : d->h_in.p;
             uint8_t* y = channel == CH_BIAWGN ? nullptr : (uint8_t*)d->h_y0.p;
-            LDPC_TRY(channel_generate(channel | ch_grid, d->dtype, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, (int32_t)n, pri,
+            LDPC_TRY(channel_generate(channel | ch_grid, d->dtype == DT_F16 ? DT_F32 : d->dtype, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, (int32_t)n, pri,
                                       y, st));
             LDPC_TRY(ldpc_decode(h, pri, y, nb, max_iter, flags, (uint8_t*)d->h_out.p, (int32_t*)d->h_iters.p, stream));
             LDPC_TRY(count_errors((uint8_t*)d->h_out.p, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters,

@@ -23,7 +23,7 @@
 namespace ldpc {
 
 enum Alg : int { ALG_MSA = 0, ALG_SPA = 1, ALG_BEC = 2 };
-enum DType : int { DT_F32 = 0, DT_F64 = 1 };
+enum DType : int { DT_F32 = 0, DT_F64 = 1, DT_F16 = 2 };  // DT_F16: fp16 STORAGE of the streaming messages, fp32 arithmetic and priors
 enum Backend : int { BK_AUTO = 0, BK_STREAM = 1, BK_FUSED = 2 };
 enum Channel : int { CH_BIAWGN = 0, CH_BSC = 1, CH_BEC = 2 };
 constexpr int CH_RAW_OBSERVATION = 0x100;  // or-ed into the channel id: BI-AWGN writes y itself instead of the LLR -2y/sigma^2

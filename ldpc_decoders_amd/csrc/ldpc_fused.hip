@@ -375,6 +375,7 @@ int fused_plan_create(Decoder* d) {
     d->fused = new FusedPlan();
     FusedPlan* p = d->fused;
     const bool short_rows = c->min_dc != c->max_dc;
+    if (d->dtype == DT_F16) return LDPC_OK;  // fp16 storage is a mode of the streaming kernels: no LDS-resident plan
     const ShapeChoice ch = choose_shape(c, d->alg, d->dtype);
     const int si = ch.si;
     if (si < 0) return LDPC_OK;

@@ -25,6 +25,8 @@
 //   iteration-0 check of the received word (BSC) ............................ src/bpa.py:20,29
 //   variable update: prior + (((0 + c_a) + c_b) + ...) in ascending edge order  src/bpa.py:35, src/math_utils.py:7
 // (The erasure decoder of src/bec.py:83-122 has its own bit-sliced streaming kernels: ldpc_bec_stream.hip.)
+#include <hip/hip_fp16.h>
+
 #include <cstdlib>
 
 #include "ldpc_cn.hpp"
@@ -782,6 +784,368 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
 
 }  // namespace
 
+// =====================================================================================================================================
+// fp16 STORAGE mode (LDPC_DTYPE_F16): the check -> variable messages -- the E-sized part of the sweep's traffic -- are kept as fp16, all
+// arithmetic and the marginals stay fp32.  A lane must still move at least 4 bytes per access to use the memory system (2-byte lanes
+// would halve the bytes AND the rate), so this mode works on PAIR-TILES of 128 frames: lane l holds frames l and 64 + l of the pair
+// (= the 64-frame tiles 2P and 2P + 1 of the planes / live words, which keep their layout), a message line is 64 x half2 = 256 B, a
+// prior line 64 x float2 = 512 B.  The sweep is the two-array form SURVEY 8(d) prices (v2c written by the variable pass and read back by the
+// check pass): with 2-byte messages every E-sized line is moved exactly once per pass and nothing is re-read -- the marginal-resident form
+// of the fp32 passes would gather 4-byte marginal lines dv times each, which at half-size messages becomes half of the traffic.  Bytes
+// per frame-sweep: check pass 2E + 2E, variable pass 2E + 2E + 4n: 8E + 4n = 1.81 MB at n = 64 800 against 12E + 12n = 3.11 MB in fp32
+// (SURVEY 8(d)'s all-fp16 figure 2(4E + n) differs only by the fp32 priors).
+// A throughput mode, NOT the parity mode: messages are rounded to 11 significant bits each sweep (and saturate at +-65504 where the fp32
+// mode would carry larger finite values); tests hold it to a stated per-sweep tolerance against the fp32 kernels and to the published
+// curves.  No frame repack; the soft output is that of the last sweep of the BATCH (frames that have left keep evolving).
+namespace {
+
+__device__ __forceinline__ float2 msg16_ld(const __half2* p) {
+    const uint32_t raw = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p));
+    return __half22float2(*reinterpret_cast<const __half2*>(&raw));
+}
+template <int ALG>
+__device__ __forceinline__ float sat16(float v) {
+    // finite values beyond the fp16 range saturate (min-sum messages of a trapped frame grow without bound); sum-product keeps its +-inf
+    // and NaN (src/bpa.py:38 relies on them)
+    if constexpr (ALG == ALG_SPA) return (__builtin_fabsf(v) <= 65504.0f || !(__builtin_fabsf(v) < __builtin_huge_valf())) ? v : __builtin_copysignf(65504.0f, v);
+    else return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+}
+template <int ALG>
+__device__ __forceinline__ void msg16_st(__half2* p, float x, float y) {
+    const __half2 h = __floats2half2_rn(sat16<ALG>(x), sat16<ALG>(y));
+    __builtin_nontemporal_store(*reinterpret_cast<const uint32_t*>(&h), reinterpret_cast<uint32_t*>(p));
+}
+
+// priors [B,n] fp32 -> pair-tile layout [P][n][64] float2; optional hard word y0 -> decision planes of the two 64-frame tiles
+__global__ __launch_bounds__(256) void k_load_tile16(const float* __restrict__ priors, const uint8_t* __restrict__ y0, int64_t B, int n,
+                                                     float2* __restrict__ prior_t, u64* __restrict__ xbits) {
+    __shared__ float sp[64][65];
+    __shared__ uint8_t sy[64][68];
+    const int P = blockIdx.y, v0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int sub = 0; sub < 2; ++sub) {
+        const int tile = 2 * P + sub;
+        __syncthreads();
+        for (int f = ty; f < 64; f += 4) {
+            const int64_t fr = (int64_t)tile * 64 + f;
+            const int v = v0 + tx;
+            float val = 0.0f;
+            uint8_t yy = 0;
+            if (fr < B && v < n) {
+                if (y0) yy = y0[fr * n + v];
+                val = priors[fr * n + v];
+            }
+            sp[f][tx] = val;
+            sy[f][tx] = yy;
+        }
+        __syncthreads();
+        for (int vv = ty; vv < 64; vv += 4) {
+            const int v = v0 + vv;
+            if (v < n) {
+                reinterpret_cast<float*>(prior_t + ((int64_t)P * n + v) * 64 + tx)[sub] = sp[tx][vv];
+                if (y0) {
+                    const u64 one = __ballot(sy[tx][vv] != 0);
+                    if (tx == 0) xbits[plane_at(tile, v, n)] = one;
+                }
+            }
+        }
+    }
+}
+
+// BI-AWGN channel + LLR straight into the pair-tile layout: the expressions of k_biawgn<float> (bit-identical priors)
+__global__ __launch_bounds__(256) void k_biawgn_tile16(SimSource s, int64_t B, int n, int bpf, int blocks_per_wave, float2* __restrict__ prior_t) {
+    const int lane = threadIdx.x, P = blockIdx.y;
+    const int64_t fa = (int64_t)P * 128 + lane, fb = fa + 64;
+    if (fa >= B) return;
+    const int j0 = (blockIdx.x * 4 + threadIdx.y) * blocks_per_wave;
+    const float sg = (float)s.sigma, k = (float)s.inv_var2, mean = (float)(2 * s.codeword - 1);
+    float2* pt = prior_t + (int64_t)P * n * 64 + lane;
+    for (int j = j0; j < min(bpf, j0 + blocks_per_wave); ++j) {
+        const Philox4 pa = philox_word_block(s.seed, s.stream, s.frame0 + (uint64_t)fa, (uint32_t)j);
+        const Philox4 pb = philox_word_block(s.seed, s.stream, s.frame0 + (uint64_t)fb, (uint32_t)j);  // (beyond the batch: never read back)
+        float za[4], zb[4];
+        box_muller<float>(pa.w[0], pa.w[1], za[0], za[1]);
+        box_muller<float>(pa.w[2], pa.w[3], za[2], za[3]);
+        box_muller<float>(pb.w[0], pb.w[1], zb[0], zb[1]);
+        box_muller<float>(pb.w[2], pb.w[3], zb[2], zb[3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (4 * j + q < n) pt[(int64_t)(4 * j + q) * 64] = make_float2(-(k * (mean + sg * za[q])), -(k * (mean + sg * zb[q])));
+    }
+}
+
+// Check pass: per check, GATHER the variable -> check lines of its edges (each line exactly once per sweep: no re-read, unlike the
+// marginal-resident fp32 passes), apply the rule, STREAM the check -> variable lines out.  First sweep: v2c = prior (src/bpa.py:19).
+template <int ALG, int DCMAX, int FIXED_DC, int UNR>
+__global__ __launch_bounds__(256) void k_cn16(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var, const int32_t* __restrict__ edge_vpos,
+                                              __half2* __restrict__ c2v, const __half2* __restrict__ v2c, const float2* __restrict__ prior_t,
+                                              const u64* __restrict__ live, int m, int n, int64_t E, int pairs, int tiles, int chunks, int cpw, int first) {
+    const int lane = threadIdx.x;
+    int P, chunk;
+    if (!task_of(pairs, chunks, 0, &P, &chunk)) return;
+    if ((live[2 * P] | (2 * P + 1 < tiles ? live[2 * P + 1] : 0ull)) == 0) return;
+    __half2* ct = c2v + (int64_t)P * E * 64 + lane;
+    const __half2* vt = v2c + (int64_t)P * E * 64 + lane;
+    const float2* pt = prior_t + (int64_t)P * n * 64 + lane;
+    const int c_end = min(m, (chunk + 1) * cpw);
+    for (int c = chunk * cpw; c < c_end; c += UNR) {
+        float vx[UNR][DCMAX], vy[UNR][DCMAX];
+        int k0[UNR], deg[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int cc = c + u;
+            if (cc < c_end) {
+                k0[u] = FIXED_DC > 0 ? cc * FIXED_DC : row_ptr[cc];
+                deg[u] = FIXED_DC > 0 ? FIXED_DC : row_ptr[cc + 1] - k0[u];
+            } else {
+                k0[u] = 0;
+                deg[u] = 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+            for (int j = 0; j < DCMAX; ++j) {
+                // a short row re-reads its last edge (an empty row edge 0): no branch per line
+                const int kk = FIXED_DC > 0 ? k0[u] + j : (deg[u] > 0 ? k0[u] + (j < deg[u] ? j : deg[u] - 1) : 0);
+                const float2 v = first ? pt[(int64_t)edge_var[kk] * 64] : msg16_ld(vt + (int64_t)edge_vpos[kk] * 64);
+                vx[u][j] = v.x;
+                vy[u][j] = v.y;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            cn_rule<float, ALG, DCMAX>(vx[u], deg[u]);
+            cn_rule<float, ALG, DCMAX>(vy[u], deg[u]);
+#pragma unroll
+            for (int j = 0; j < DCMAX; ++j)
+                if (j < deg[u]) msg16_st<ALG>(ct + (int64_t)(k0[u] + j) * 64, vx[u][j], vy[u][j]);
+        }
+    }
+}
+
+// Variable pass: per variable, gather its check -> variable lines (each read once), marginal = prior + ordered sum (src/bpa.py:35), decision
+// bits, and v2c_j = marginal - c2v_j (src/bpa.py:37) STREAMED out in variable-major order (line p0 + j).  The marginal itself is written
+// only when a soft output was asked for.
+template <int ALG, int DVMAX, int UNR, int FIXED_DV>
+__global__ __launch_bounds__(256) void k_vn16(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ col_edge, const __half2* __restrict__ c2v,
+                                              __half2* __restrict__ v2c, const float2* __restrict__ prior_t, float2* __restrict__ marg_t,
+                                              const u64* __restrict__ live, u64* __restrict__ xbits, int n, int64_t E, int pairs, int tiles, int chunks, int vpw) {
+    const int lane = threadIdx.x;
+    int P, chunk;
+    if (!task_of(pairs, chunks, 0, &P, &chunk)) return;
+    const bool has_b = 2 * P + 1 < tiles;
+    const u64 lva = live[2 * P], lvb = has_b ? live[2 * P + 1] : 0ull;
+    if ((lva | lvb) == 0) return;
+    const __half2* ct = c2v + (int64_t)P * E * 64 + lane;
+    __half2* vt = v2c + (int64_t)P * E * 64 + lane;
+    const float2* pt = prior_t + (int64_t)P * n * 64 + lane;
+    float2* mt = marg_t ? marg_t + (int64_t)P * n * 64 + lane : nullptr;
+    u64* xa = xbits + plane_at(2 * P, 0, n);
+    u64* xb = xbits + plane_at(2 * P + 1, 0, n);  // (only touched when the pair has a second tile)
+    const int v_end = min(n, (chunk + 1) * vpw);
+    for (int vbase = chunk * vpw; vbase < v_end; vbase += UNR) {
+        float2 c[UNR][DVMAX], pr[UNR];
+        int deg[UNR], p0[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int vv = vbase + u < v_end ? vbase + u : v_end - 1;  // past the end: the last variable once more, result unused
+            p0[u] = FIXED_DV > 0 ? vv * FIXED_DV : col_ptr[vv];
+            deg[u] = vbase + u < v_end ? (FIXED_DV > 0 ? FIXED_DV : col_ptr[vv + 1] - p0[u]) : -1;
+            pr[u] = pt[(int64_t)vv * 64];
+#pragma unroll
+            for (int j = 0; j < DVMAX; ++j) {
+                c[u][j] = make_float2(0.0f, 0.0f);
+                if (FIXED_DV > 0 || j < deg[u]) c[u][j] = msg16_ld(ct + (int64_t)col_edge[p0[u] + j] * 64);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (deg[u] < 0) continue;  // wave-uniform
+            float sx = 0.0f, sy = 0.0f;  // ordered sum from +0.0, prior last (src/bpa.py:35, src/math_utils.py:7)
+#pragma unroll
+            for (int j = 0; j < DVMAX; ++j)
+                if (FIXED_DV > 0 || j < deg[u]) {
+                    sx += c[u][j].x;
+                    sy += c[u][j].y;
+                }
+            const float2 marg = make_float2(pr[u].x + sx, pr[u].y + sy);
+            if (mt) mt[(int64_t)(vbase + u) * 64] = marg;
+#pragma unroll
+            for (int j = 0; j < DVMAX; ++j)
+                if (FIXED_DV > 0 || j < deg[u]) msg16_st<ALG>(vt + (int64_t)(p0[u] + j) * 64, marg.x - c[u][j].x, marg.y - c[u][j].y);
+            const u64 onea = __ballot(marg.x < 0.0f), oneb = __ballot(marg.y < 0.0f);  // NaN marginal -> 0 (src/bpa.py:38,62)
+            const int vv = vbase + u;
+            u64 ma = onea, mb = oneb;
+            if (lva != ~0ull) ma = (xa[8 * vv] & ~lva) | (onea & lva);  // frames that have left keep their decisions
+            if (has_b && lvb != ~0ull) mb = (xb[8 * vv] & ~lvb) | (oneb & lvb);
+            if (lane == 0) {
+                xa[8 * vv] = ma;
+                if (has_b) xb[8 * vv] = mb;
+            }
+        }
+    }
+}
+
+// marginal pair-tile [n][64] float2 -> [B,n] (diagnostic / tolerance tests; frames that have left keep evolving in this mode, so the
+// soft output is meaningful for runs without early exit)
+__global__ void k_soft_out16(const float2* __restrict__ soft_t, float* __restrict__ out, int64_t B, int n) {
+    const int P = blockIdx.y, lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n) return;
+    const float2 m = soft_t[((int64_t)P * n + v) * 64 + lane];
+    const int64_t fa = (int64_t)P * 128 + lane, fb = fa + 64;
+    if (fa < B) out[fa * n + v] = m.x;
+    if (fb < B) out[fb * n + v] = m.y;
+}
+
+#ifndef LDPC_CN16_UNR
+#define LDPC_CN16_UNR 2
+#endif
+template <int ALG>
+int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags_in, uint8_t* xhat, int32_t* iters,
+          float* soft_out, hipStream_t st, const SimSource* sim) {
+    const Code* c = d->code;
+    const int n = c->n, m = c->m;
+    const int64_t E = c->E;
+    if (c->max_dc > 64 || c->max_dv > 64) {
+        set_error("streaming backend supports node degrees up to 64 (max_dc=%d, max_dv=%d)", c->max_dc, c->max_dv);
+        return LDPC_E_UNSUPPORTED;
+    }
+    const int tiles = (int)((B + 63) / 64), pairs = (tiles + 1) / 2;
+    const bool early = !(flags_in & FLAG_NO_EARLY_EXIT);
+    LDPC_TRY(d->msg.reserve((size_t)pairs * E * 64 * sizeof(__half2)));
+    LDPC_TRY(d->msg2.reserve((size_t)pairs * E * 64 * sizeof(__half2)));  // variable -> check lines, variable-major
+    if (soft_out) LDPC_TRY(d->marg.reserve((size_t)pairs * n * 64 * sizeof(float2)));
+    if (!d->scratch.p) {  // row-major edge k -> its position in the CSC edge list (where the variable pass writes its v2c line)
+        std::vector<int32_t> vpos((size_t)E);
+        for (int64_t p = 0; p < E; ++p) vpos[(size_t)c->col_edge[(size_t)p]] = (int32_t)p;
+        LDPC_TRY(d->scratch.reserve((size_t)E * sizeof(int32_t) + 16));
+        LDPC_HIP_TRY(hipMemcpy(d->scratch.p, vpos.data(), (size_t)E * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    const int32_t* edge_vpos = (const int32_t*)d->scratch.p;
+    LDPC_TRY(d->prior.reserve((size_t)pairs * n * 64 * sizeof(float2)));
+    LDPC_TRY(d->xbits.reserve(plane_words(2 * pairs, n) * 8));
+    LDPC_TRY(d->live.reserve((size_t)2 * pairs * 8));
+    LDPC_TRY(d->flags.reserve((size_t)2 * pairs * 16 + 64));
+    __half2* msg = (__half2*)d->msg.p;
+    __half2* v2c = (__half2*)d->msg2.p;
+    float2* marg = soft_out ? (float2*)d->marg.p : nullptr;
+    float2* prior = (float2*)d->prior.p;
+    u64* xbits = (u64*)d->xbits.p;
+    u64* live = (u64*)d->live.p;
+    u64* tflags = (u64*)d->flags.p;
+    int* live_tiles = (int*)((char*)d->flags.p + (size_t)2 * pairs * 16);
+    volatile int* poll_host = (volatile int*)d->pinned;
+    LDPC_HIP_TRY(hipMemsetAsync(xbits, 0, plane_words(2 * pairs, n) * 8, st));
+    LDPC_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)2 * pairs * 16 + 64, st));
+    LDPC_HIP_TRY(hipMemsetAsync(live, 0, (size_t)2 * pairs * 8, st));
+    LDPC_HIP_TRY(hipMemsetAsync(iters, 0, (size_t)B * sizeof(int32_t), st));
+    if (sim) {
+        const int bpf = (n + 3) / 4, bpw = 16;
+        hipLaunchKernelGGL(k_biawgn_tile16, dim3(((bpf + bpw - 1) / bpw + 3) / 4, pairs), dim3(64, 4), 0, st, *sim, B, n, bpf, bpw, prior);
+    } else {
+        hipLaunchKernelGGL(k_load_tile16, dim3((n + 63) / 64, pairs), dim3(256), 0, st, priors, y0, B, n, prior, xbits);
+    }
+    hipLaunchKernelGGL(k_init_live, dim3((tiles + 255) / 256), dim3(256), 0, st, live, B, tiles);
+
+    const int cpw = env_int("LDPC_STREAM_CPW", 4), vpw = env_int("LDPC_STREAM_VPW", 16);
+    const int cn_chunks = (m + cpw - 1) / cpw, vn_chunks = (n + vpw - 1) / vpw;
+    const int cap = max_iter > 0 ? max_iter : 100000;
+    const int poll_every = 4;
+    const bool reg36 = c->min_dc == c->max_dc && c->max_dc == 6;
+    const bool dv3 = c->min_dv == c->max_dv && c->max_dv == 3;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    std::vector<ProfSpan> spans;
+    size_t ev_next = 0;
+    int sweeps = 0;
+    bool all_left = false;
+    for (int it = 0; it < cap && !all_left; ++it) {
+        if (early && (it > 0 || y0 != nullptr)) {
+            const bool poll = (it % poll_every) == 0;
+            if (poll) LDPC_HIP_TRY(hipMemsetAsync(live_tiles, 0, 2 * sizeof(int), st));
+            const int groups = (tiles + 7) / 8;
+            int sblocks = (1024 + groups - 1) / groups;
+            const int smax = (m + 1023) / 1024;
+            sblocks = sblocks < 1 ? 1 : (sblocks > smax ? smax : sblocks);
+            hipLaunchKernelGGL(k_syndrome_part, dim3(sblocks, groups), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, xbits, live, tflags, m, n, tiles,
+                               (m + sblocks - 1) / sblocks);
+            hipLaunchKernelGGL(k_syndrome_fin, dim3(tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr, B, sweeps, (const int32_t*)nullptr);
+            if (poll) {
+                LDPC_HIP_TRY(hipMemcpyAsync((void*)poll_host, live_tiles, sizeof(int), hipMemcpyDeviceToHost, st));
+                LDPC_HIP_TRY(hipStreamSynchronize(st));
+                if (poll_host[0] == 0) {
+                    all_left = true;
+                    break;
+                }
+            }
+        }
+        if (d->profile) {
+            LDPC_TRY(prof_event(d, ev_next++, &e0));
+            LDPC_TRY(prof_event(d, ev_next++, &e1));
+            LDPC_TRY(prof_event(d, ev_next++, &e2));
+            LDPC_HIP_TRY(hipEventRecord(e0, st));
+        }
+        const int first = it == 0 ? 1 : 0;
+        const dim3 cgrid(task_blocks(pairs, cn_chunks, 0)), vgrid(task_blocks(pairs, vn_chunks, 0)), blk(64, 4);
+#define LDPC_CN16(DCM, FDC, UNR) \
+    hipLaunchKernelGGL((k_cn16<ALG, DCM, FDC, UNR>), cgrid, blk, 0, st, c->d_row_ptr, c->d_edge_var, edge_vpos, msg, v2c, prior, live, m, n, E, pairs, tiles, cn_chunks, cpw, first)
+        if (reg36) LDPC_CN16(6, 6, LDPC_CN16_UNR);
+        else if (c->max_dc <= 4) LDPC_CN16(4, 0, 2);
+        else if (c->max_dc <= 6) LDPC_CN16(6, 0, 2);
+        else if (c->max_dc <= 8) LDPC_CN16(8, 0, 1);
+        else if (c->max_dc <= 16) LDPC_CN16(16, 0, 1);
+        else if (c->max_dc <= 32) LDPC_CN16(32, 0, 1);
+        else LDPC_CN16(64, 0, 1);
+#undef LDPC_CN16
+        if (d->profile) LDPC_HIP_TRY(hipEventRecord(e1, st));
+#define LDPC_VN16(DVM, UNR, FDV) \
+    hipLaunchKernelGGL((k_vn16<ALG, DVM, UNR, FDV>), vgrid, blk, 0, st, c->d_col_ptr, c->d_col_edge, msg, v2c, prior, marg, live, xbits, n, E, pairs, tiles, vn_chunks, vpw)
+        if (dv3) LDPC_VN16(3, 4, 3);
+        else if (c->max_dv <= 4) LDPC_VN16(4, 4, 0);
+        else if (c->max_dv <= 8) LDPC_VN16(8, 2, 0);
+        else if (c->max_dv <= 16) LDPC_VN16(16, 1, 0);
+        else if (c->max_dv <= 32) LDPC_VN16(32, 1, 0);
+        else LDPC_VN16(64, 1, 0);
+#undef LDPC_VN16
+        if (d->profile) {
+            LDPC_HIP_TRY(hipEventRecord(e2, st));
+            spans.push_back({0, e0, e1});
+            spans.push_back({1, e1, e2});
+        }
+        ++sweeps;
+    }
+    hipLaunchKernelGGL(k_finish_iters, dim3(tiles), dim3(64), 0, st, live, iters, B, sweeps, (const int32_t*)nullptr);
+    hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256, tiles), dim3(256), 0, st, xbits, xhat, B, n, (const int32_t*)nullptr);
+    if (soft_out) hipLaunchKernelGGL(k_soft_out16, dim3((n + 3) / 4, pairs), dim3(256), 0, st, marg, soft_out, B, n);
+    LDPC_HIP_TRY(hipGetLastError());
+    if (d->profile) {
+        LDPC_HIP_TRY(hipStreamSynchronize(st));
+        LDPC_TRY(prof_collect(d, spans));
+    }
+    d->last_repacks = 0;
+    d->last_sweeps = sweeps;
+    d->last_backend = BK_STREAM;
+    return LDPC_OK;
+}
+
+}  // namespace
+
+// fp16-storage mode entry points (LDPC_DTYPE_F16): priors are fp32
+static int stream_decode_f16(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags, uint8_t* xhat, int32_t* iters,
+                             float* soft_out, hipStream_t st, const SimSource* sim) {
+    if (B <= 0) return LDPC_OK;
+    if (B > (int64_t)65535 * 64) {
+        set_error("batch of %lld frames exceeds one launch (max %d); split the call", (long long)B, 65535 * 64);
+        return LDPC_E_ARG;
+    }
+    if (d->alg == ALG_MSA) return run16<ALG_MSA>(d, (const float*)priors, y0, B, max_iter, flags, xhat, iters, soft_out, st, sim);
+    if (d->alg == ALG_SPA) return run16<ALG_SPA>(d, (const float*)priors, y0, B, max_iter, flags, xhat, iters, soft_out, st, sim);
+    set_error("fp16 storage: LLR decoders (the erasure decoder moves 2 bits per message already)");
+    return LDPC_E_UNSUPPORTED;
+}
+
+
 // ldpc_simulate on the streaming kernels, BI-AWGN with the all-`codeword` word: channel + LLR generated into the tiles, then the decode
 int stream_simulate_biawgn(Decoder* d, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
                            int32_t max_iter, uint32_t flags, uint8_t* xhat, int32_t* iters, hipStream_t st) {
@@ -792,6 +1156,7 @@ int stream_simulate_biawgn(Decoder* d, double param, int codeword, uint64_t seed
     }
     const double var = pow(10.0, -param / 10.0);  // src/biawgn.py:10 -- the host arithmetic of channel_generate()
     const SimSource s{sqrt(var), 2.0 / var, codeword, seed, frame0, (uint32_t)stream_id};
+    if (d->dtype == DT_F16) return stream_decode_f16(d, nullptr, nullptr, B, max_iter, flags, xhat, iters, nullptr, st, &s);
     if (d->alg == ALG_MSA)
         return d->dtype == DT_F64 ? run<double, ALG_MSA>(d, nullptr, nullptr, B, max_iter, flags, xhat, iters, nullptr, st, &s)
                                   : run<float, ALG_MSA>(d, nullptr, nullptr, B, max_iter, flags, xhat, iters, nullptr, st, &s);
@@ -817,6 +1182,7 @@ int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, 
         set_error("priors pointer is null");
         return LDPC_E_ARG;
     }
+    if (d->dtype == DT_F16) return stream_decode_f16(d, priors, y0, B, max_iter, flags, xhat, iters, (float*)soft_out, st, nullptr);
     if (d->alg == ALG_MSA) {
         return d->dtype == DT_F64 ? run<double, ALG_MSA>(d, priors, y0, B, max_iter, flags, xhat, iters, soft_out, st)
                                   : run<float, ALG_MSA>(d, priors, y0, B, max_iter, flags, xhat, iters, soft_out, st);

@@ -9,7 +9,7 @@ UNITS=${@:-ldpc_fused_shapes_f32_dc6.hip ldpc_fused_shapes_f32_dcx.hip ldpc_fuse
 mkdir -p $CSRC/variants/$NAME
 make -s -C $CSRC -j8 libldpc_hip.so
 OBJS=""
-for f in ldpc_api ldpc_stream ldpc_fused ldpc_fused_shapes_f32_dc6 ldpc_fused_shapes_f32_dcx ldpc_fused_shapes_f64_dc6 ldpc_fused_shapes_f64_dcx ldpc_channel ldpc_layout ldpc_ml ldpc_admm; do
+for f in ldpc_api ldpc_stream ldpc_fused ldpc_fused_shapes_f32_dc6 ldpc_fused_shapes_f32_dcx ldpc_fused_shapes_f64_dc6 ldpc_fused_shapes_f64_dcx ldpc_fused_shapes_bec ldpc_bec_stream ldpc_channel ldpc_layout ldpc_ml ldpc_admm; do
   if echo " $UNITS " | grep -q " $f.hip "; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function $FLAGS -c $CSRC/$f.hip -o $CSRC/variants/$NAME/$f.o &
     OBJS="$OBJS $CSRC/variants/$NAME/$f.o"
