@@ -141,7 +141,12 @@ __device__ __forceinline__ float gat_tab(const unsigned char* base, const uint32
 template <int R0, int R1>
 __device__ __forceinline__ void lds_st2_rows(uint32_t vaddr, float a, float b) {
     static_assert(R0 >= 0 && R0 < 256 && R1 >= 0 && R1 < 256, "8-bit row offsets");
+#ifdef LDPC_BIG_UNPAIRED_STORES  // A/B (profiles/r04_big_store_pairing.txt): the same two rows as two ds_write_b32 -- 4 + 4 store-path cycles instead of 6
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vaddr), "v"(a), "n"(R0 * 256) : "memory");
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vaddr), "v"(b), "n"(R1 * 256) : "memory");
+#else
     asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(vaddr), "v"(a), "v"(b), "n"(R0), "n"(R1) : "memory");
+#endif
 }
 
 // one row of 8-byte elements, lane-contiguous: ds_write_b64 with an immediate row offset.  Written as inline asm so that the

@@ -15,7 +15,7 @@ import torch  # noqa: E402
 from bench import HBM_PEAK_GBS, fused_roofline, load_code  # noqa: E402
 from ldpc_decoders_amd._device import DecoderHandle  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 try:
     COUNTERS = json.load(open(os.path.join(ROOT, "profiles", "roofline_counters.json")))
 except Exception:
@@ -30,8 +30,12 @@ CASES = [  # config, code, decoder alg, channel, param, batch, steps, backend[, 
     ("3: n=1200 (3,6) SPA BSC", "1200_3_6_rand_ldpc_1", "SPA", "bsc", 0.05, 65536, 6, "auto"),
     ("3: n=1200 (3,6) SPA BI-AWGN, fp64 (the reference's formula verbatim, LDS kernel)", "1200_3_6_rand_ldpc_1", "SPA", "biawgn", 1.5, 65536, 3, "auto", "f64"),
     ("3: n=1200 (3,6) SPA BI-AWGN, fp64, streaming kernels", "1200_3_6_rand_ldpc_1", "SPA", "biawgn", 1.5, 16384, 1, "stream", "f64"),
-    ("3: n=1200 (3,6) erasure decoder BEC", "1200_3_6_rand_ldpc_1", "BEC", "bec", 0.40, 65536, 6, "auto"),
-    ("3: n=1200 (3,6) erasure decoder BEC", "1200_3_6_rand_ldpc_1", "BEC", "bec", 0.35, 65536, 6, "auto"),
+    ("3: n=1200 (3,6) erasure decoder BEC, bit-sliced on the LDS, 2^20-frame launches (continuous refill wants long launches)", "1200_3_6_rand_ldpc_1", "BEC", "bec", 0.40, 1048576, 6, "auto"),
+    ("3: n=1200 (3,6) erasure decoder BEC, bit-sliced on the LDS, 2^20-frame launches (continuous refill wants long launches)", "1200_3_6_rand_ldpc_1", "BEC", "bec", 0.35, 1048576, 6, "auto"),
+    ("3: same, the BASELINE batch of 65 536 frames per launch (two slabs of 32 frames per workgroup: launch-bound)", "1200_3_6_rand_ldpc_1", "BEC", "bec", 0.40, 65536, 6, "auto"),
+    ("3: same, bit-sliced streaming kernels (state in HBM)", "1200_3_6_rand_ldpc_1", "BEC", "bec", 0.40, 65536, 3, "stream"),
+    ("4: rate-1/2 irregular n=10000 erasure decoder (bit-sliced streaming: a slab is 245 KB of bit planes)", "gen:irg:10000", "BEC", "bec", 0.44, 32768, 2, "auto"),
+    ("5: (3,6) n=64800 erasure decoder (bit-sliced streaming)", "gen:reg:64800:3:6", "BEC", "bec", 0.40, 32768, 2, "auto"),
     ("4: rate-1/2 irregular n=10000 MSA (2^20 frames over 8 GPUs = 131072 per GPU)", "gen:irg:10000", "MSA", "biawgn", 1.2, 131072, 2, "auto"),
     ("4: rate-1/2 irregular n=10000 MSA (2^20 frames over 8 GPUs = 131072 per GPU)", "gen:irg:10000", "MSA", "biawgn", 1.8, 131072, 2, "auto"),
     ("4: same, streaming kernels", "gen:irg:10000", "MSA", "biawgn", 1.2, 32768, 1, "stream"),
@@ -39,6 +43,9 @@ CASES = [  # config, code, decoder alg, channel, param, batch, steps, backend[, 
     ("4: same, fp64 (the reference's arithmetic; 327 KB per frame: streaming kernels)", "gen:irg:10000", "MSA", "biawgn", 1.8, 32768, 1, "auto", "f64"),
     ("5: (3,6) n=64800 MSA, early termination (2^18 frames over 8 GPUs = 32768 per GPU)", "gen:reg:64800:3:6", "MSA", "biawgn", 1.0, 32768, 1, "auto"),
     ("5: (3,6) n=64800 MSA, early termination (2^18 frames over 8 GPUs = 32768 per GPU)", "gen:reg:64800:3:6", "MSA", "biawgn", 2.0, 32768, 1, "auto"),
+    ("5: same, fp16 STORAGE mode (2-byte messages, fp32 arithmetic: tolerance mode, not the parity mode)", "gen:reg:64800:3:6", "MSA", "biawgn", 1.0, 32768, 1, "auto", "f16"),
+    ("5: same, fp16 STORAGE mode (2-byte messages, fp32 arithmetic: tolerance mode, not the parity mode)", "gen:reg:64800:3:6", "MSA", "biawgn", 2.0, 32768, 1, "auto", "f16"),
+    ("4: rate-1/2 irregular n=10000 MSA, fp16 STORAGE mode on the streaming kernels", "gen:irg:10000", "MSA", "biawgn", 1.8, 32768, 1, "stream", "f16"),
 ]
 rows = []
 cache = {}
@@ -61,7 +68,13 @@ for case in CASES:
     dt = time.perf_counter() - t0
     c = cnt.cpu().numpy()
     frames, sweeps = int(c[0]), int(c[3])
-    bytes_fs = (8 if prec == "f64" else 4) * (4 * g.E + g.n) if alg != "BEC" else (4 * g.E + g.n)
+    # algorithmic bytes per frame-sweep: SURVEY 8(d) s(4E + n); fp16 storage: 2-byte messages + 4-byte priors = 8E + 4n; erasure decoder:
+    # 2 bits per message, (4E + m + 3n) / 4 bytes for the bit-sliced streaming sweep (ldpc_bec_stream.hip)
+    bytes_fs = (8 if prec == "f64" else 4) * (4 * g.E + g.n)
+    if prec == "f16":
+        bytes_fs = 8 * g.E + 4 * g.n
+    if alg == "BEC":
+        bytes_fs = (4 * g.E + g.m + 3 * g.n) / 4.0
     # roofline of the dominant kernel: LDS-resident kernels from the committed PMC counters of that very kernel (keyed by its name) x the
     # frame-sweeps/s measured here; streaming kernels against the HBM peak with the section-8(d) algorithmic bytes of the sweep
     backend_used = h.last_stats()[0]
@@ -74,7 +87,8 @@ for case in CASES:
         roof["note"] = "whole step (channel + decode + count are this one kernel): busy cycles per frame-sweep (PMC) x frame-sweeps/s of this run / available cycles at 2.4 GHz"
     else:
         gbs = sweeps * bytes_fs / dt / 1e9
-        roof = dict(bound="hbm", frac=round(gbs / HBM_PEAK_GBS, 4), achieved_GBps=round(gbs, 1), peak_GBps=HBM_PEAK_GBS, kernel="k_cn + k_vn",
+        roof = dict(bound="hbm", frac=round(gbs / HBM_PEAK_GBS, 4), achieved_GBps=round(gbs, 1), peak_GBps=HBM_PEAK_GBS,
+                    kernel="k_becs_cn + k_becs_vn" if alg == "BEC" else ("k_cn16 + k_vn16" if prec == "f16" else "k_cn + k_vn"),
                     counters_from="HBM bytes per launch of both passes: profiles/roofline_counters.json (hbm:* entries)",
                     note="whole step incl. channel, tile load, syndrome, repack and counting kernels: executed frame-sweeps x s(4E+n) / wall time / 8 TB/s")
     rows.append(dict(roofline=roof, config=cfg, code=code_name, n=g.n, E=g.E, decoder=alg, precision=prec, channel=ch, param=prm, max_iter=50, frames_per_step=B, steps=steps,
