@@ -6,7 +6,7 @@
 # it into profiles/<tag>_roofline_counters.json (+ profiles/roofline_counters.json, the copy bench.py and measure_configs.py read).
 #   tools/collect_rooflines.sh <tag> [case ...]
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
@@ -36,6 +36,9 @@ CASES=(
  "c5_stream_f32|--code gen:reg:64800:3:6 --alg MSA --channel biawgn --param 1.0 --batch 8192 --precision f32 --backend stream --launches 1|hbm"
  "c2_stream_f32|--code 1200_3_6_rand_ldpc_1 --alg MSA --channel biawgn --param 1.0 --batch 65536 --precision f32 --backend stream --launches 1|hbm"
  "c2_stream_f64|--code 1200_3_6_rand_ldpc_1 --alg MSA --channel biawgn --param 1.0 --batch 65536 --precision f64 --backend stream --launches 1|hbm"
+ "c5_stream_f16|--code gen:reg:64800:3:6 --alg MSA --channel biawgn --param 1.0 --batch 8192 --precision f16 --launches 1|hbm"
+ "c5_bec_stream|--code gen:reg:64800:3:6 --alg BEC --channel bec --param 0.40 --batch 32768 --precision f32 --launches 1|hbm"
+ "c4_bec_stream|--code gen:irg:10000 --alg BEC --channel bec --param 0.44 --batch 32768 --precision f32 --launches 1|hbm"
 )
 for C in "${CASES[@]}"; do
   NAME=${C%%|*}; REST=${C#*|}; ARGS=${REST%%|*}; PASSES=${REST#*|}

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX: everything a round's measurements are quoted from, under gpurun_out/<tag>/.   tools/round_measure.sh <tag> [quick]
 # Order matters: the PMC counters are collected first and condensed ON THE BOX (profiles/roofline_counters.json), because bench.py and
 # tools/measure_configs.py read them; whatever lands in profiles/ there is copied to gpurun_out/<tag>/profiles/ for the trip home.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -17,7 +17,9 @@ python bench.py --code gen:reg:64800:3:6 --batch 32768 --snr 1.0 --steps 2 --war
 python bench.py --code gen:reg:64800:3:6 --batch 32768 --snr 2.0 --steps 2 --warmup 1 --repeats 3 --precision f32 --no-cpu-baseline --points > $OUT/bench_config5_n64800_2.0dB.json 2> $OUT/bench_c5b.err
 python bench.py --code gen:irg:10000 --batch 131072 --snr 1.2 --steps 3 --warmup 1 --repeats 3 --precision f32 --no-cpu-baseline --points > $OUT/bench_config4_n10000_irregular.json 2> $OUT/bench_c4a.err
 python bench.py --code gen:irg:10000 --batch 32768 --snr 1.8 --steps 2 --warmup 1 --repeats 3 --precision f64 --no-cpu-baseline --points > $OUT/bench_config4_n10000_irregular_f64_stream.json 2> $OUT/bench_c4b.err
-for f in bench bench_f32 bench_config5_n64800_1.0dB bench_config5_n64800_2.0dB bench_config4_n10000_irregular bench_config4_n10000_irregular_f64_stream; do cp $OUT/$f.json profiles/${TAG}_$f.json 2>/dev/null; done
+# the driver's own command (BENCH_rNN.json): --steps 20 --warmup 5
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_command.json 2> $OUT/bench_drv.err
+for f in bench bench_f32 bench_config5_n64800_1.0dB bench_config5_n64800_2.0dB bench_config4_n10000_irregular bench_config4_n10000_irregular_f64_stream bench_driver_command; do cp $OUT/$f.json profiles/${TAG}_$f.json 2>/dev/null; done
 # rocprofv3 --kernel-trace --stats of the bench command itself (the contract's "same command"): its average kernel duration is what
 # roofline.avg_launch_ms (HIP events inside bench.py) must agree with
 ( cd /tmp && export TMPDIR=/tmp

@@ -17,7 +17,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 PEAK_CLOCK = 2.4e9
@@ -190,7 +190,7 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
         E, n = ih.get("E", 0), ih.get("n", 0)
         sweeps = None
         for k in sorted(fs_):
-            if not k.startswith("k_") or k.startswith("k_copy4"):
+            if not k.startswith("k_") or k.startswith("k_copy4") or len(fs_[k].get("FETCH_SIZE", [])) == 0:
                 continue
             f_, w_ = fs_[k]["FETCH_SIZE"], ws_.get(k, {}).get("WRITE_SIZE", [0])
             fa, wa = sum(f_) / len(f_), sum(w_) / max(len(w_), 1)
@@ -200,6 +200,11 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
                 # frames live in a launch vary with early termination: use launches at full batch only when no frame leaves (1.0 dB cases)
                 frames = ih.get("batch", 0)
                 alg = frames * s * ((2 * E + n) if k.startswith("k_cn<") else (E + 2 * n))
+            elif k.startswith("k_cn16<") or k.startswith("k_vn16<"):  # fp16 storage, two-array sweep: 2-byte messages, 4-byte priors
+                alg = ih.get("batch", 0) * ((4 * E) if k.startswith("k_cn16<") else (4 * E + 4 * n))
+            elif k.startswith("k_becs_cn") or k.startswith("k_becs_vn"):  # bit-sliced erasure passes: 8-byte elements per 32 frames
+                m_ = ih.get("m", 0)
+                alg = ih.get("batch", 0) * ((E + m_) if k.startswith("k_becs_cn") else (3 * E + 3 * n)) // 4
             ent = dict(case=case, kernel=k, launches=len(f_), fetch_kib_per_launch=round(fa, 1), write_kib_per_launch=round(wa, 1),
                        hbm_bytes_per_launch=int(tot_b), calibration=dict(fetch=round(kf, 4), write=round(kw, 4)),
                        compulsory_bytes_per_launch=alg, traffic_over_compulsory=round(tot_b / alg, 4) if alg else None,
