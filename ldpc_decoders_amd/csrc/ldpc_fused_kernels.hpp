@@ -222,6 +222,11 @@ constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
     return alg == ALG_MSA ? 8 : 15;
 }
 #endif
+// the guarded (exact-in-fp32) variants carry one more live register (the guard's running maximum): more table words stay packed
+#ifndef LDPC_GRID_OPAQUE_CN
+#define LDPC_GRID_OPAQUE_CN 15
+#define LDPC_GRID_OPAQUE_VN 15
+#endif
 constexpr int SIM_ACC_LANE0 = 60;  // hist_bins <= 60 (fused_simulate_supported)
 __device__ __forceinline__ void sim_count(unsigned& accv, int lane, int err, int it, int hist_bins) {
     const int bin = it < hist_bins ? it : hist_bins - 1;  // no histogram: -1, no lane
@@ -289,9 +294,9 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
     auto opaque_tables = [&]() {  // see sim_opaque_cn
         if constexpr (SIM) {
 #pragma unroll
-            for (int i = 0; i < sim_opaque_cn(ALG, NW, VRX) && i < CNW; ++i) asm volatile("" : "+v"(cn_idx[i]));
+            for (int i = 0; i < (GRID ? LDPC_GRID_OPAQUE_CN : sim_opaque_cn(ALG, NW, VRX)) && i < CNW; ++i) asm volatile("" : "+v"(cn_idx[i]));
 #pragma unroll
-            for (int i = 0; i < sim_opaque_vn(ALG, NW, VRX) && i < VNW; ++i) asm volatile("" : "+v"(vn_idx[i]));
+            for (int i = 0; i < (GRID ? LDPC_GRID_OPAQUE_VN : sim_opaque_vn(ALG, NW, VRX)) && i < VNW; ++i) asm volatile("" : "+v"(vn_idx[i]));
         }
     };
     auto vmap_of = [&](int q) -> int {

@@ -50,6 +50,9 @@ def test_numpy_oracle_bit_exact(path):
                 assert np.array_equal(marg[0], want)
 
 
+C_ORACLE_SPA_ITERATION_COUNTS_THAT_MAY_DIFFER = {"bsc_SPA_4_2_test_0p1_cw0_it10": {2, 12, 21, 201, 235}}
+
+
 @pytest.mark.parametrize("path", decode_cases(), ids=case_id)
 def test_c_oracle(path):
     c = load_case(path)
@@ -66,9 +69,16 @@ def test_c_oracle(path):
     keep = np.setdiff1d(np.arange(len(y)), c["raw_rows"])
     if c["decoder"] == "MSA":
         assert (xh[keep] == want[keep]).all() and (it[keep] == c["iters"][keep]).all()
-    else:  # libm vs numpy transcendental rounding may flip a chaotic, non-converging frame
+    else:
+        # sum-product: the C library's tanh / log / exp / atanh may differ from numpy's by ulps.  MEASURED on all 2 770 golden frames
+        # (held as tightly as measured, not to a floor): every frame's decisions are the reference's; iteration
+        # counts of the converging frames too, except five frames of the 5-bit toy code over the BSC, named here.
         same = (xh[keep] == want[keep]).all(axis=1)
-        assert same.mean() >= 0.9
+        assert same.all(), "C oracle sum-product: frames %s differ from the reference" % keep[~same].tolist()
+        conv = c["iters"][keep] < c["max_iter"]
+        off = keep[conv][it[keep][conv] != c["iters"][keep][conv]]
+        allowed = C_ORACLE_SPA_ITERATION_COUNTS_THAT_MAY_DIFFER.get(case_id(path), set())
+        assert set(off.tolist()) <= allowed, "C oracle sum-product: iteration counts of frames %s differ" % sorted(set(off.tolist()) - allowed)
 
 
 @pytest.mark.parametrize("path", [p for p in decode_cases("*_SPA_*") if "bec_" not in p and ("1200" in p or "512" in p)], ids=case_id)
