@@ -130,8 +130,8 @@ def _published_point(channel, code_name, decoder, max_iter, codeword, param):
 
 def test_config3_spa_bsc_full_batch():
     # config 3: n = 1200 sum-product over the BSC, batch 65 536 on one GPU (device channel kernel, fp32 LDS kernel).
-    # (1) size-independent properties on the whole batch; (2) 4 096 frames re-decoded by the fp64 phi-domain oracle: identical decisions
-    # (measured: all but two non-converging frames, which are named below); (3) the reference's own arithmetic (fp64, formula
+    # (1) size-independent properties on the whole batch; (2) ALL 65 536 frames re-decoded by the fp64 phi-domain oracle: identical decisions
+    # (measured: all but a few non-converging frames, which are named below); (3) the reference's own arithmetic (fp64, formula
     # verbatim) at the reference's published operating point -- bsc-1200_3_6_rand_ldpc_1-SPA-10-0.json, p = 0.06, 581 frames upstream --
     # word-error rate within 4 sigma of the published value, bit-error rate within its spread.
     import multiprocessing as mp
@@ -150,9 +150,9 @@ def test_config3_spa_bsc_full_batch():
     xh, it = xhat.cpu().numpy(), iters.cpu().numpy()
     done = it < 50
     assert done.mean() > 0.9 and code.syndrome(xh[done]).sum() == 0     # every frame that left early carries a codeword
-    idx = np.arange(0, B, 16)                                            # 4 096 frames spread over the batch
+    idx = np.arange(B)                                                   # EVERY frame of the batch (round 3 re-decoded 4 096 of them)
     yh, ph = y[idx].cpu().numpy().astype(float), pri[idx].double().cpu().numpy()
-    with mp.get_context("fork").Pool(16) as pool:
+    with mp.get_context("fork").Pool(min(os.cpu_count() or 16, 128)) as pool:
         parts = pool.map(_phi_chunk, [("1200_3_6_rand_ldpc_1", yh[i:i + 256], ph[i:i + 256], 50) for i in range(0, len(idx), 256)])
     xo = np.concatenate([p[0] for p in parts])
     io = np.concatenate([p[1] for p in parts])
@@ -174,9 +174,10 @@ def test_config3_spa_bsc_full_batch():
     assert 0.6 <= (ber / wer) / (ref["ber"] / ref["wer"]) <= 1.6
 
 
-# fp32 message arithmetic against the fp64 oracle: measured on the 4 096 re-decoded frames (profiles/r03H_parity_measured.txt), two
-# non-converging frames end in different words; the list names them, any other frame must be identical
-CONFIG3_SPA_FRAMES_THAT_MAY_DIFFER = {18000, 36016}
+# fp32 message arithmetic against the fp64 oracle: measured on ALL 65 536 frames of the batch (round 4; 25 s of host time on the bench
+# host), 26 non-converging frames (0.04 %) end in different words; the list names them, any other frame must be identical
+CONFIG3_SPA_FRAMES_THAT_MAY_DIFFER = {27, 3405, 5630, 6517, 6765, 8213, 9090, 17125, 17180, 18000, 21207, 24486, 24982, 29821, 30669, 32453,
+                                      36016, 39127, 48564, 49307, 50062, 54958, 55836, 57414, 58233, 61295}
 
 
 def test_config3_erasure_full_batch():

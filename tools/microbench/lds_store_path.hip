@@ -12,7 +12,10 @@ __global__ __launch_bounds__(256) void k(double* out, int iters) {
     const uint32_t base = (uint32_t)(uintptr_t)smem + w * 8192;
     // lane-contiguous address and a conflict-free "gathered" one (a permutation of the lanes inside each half-wave)
     const uint32_t a_lin = base + lane * 8, a_perm = base + ((lane & 32) | ((lane * 5 + 3) & 31)) * 8;
-    double v = (double)lane, acc = 0.0;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const uint32_t a_lin2 = base + lane * 16;
+    double v = (double)lane, acc = 0.0, v2 = v + 1.0;
+    d2 q = {v, v2};
     for (int i = lane; i < 1024; i += 64) reinterpret_cast<double*>(smem + w * 8192)[i] = 0.0;
     __syncthreads();
     for (int it = 0; it < iters; ++it) {
@@ -23,6 +26,17 @@ __global__ __launch_bounds__(256) void k(double* out, int iters) {
             if (KIND == 2) asm volatile("ds_add_f64 %0, %1 offset:%2" ::"v"(a_perm), "v"(v), "n"(r * 512) : "memory");
             if (KIND == 3) { double t; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t) : "v"(a_perm), "n"(r * 512) : "memory"); acc += t; }
             if (KIND == 4) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(a_perm), "v"((float)v), "n"(r * 512) : "memory");
+            // two rows per instruction (round 4, second half): counted per INSTRUCTION, i.e. per two rows of 64 doubles
+            if (KIND == 5 && (r & 1) == 0) asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(a_perm), "v"(v), "v"(v2), "n"(r), "n"(r + 1) : "memory");
+            if (KIND == 6 && (r & 1) == 0) asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(a_lin2), "v"(v), "v"(v2), "n"((r & 2) * 64), "n"((r & 2) * 64 + 1) : "memory");
+            if (KIND == 7 && (r & 1) == 0) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a_lin2), "v"(q), "n"(r * 512) : "memory");
+            if (KIND == 8 && (r & 1) == 0) { d2 t; asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(t) : "v"(a_perm), "n"(r), "n"(r + 1) : "memory"); acc += t.x + t.y; }
+            if (KIND == 9 && (r & 1) == 0) { d2 t; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(a_lin2), "n"(r * 512) : "memory"); acc += t.x + t.y; }
+            // the kernel's mix: are loads and stores additive on the path?  per group of 4 slots: 2 gathers + 1 row store (3 instructions)
+            if (KIND == 10 && (r & 3) != 3) {
+                if ((r & 3) == 2) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a_lin), "v"(v), "n"(r * 512) : "memory");
+                else { double t; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t) : "v"(a_perm), "n"(r * 512) : "memory"); acc += t; }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -44,8 +58,15 @@ double run(double* out, int iters) {
 int main() {
     double* out; hipMalloc(&out, 256 * 4 * 256 * 8);
     const int iters = 20000;
-    const char* names[] = {"ds_write_b64 lane-contiguous", "ds_write_b64 permuted", "ds_add_f64 permuted", "ds_read_b64 permuted", "ds_write_b32 permuted"};
-    double t[5] = {run<0>(out, iters), run<1>(out, iters), run<2>(out, iters), run<3>(out, iters), run<4>(out, iters)};
-    for (int i = 0; i < 5; ++i) printf("%-30s %.2f ns per wave-instruction per CU = %.2f cycles at 2.4 GHz\n", names[i], t[i] * 1e9, t[i] * 2.4e9);
+    const char* names[] = {"ds_write_b64 lane-contiguous", "ds_write_b64 permuted", "ds_add_f64 permuted", "ds_read_b64 permuted", "ds_write_b32 permuted",
+                           "ds_write2st64_b64 (2 rows)", "ds_write2_b64 (16 B per lane)", "ds_write_b128 (16 B per lane)", "ds_read2st64_b64 (2 rows)", "ds_read_b128 (16 B per lane)",
+                           "mix: 2 ds_read_b64 + 1 ds_write_b64"};
+    const double per16[] = {16, 16, 16, 16, 16, 8, 8, 8, 8, 8, 12};  // instructions issued per 16 slots
+    double t[11] = {run<0>(out, iters), run<1>(out, iters), run<2>(out, iters), run<3>(out, iters), run<4>(out, iters), run<5>(out, iters),
+                    run<6>(out, iters), run<7>(out, iters), run<8>(out, iters), run<9>(out, iters), run<10>(out, iters)};
+    for (int i = 0; i < 11; ++i) {
+        const double ti = t[i] * 16.0 / per16[i];
+        printf("%-36s %.2f ns per wave-instruction per CU = %.2f cycles at 2.4 GHz\n", names[i], ti * 1e9, ti * 2.4e9);
+    }
     return 0;
 }
