@@ -277,10 +277,13 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
     for (int vbase = chunk * vpw; vbase < v_end; vbase += UNR) {
         T c[UNR][DVMAX];
         T pr[UNR];
+        u64 old[UNR];
         int p0[UNR], deg[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int vv = vbase + u;
+            // decisions of frames that have left, read ahead of the lines (a read behind this variable's marginal store would wait for it)
+            if (lv != ~0ull) old[u] = xb[8 * (vv < v_end ? vv : v_end - 1)];
             if constexpr (FIXED_DV > 0) {
                 p0[u] = (vv < v_end ? vv : v_end - 1) * FIXED_DV;  // past the end: the last variable's lines once more, result unused
                 deg[u] = vv < v_end ? FIXED_DV : -1;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
             const u64 one = __ballot(b_one);
             const int vv = vbase + u;
             u64 merged = one;
-            if (lv != ~0ull) merged = (xb[8 * vv] & ~lv) | (one & lv);
+            if (lv != ~0ull) merged = (old[u] & ~lv) | (one & lv);
             if (lane == 0) xb[8 * vv] = merged;
         }
     }
@@ -799,10 +802,10 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
 // curves.  No frame repack; the soft output is that of the last sweep of the BATCH (frames that have left keep evolving).
 namespace {
 
-__device__ __forceinline__ float2 msg16_ld(const __half2* p) {
-    const uint32_t raw = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p));
-    return __half22float2(*reinterpret_cast<const __half2*>(&raw));
-}
+// the load and the conversion are separate so that a kernel can issue all its line loads before it touches the first result
+__device__ __forceinline__ uint32_t msg16_ld_raw(const __half2* p) { return __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p)); }
+__device__ __forceinline__ float2 msg16_cvt(uint32_t raw) { return __half22float2(*reinterpret_cast<const __half2*>(&raw)); }
+__device__ __forceinline__ float2 msg16_ld(const __half2* p) { return msg16_cvt(msg16_ld_raw(p)); }
 template <int ALG>
 __device__ __forceinline__ float sat16(float v) {
     // finite values beyond the fp16 range saturate (min-sum messages of a trapped frame grow without bound); sum-product keeps its +-inf
@@ -876,10 +879,11 @@ __global__ __launch_bounds__(256) void k_biawgn_tile16(SimSource s, int64_t B, i
 
 // Check pass: per check, GATHER the variable -> check lines of its edges (each line exactly once per sweep: no re-read, unlike the
 // marginal-resident fp32 passes), apply the rule, STREAM the check -> variable lines out.  First sweep: v2c = prior (src/bpa.py:19).
-template <int ALG, int DCMAX, int FIXED_DC, int UNR>
+// FIRST is a template parameter: as a run-time flag the compiler kept a branch per line and waited for every gathered line before issuing the next
+template <int ALG, int DCMAX, int FIXED_DC, int UNR, bool FIRST>
 __global__ __launch_bounds__(256) void k_cn16(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var, const int32_t* __restrict__ edge_vpos,
                                               __half2* __restrict__ c2v, const __half2* __restrict__ v2c, const float2* __restrict__ prior_t,
-                                              const u64* __restrict__ live, int m, int n, int64_t E, int pairs, int tiles, int chunks, int cpw, int first) {
+                                              const u64* __restrict__ live, int m, int n, int64_t E, int pairs, int tiles, int chunks, int cpw) {
     const int lane = threadIdx.x;
     int P, chunk;
     if (!task_of(pairs, chunks, 0, &P, &chunk)) return;
@@ -908,7 +912,9 @@ __global__ __launch_bounds__(256) void k_cn16(const int32_t* __restrict__ row_pt
             for (int j = 0; j < DCMAX; ++j) {
                 // a short row re-reads its last edge (an empty row edge 0): no branch per line
                 const int kk = FIXED_DC > 0 ? k0[u] + j : (deg[u] > 0 ? k0[u] + (j < deg[u] ? j : deg[u] - 1) : 0);
-                const float2 v = first ? pt[(int64_t)edge_var[kk] * 64] : msg16_ld(vt + (int64_t)edge_vpos[kk] * 64);
+                float2 v;
+                if constexpr (FIRST) v = pt[(int64_t)edge_var[kk] * 64];
+                else v = msg16_ld(vt + (int64_t)edge_vpos[kk] * 64);
                 vx[u][j] = v.x;
                 vy[u][j] = v.y;
             }
@@ -946,6 +952,8 @@ __global__ __launch_bounds__(256) void k_vn16(const int32_t* __restrict__ col_pt
     const int v_end = min(n, (chunk + 1) * vpw);
     for (int vbase = chunk * vpw; vbase < v_end; vbase += UNR) {
         float2 c[UNR][DVMAX], pr[UNR];
+        uint32_t raw[UNR][DVMAX];
+        u64 olda[UNR], oldb[UNR];
         int deg[UNR], p0[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -953,12 +961,20 @@ __global__ __launch_bounds__(256) void k_vn16(const int32_t* __restrict__ col_pt
             p0[u] = FIXED_DV > 0 ? vv * FIXED_DV : col_ptr[vv];
             deg[u] = vbase + u < v_end ? (FIXED_DV > 0 ? FIXED_DV : col_ptr[vv + 1] - p0[u]) : -1;
             pr[u] = pt[(int64_t)vv * 64];
+            // decisions of frames that have left, read with the lines (a read behind the stores of this variable would wait for them)
+            if (lva != ~0ull) olda[u] = xa[8 * vv];
+            if (has_b && lvb != ~0ull) oldb[u] = xb[8 * vv];
+            // lines of an irregular variable sit behind a wave-uniform branch each; nothing in the branch but the load (no default value, no
+            // conversion), so that no load waits for the one before it
 #pragma unroll
             for (int j = 0; j < DVMAX; ++j) {
-                c[u][j] = make_float2(0.0f, 0.0f);
-                if (FIXED_DV > 0 || j < deg[u]) c[u][j] = msg16_ld(ct + (int64_t)col_edge[p0[u] + j] * 64);
+                if (FIXED_DV > 0 || j < deg[u]) raw[u][j] = msg16_ld_raw(ct + (int64_t)col_edge[p0[u] + j] * 64);
             }
         }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int j = 0; j < DVMAX; ++j) c[u][j] = (FIXED_DV > 0 || j < deg[u]) ? msg16_cvt(raw[u][j]) : make_float2(0.0f, 0.0f);
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             if (deg[u] < 0) continue;  // wave-uniform
@@ -977,8 +993,8 @@ __global__ __launch_bounds__(256) void k_vn16(const int32_t* __restrict__ col_pt
             const u64 onea = __ballot(marg.x < 0.0f), oneb = __ballot(marg.y < 0.0f);  // NaN marginal -> 0 (src/bpa.py:38,62)
             const int vv = vbase + u;
             u64 ma = onea, mb = oneb;
-            if (lva != ~0ull) ma = (xa[8 * vv] & ~lva) | (onea & lva);  // frames that have left keep their decisions
-            if (has_b && lvb != ~0ull) mb = (xb[8 * vv] & ~lvb) | (oneb & lvb);
+            if (lva != ~0ull) ma = (olda[u] & ~lva) | (onea & lva);  // frames that have left keep their decisions
+            if (has_b && lvb != ~0ull) mb = (oldb[u] & ~lvb) | (oneb & lvb);
             if (lane == 0) {
                 xa[8 * vv] = ma;
                 if (has_b) xb[8 * vv] = mb;
@@ -1086,10 +1102,15 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
             LDPC_TRY(prof_event(d, ev_next++, &e2));
             LDPC_HIP_TRY(hipEventRecord(e0, st));
         }
-        const int first = it == 0 ? 1 : 0;
+        const bool first = it == 0;
         const dim3 cgrid(task_blocks(pairs, cn_chunks, 0)), vgrid(task_blocks(pairs, vn_chunks, 0)), blk(64, 4);
-#define LDPC_CN16(DCM, FDC, UNR) \
-    hipLaunchKernelGGL((k_cn16<ALG, DCM, FDC, UNR>), cgrid, blk, 0, st, c->d_row_ptr, c->d_edge_var, edge_vpos, msg, v2c, prior, live, m, n, E, pairs, tiles, cn_chunks, cpw, first)
+#define LDPC_CN16_LAUNCH(DCM, FDC, UNR, FIRST) \
+    hipLaunchKernelGGL((k_cn16<ALG, DCM, FDC, UNR, FIRST>), cgrid, blk, 0, st, c->d_row_ptr, c->d_edge_var, edge_vpos, msg, v2c, prior, live, m, n, E, pairs, tiles, cn_chunks, cpw)
+#define LDPC_CN16(DCM, FDC, UNR)                       \
+    do {                                               \
+        if (first) LDPC_CN16_LAUNCH(DCM, FDC, UNR, true); \
+        else LDPC_CN16_LAUNCH(DCM, FDC, UNR, false);      \
+    } while (0)
         if (reg36) LDPC_CN16(6, 6, LDPC_CN16_UNR);
         else if (c->max_dc <= 4) LDPC_CN16(4, 0, 2);
         else if (c->max_dc <= 6) LDPC_CN16(6, 0, 2);
@@ -1098,6 +1119,7 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
         else if (c->max_dc <= 32) LDPC_CN16(32, 0, 1);
         else LDPC_CN16(64, 0, 1);
 #undef LDPC_CN16
+#undef LDPC_CN16_LAUNCH
         if (d->profile) LDPC_HIP_TRY(hipEventRecord(e1, st));
 #define LDPC_VN16(DVM, UNR, FDV) \
     hipLaunchKernelGGL((k_vn16<ALG, DVM, UNR, FDV>), vgrid, blk, 0, st, c->d_col_ptr, c->d_col_edge, msg, v2c, prior, marg, live, xbits, n, E, pairs, tiles, vn_chunks, vpw)
