@@ -95,6 +95,13 @@ __host__ inline int task_blocks(int tiles, int chunks, int xcd_aware) {
 }
 
 // index of the bit-plane word of (tile, variable): eight tiles interleaved per variable
+// Wave-uniform 8-byte read through the SCALAR cache (constant address space: the compiler emits s_load_dwordx2, counted by lgkmcnt and
+// therefore independent of the vector loads and stores in flight).  Only for words no wave writes before this wave has read them in the
+// same launch: the decision word of (tile, variable) is read and then written by exactly one wave per sweep.
+__device__ __forceinline__ u64 uniform_ld64(const u64* p) {
+    typedef const __attribute__((address_space(4))) u64* cptr;
+    return *(cptr)(uintptr_t)p;
+}
 __host__ __device__ __forceinline__ int64_t plane_at(int tile, int64_t v, int n) { return ((int64_t)(tile >> 3) * n + v) * 8 + (tile & 7); }
 __host__ inline size_t plane_words(int tiles, int n) { return (size_t)((tiles + 7) / 8) * n * 8; }
 
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
         for (int u = 0; u < UNR; ++u) {
             const int vv = vbase + u;
             // decisions of frames that have left, read ahead of the lines (a read behind this variable's marginal store would wait for it)
-            if (lv != ~0ull) old[u] = xb[8 * (vv < v_end ? vv : v_end - 1)];
+            if (lv != ~0ull) old[u] = uniform_ld64(xb + 8 * (vv < v_end ? vv : v_end - 1));
             if constexpr (FIXED_DV > 0) {
                 p0[u] = (vv < v_end ? vv : v_end - 1) * FIXED_DV;  // past the end: the last variable's lines once more, result unused
                 deg[u] = vv < v_end ? FIXED_DV : -1;
@@ -962,8 +969,8 @@ __global__ __launch_bounds__(256) void k_vn16(const int32_t* __restrict__ col_pt
             deg[u] = vbase + u < v_end ? (FIXED_DV > 0 ? FIXED_DV : col_ptr[vv + 1] - p0[u]) : -1;
             pr[u] = pt[(int64_t)vv * 64];
             // decisions of frames that have left, read with the lines (a read behind the stores of this variable would wait for them)
-            if (lva != ~0ull) olda[u] = xa[8 * vv];
-            if (has_b && lvb != ~0ull) oldb[u] = xb[8 * vv];
+            if (lva != ~0ull) olda[u] = uniform_ld64(xa + 8 * vv);
+            if (has_b && lvb != ~0ull) oldb[u] = uniform_ld64(xb + 8 * vv);
             // lines of an irregular variable sit behind a wave-uniform branch each; nothing in the branch but the load (no default value, no
             // conversion), so that no load waits for the one before it
 #pragma unroll
