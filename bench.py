@@ -223,7 +223,17 @@ def fused_roofline(kernel_name, frame_sweeps_per_s, cus, counters=None):
     bound = "lds" if lds >= valu else "valu"
     peak = NOMINAL_CLOCK_HZ * cus * 256 / 1e9  # the LDS array is 64 banks x 4 B wide per clock and CU
     useful = frame_sweeps_per_s * (e["lds_idx_active_per_frame_sweep"] - e["bank_conflict_per_frame_sweep"]) / (cus * NOMINAL_CLOCK_HZ)
-    return dict(bound=bound, frac=round(max(lds, valu), 4), lds_frac=round(lds, 4), lds_frac_without_bank_conflicts=round(useful, 4), valu_frac=round(valu, 4),
+    # the unit of the LDS pipeline that binds an 8-byte-element kernel is the store (issue / transfer) path, not the array the counter above
+    # sees: measured load / store instruction counts x per-instruction cycles -- the hardware guide's (2 / 6) and the ones measured on this
+    # chip (2.55 / 6.3, additive in a mixed stream: profiles/r04_lds_store_path.txt)
+    path = {}
+    for key, name in (("lds_path_cycles_per_frame_sweep", "lds_store_path_frac_guide_constants"),
+                      ("lds_path_cycles_per_frame_sweep_measured_constants", "lds_store_path_frac_measured_constants")):
+        if e.get(key):
+            path[name] = round(frame_sweeps_per_s * e[key] / (cus * NOMINAL_CLOCK_HZ), 4)
+    if path:
+        path["binding_unit"] = max((("lds_array", lds), ("valu", valu), ("lds_store_path", max(path.values()))), key=lambda t: t[1])[0]
+    return dict(bound=bound, frac=round(max(lds, valu), 4), lds_frac=round(lds, 4), lds_frac_without_bank_conflicts=round(useful, 4), valu_frac=round(valu, 4), **path,
                 achieved=round(lds * peak, 1) if bound == "lds" else round(valu * 100, 2), peak=round(peak, 1) if bound == "lds" else 100.0,
                 unit="GB/s" if bound == "lds" else "% of VALU issue cycles",
                 lds_cycles_per_frame_sweep=e["lds_idx_active_per_frame_sweep"], bank_conflict_cycles_per_frame_sweep=e["bank_conflict_per_frame_sweep"],

@@ -27,6 +27,7 @@ echo "VALU mix counters:$SQ3"
 CASES=(
  "c2_f64|--code 1200_3_6_rand_ldpc_1 --alg MSA --channel biawgn --param 1.0 --batch 65536 --precision f64 --launches 3|sq hbm"
  "c2_f32|--code 1200_3_6_rand_ldpc_1 --alg MSA --channel biawgn --param 1.0 --batch 65536 --precision f32 --launches 3|sq hbm"
+ "c2_f32_grid|--code 1200_3_6_rand_ldpc_1 --alg MSA --channel biawgn --param 1.0 --batch 65536 --precision f32 --prior-grid 8 --launches 3|sq hbm"
  "c3_spa_bsc_f32|--code 1200_3_6_rand_ldpc_1 --alg SPA --channel bsc --param 0.07 --batch 65536 --precision f32 --launches 3|sq hbm"
  "c3_bec|--code 1200_3_6_rand_ldpc_1 --alg BEC --channel bec --param 0.40 --batch 1048576 --precision f32 --launches 3|sq hbm"
  "c3_spa_biawgn_f64|--code 1200_3_6_rand_ldpc_1 --alg SPA --channel biawgn --param 1.5 --batch 65536 --precision f64 --launches 2|sq hbm"

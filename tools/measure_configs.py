@@ -26,6 +26,8 @@ CASES = [  # config, code, decoder alg, channel, param, batch, steps, backend[, 
     ("2: n=1200 (3,6) MSA BI-AWGN, fp64 (the reference's arithmetic, bit-identical decisions)", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 2.0, 65536, 6, "auto", "f64"),
     ("2: n=1200 (3,6) MSA BI-AWGN, fp32 mode", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 1.0, 65536, 6, "auto"),
     ("2: n=1200 (3,6) MSA BI-AWGN, fp32 mode", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 2.0, 65536, 6, "auto"),
+    ("2: same, exact-in-fp32 mode (priors on the 2^-8 grid, in-kernel guard, frames beyond it re-decoded in fp64: an fp64 run's counters)", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 1.0, 65536, 6, "auto", "f32", 8),
+    ("2: same, exact-in-fp32 mode (priors on the 2^-8 grid, in-kernel guard, frames beyond it re-decoded in fp64: an fp64 run's counters)", "1200_3_6_rand_ldpc_1", "MSA", "biawgn", 2.0, 65536, 6, "auto", "f32", 8),
     ("3: n=1200 (3,6) SPA BSC", "1200_3_6_rand_ldpc_1", "SPA", "bsc", 0.07, 65536, 6, "auto"),
     ("3: n=1200 (3,6) SPA BSC", "1200_3_6_rand_ldpc_1", "SPA", "bsc", 0.05, 65536, 6, "auto"),
     ("3: n=1200 (3,6) SPA BI-AWGN, fp64 (the reference's formula verbatim, LDS kernel)", "1200_3_6_rand_ldpc_1", "SPA", "biawgn", 1.5, 65536, 3, "auto", "f64"),
@@ -38,6 +40,8 @@ CASES = [  # config, code, decoder alg, channel, param, batch, steps, backend[, 
     ("5: (3,6) n=64800 erasure decoder (bit-sliced streaming)", "gen:reg:64800:3:6", "BEC", "bec", 0.40, 32768, 2, "auto"),
     ("4: rate-1/2 irregular n=10000 MSA (2^20 frames over 8 GPUs = 131072 per GPU)", "gen:irg:10000", "MSA", "biawgn", 1.2, 131072, 2, "auto"),
     ("4: rate-1/2 irregular n=10000 MSA (2^20 frames over 8 GPUs = 131072 per GPU)", "gen:irg:10000", "MSA", "biawgn", 1.8, 131072, 2, "auto"),
+    ("4: same, exact-in-fp32 mode (2^-8 grid + guard + fp64 redo): the fp64 reference's counters from the LDS kernel", "gen:irg:10000", "MSA", "biawgn", 1.2, 131072, 2, "auto", "f32", 8),
+    ("4: same, exact-in-fp32 mode (2^-8 grid + guard + fp64 redo): the fp64 reference's counters from the LDS kernel", "gen:irg:10000", "MSA", "biawgn", 1.8, 131072, 2, "auto", "f32", 8),
     ("4: same, streaming kernels", "gen:irg:10000", "MSA", "biawgn", 1.2, 32768, 1, "stream"),
     ("4: same, streaming kernels (frames leave after 11..50 sweeps: per-frame early termination by frame repack)", "gen:irg:10000", "MSA", "biawgn", 1.8, 32768, 1, "stream"),
     ("4: same, fp64 (the reference's arithmetic; 327 KB per frame: streaming kernels)", "gen:irg:10000", "MSA", "biawgn", 1.8, 32768, 1, "auto", "f64"),
@@ -52,18 +56,27 @@ cache = {}
 for case in CASES:
     cfg, code_name, alg, ch, prm, B, steps, backend = case[:8]
     prec = case[8] if len(case) > 8 else "f32"
+    grid = case[9] if len(case) > 9 else None
+    redone = 0
     if code_name not in cache:
         cache[code_name] = load_code(code_name)
     code = cache[code_name]
     g = code
     h = DecoderHandle(code, alg, prec, backend)
     cnt = torch.zeros(4 + 51, dtype=torch.int64, device="cuda")
-    h.simulate(ch, prm, 0, 0x5EED1200, 0, 0, B, 50, cnt, hist_bins=51)  # warm-up at full size: workspaces are allocated here
+    def run(stream_id, frame0):
+        global redone
+        if grid is None:
+            h.simulate(ch, prm, 0, 0x5EED1200, stream_id, frame0, B, 50, cnt, hist_bins=51)
+        else:
+            redone += h.simulate_exact_fp32(prm, 0, 0x5EED1200, stream_id, frame0, B, 50, cnt, grid, hist_bins=51)
+    run(0, 0)  # warm-up at full size: workspaces are allocated here
     torch.cuda.synchronize()
     cnt.zero_()
     t0 = time.perf_counter()
+    redone = 0
     for s in range(steps):
-        h.simulate(ch, prm, 0, 0x5EED1200, 1, s * B, B, 50, cnt, hist_bins=51)
+        run(1, s * B)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c = cnt.cpu().numpy()
@@ -80,6 +93,8 @@ for case in CASES:
     backend_used = h.last_stats()[0]
     if backend_used == "fused":
         kname = h.kernel_name(True)
+        if grid is not None:
+            kname = kname.replace("k_fused_bp<0, ", "k_fused_bp_grid<")
         roof = fused_roofline(kname, sweeps / dt, CUS, COUNTERS) or dict(bound="lds", frac=None, note="no committed counters for " + kname)
         roof = {k: roof.get(k) for k in ("bound", "frac", "lds_frac", "valu_frac", "lds_cycles_per_frame_sweep", "valu_busy_cycles_per_frame_sweep",
                                         "counters_workload", "counters_from", "note") if roof.get(k) is not None}
@@ -95,7 +110,7 @@ for case in CASES:
                      backend=h.last_stats()[0], repacks=h.last_repacks(), waves_per_frame=h.fused_info()["waves_per_frame"] if h.last_stats()[0] == "fused" else 0,
                      frames_per_s=round(frames / dt, 1), ms_per_step=round(1e3 * dt / steps, 3), mean_sweeps=round(sweeps / frames, 3),
                      wer=round(int(c[1]) / frames, 6), ber=int(c[2]) / (frames * g.n),
-                     algorithmic_GBps=round(sweeps * bytes_fs / dt / 1e9, 1)))
+                     algorithmic_GBps=round(sweeps * bytes_fs / dt / 1e9, 1), **(dict(prior_grid="2^-%d" % grid, frames_redone_in_fp64=redone) if grid is not None else {})))
     print(json.dumps(rows[-1]), flush=True)
     del h
 with open(os.path.join(ROOT, "profiles", "%s_all_configs.json" % tag), "w") as fp:

@@ -140,6 +140,10 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
                       ("k_fused_bp 16-wave", 2.0, 3.0, "ds_read_b32 2, ds_write2st64_b32 6 per two rows / addtid 2") if ", 16, " in k else \
                       ("k_fused_bp", 2.0, 2.0, "ds_read_b32 2, ds_write_addtid_b32 2")
                 path = ld * fam[1] + st_ * fam[2] + at * 8.0
+                # the same split with the constants MEASURED on this chip for 8-byte elements (profiles/r04_lds_store_path.txt: ds_read_b64 2.55,
+                # ds_write_b64 6.3 cycles per wave-instruction per CU, ds_add_f64 8.07; a 2-load + 1-store mix runs at their sum: the path is additive)
+                if fam[0] in ("k_fused_f64", "k_fused_becs"):
+                    e["lds_path_cycles_per_frame_sweep_measured_constants"] = round(ld * 2.55 + st_ * 6.3 + at * 8.07, 1)
                 e.update(lds_loads_per_frame_sweep=round(ld, 2), lds_stores_per_frame_sweep=round(st_, 2), lds_atomics_per_frame_sweep=round(at, 2),
                          lds_path_cycles_per_frame_sweep=round(path, 1), lds_path_model=fam[3],
                          lds_data_fifo_full_per_frame_sweep=round(t4.get("SQ_LDS_DATA_FIFO_FULL", 0.0), 2),
@@ -166,12 +170,18 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
                 arr, pth, val = e["lds_frac_at_peak_clock_unprofiled"], round(fsps * e["lds_path_cycles_per_frame_sweep"] / (cus * PEAK_CLOCK), 4), e["valu_frac_at_peak_clock_unprofiled"]
                 e["lds_path_frac_at_peak_clock_unprofiled"] = pth
                 e["binding_unit"] = max((("lds_array", arr), ("lds_store_path", pth), ("valu", val)), key=lambda t: t[1])[0]
+                if "lds_path_cycles_per_frame_sweep_measured_constants" in e:
+                    e["lds_path_frac_measured_constants"] = round(fsps * e["lds_path_cycles_per_frame_sweep_measured_constants"] / (cus * PEAK_CLOCK), 4)
                 md.append("LDS split: %.1f loads + %.1f stores + %.1f atomics per frame-sweep -> issue / transfer path %.1f cycles (%s) = **%.3f** of "
                           "peak; array %.3f, VALU %.3f => binding unit: **%s**.  Queue counters per frame-sweep: data FIFO full %.2f, command FIFO "
                           "full %.2f, address conflicts %.2f, SQ_WAIT_INST_LDS %.2f quad-cycles." % (
                               e["lds_loads_per_frame_sweep"], e["lds_stores_per_frame_sweep"], e["lds_atomics_per_frame_sweep"], e["lds_path_cycles_per_frame_sweep"],
                               e["lds_path_model"], pth, arr, val, e["binding_unit"], e["lds_data_fifo_full_per_frame_sweep"],
                               e["lds_cmd_fifo_full_per_frame_sweep"], e["lds_addr_conflict_per_frame_sweep"], e["wait_inst_lds_quad_cycles_per_frame_sweep"]))
+                if "lds_path_frac_measured_constants" in e:
+                    md.append("With the per-instruction cycles MEASURED on this chip (profiles/r04_lds_store_path.txt: ds_read_b64 2.55, ds_write_b64 6.3, additive "
+                              "in a mixed stream) the same split is %.1f cycles per frame-sweep = **%.3f** of the path's capacity." % (
+                                  e["lds_path_cycles_per_frame_sweep_measured_constants"], e["lds_path_frac_measured_constants"]))
             if "wait_any_share" in e:
                 md.append("Wave time: %.0f %% waiting (s_waitcnt / barrier), %.0f %% issue stalls, %.0f %% issuing." % (
                     100 * (e["wait_any_share"] or 0), 100 * (e["wait_inst_any_share"] or 0), 100 * (e["active_inst_any_share"] or 0)))
