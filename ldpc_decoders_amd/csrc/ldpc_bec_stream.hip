@@ -38,47 +38,64 @@ __device__ __forceinline__ void st2_nt(uint2* p, uint32_t k, uint32_t v) {
     __builtin_nontemporal_store(((u64)v << 32) | k, reinterpret_cast<u64*>(p));
 }
 
-// received symbols [B, n] bytes {0, 1, 2 = erased} -> prior / xhat planes; one thread per variable (coalesced along v), the 2048
-// frames of the supertile in turn.  Frames beyond the batch are a known 0 (never erased: they leave before the first sweep).
+// received symbols [B, n] bytes {0, 1, 2 = erased} -> prior / xhat planes.  One workgroup = (supertile, 64 variables): lane l of every wave
+// follows variable v0 + l through the frames (each load instruction reads the 64 consecutive bytes of one frame), builds the plane word
+// of 32 frames in registers and parks it in an LDS tile [variable][lane word]; the tile then leaves as 512-byte lines.  (The first
+// version had one thread per variable write its 8-byte elements 512 B apart: 4.2 GB of write traffic for 1.1 GB of planes at n = 64 800.)
+// Frames beyond the batch are a known 0 (never erased: they leave before the first sweep).
 __global__ __launch_bounds__(256) void k_becs_load(const uint8_t* __restrict__ y, int64_t B, int n, uint2* __restrict__ prior,
                                                    uint2* __restrict__ xhat, uint32_t* __restrict__ live, uint32_t* __restrict__ flags) {
-    const int T = blockIdx.y;
-    const int v = blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint2 tile[64][65];
+    const int T = blockIdx.y, v0 = blockIdx.x * 64;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t f0 = (int64_t)T * SUPER;
-    if (v < n) {
-        for (int lane = 0; lane < 64; ++lane) {
-            uint32_t kk = ~0u, vv = 0u;
-            const int64_t fl = f0 + (int64_t)lane * 32;
-            if (fl < B) {
-                kk = 0u;
-                const int nb = (int)((B - fl) < 32 ? (B - fl) : 32);
-                for (int b = 0; b < nb; ++b) {
-                    const uint32_t s = y[(fl + b) * n + v];
-                    kk |= (s != 2u ? 1u : 0u) << b;
-                    vv |= (s == 1u ? 1u : 0u) << b;
+    const bool has_v = v0 + l < n;
+    for (int L = w; L < 64; L += 4) {  // lane word L of the supertile: frames f0 + 32 L ... + 31
+        uint32_t kk = ~0u, vv = 0u;
+        const int64_t fl = f0 + (int64_t)L * 32;
+        if (fl < B) {
+            kk = 0u;
+            const int nb = (int)((B - fl) < 32 ? (B - fl) : 32);
+            if (has_v) {
+                const uint8_t* yp = y + fl * n + v0 + l;
+                if (nb == 32) {
+#pragma unroll 8
+                    for (int b = 0; b < 32; ++b) {
+                        const uint32_t sy = yp[(int64_t)b * n];
+                        kk |= (sy != 2u ? 1u : 0u) << b;
+                        vv |= (sy == 1u ? 1u : 0u) << b;
+                    }
+                } else {
+                    for (int b = 0; b < nb; ++b) {
+                        const uint32_t sy = yp[(int64_t)b * n];
+                        kk |= (sy != 2u ? 1u : 0u) << b;
+                        vv |= (sy == 1u ? 1u : 0u) << b;
+                    }
                 }
-                if (nb < 32) kk |= ~0u << nb;
+            } else {
+                kk = ~0u;
             }
-            const size_t at = ((size_t)T * n + v) * 64 + lane;
-            prior[at] = make_uint2(kk, vv);
-            xhat[at] = make_uint2(~kk, vv);  // x_hat starts as the received word (src/bec.py:89): {erased, value}
-            if (~kk) atomicOr(&flags[((size_t)T * 2 + 1) * 64 + lane], ~kk);  // frames that hold an erasure
+            if (nb < 32) kk |= ~0u << nb;
         }
+        tile[l][L] = make_uint2(kk, vv);
+        uint32_t era = has_v ? ~kk : 0u;  // frames of this lane word that hold an erasure among these 64 variables
+#pragma unroll
+        for (int o = 32; o; o >>= 1) era |= __shfl_xor(era, o);
+        if (l == 0 && era) atomicOr(&flags[((size_t)T * 2 + 1) * 64 + L], era);
+    }
+    __syncthreads();
+    for (int i = w; i < 64; i += 4) {
+        if (v0 + i >= n) break;
+        const uint2 e = tile[i][l];
+        const size_t at = ((size_t)T * n + v0 + i) * 64 + l;
+        prior[at] = e;
+        xhat[at] = make_uint2(~e.x, e.y);  // x_hat starts as the received word (src/bec.py:89): {erased, value}
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         const int64_t fl = f0 + (int64_t)threadIdx.x * 32;
         const int64_t rem = B - fl;
         live[(size_t)T * 64 + threadIdx.x] = rem >= 32 ? ~0u : (rem <= 0 ? 0u : ((1u << rem) - 1u));
     }
-}
-
-// v2c = prior on every edge (src/bec.py:86): line p of the variable-major order belongs to variable var_of_pos[p]
-__global__ __launch_bounds__(256) void k_becs_init(const int32_t* __restrict__ var_of_pos, const uint2* __restrict__ prior, uint2* __restrict__ v2c,
-                                                   int n, int64_t E) {
-    const int T = blockIdx.y, lane = threadIdx.x & 63;
-    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= E) return;
-    v2c[((size_t)T * E + p) * 64 + lane] = prior[((size_t)T * n + var_of_pos[p]) * 64 + lane];
 }
 
 // Frames leave (src/bec.py:96-97,120): before the first sweep those without an erasure, afterwards those whose last sweep changed
@@ -117,9 +134,11 @@ __global__ __launch_bounds__(64) void k_becs_finish(const uint32_t* __restrict__
 // ---------------------------------------------------------------------------------------------------------------------
 // Check pass: one wave = (supertile, run of checks).  A check reads the v2c line of each of its edges (each line exactly once in a
 // sweep: non-temporal) and writes ONE summary line.
+// The first sweep reads v2c = prior (src/bec.py:86) straight from the prior lines of the edges' variables (the caller passes the prior
+// planes, n lines per supertile, and the edge -> variable table): no initialisation pass over the E message lines.
 __global__ __launch_bounds__(256) void k_becs_cn(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_vpos,
                                                  const uint2* __restrict__ v2c, uint2* __restrict__ sum, const uint32_t* __restrict__ live,
-                                                 int m, int64_t E, int tiles, int chunks, int cpw) {
+                                                 int m, int64_t E, int tiles, int chunks, int cpw) {  // E: lines per supertile of `v2c`
     const int lane = threadIdx.x & 63;
     const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int T = __builtin_amdgcn_readfirstlane(task / chunks), chunk = __builtin_amdgcn_readfirstlane(task - (task / chunks) * chunks);
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(256) void k_becs_cn(const int32_t* __restrict__ row
 // Variable pass: one wave = (supertile, run of variables).  Per variable: gather the summaries of its checks, stream its own last
 // messages in and the new ones out (variable-major lines: contiguous), update the decisions of the live frames.
 // DVMAX <= 16: the messages of a variable stay in registers between the counting pass and the output pass.
-template <int DVMAX>
+template <int DVMAX, bool FIRST>
 __global__ __launch_bounds__(256) void k_becs_vn(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ chk_of_pos,
                                                  const uint2* __restrict__ sum, uint2* __restrict__ v2c, const uint2* __restrict__ prior,
                                                  uint2* __restrict__ xhat, const uint32_t* __restrict__ live, uint32_t* __restrict__ flags,
@@ -180,7 +199,8 @@ __global__ __launch_bounds__(256) void k_becs_vn(const int32_t* __restrict__ col
         for (int j = 0; j < DVMAX; ++j) {
             if (j < deg) {
                 s[j] = ld2(st + (size_t)chk_of_pos[p0 + j] * 64);
-                o[j] = ld2_nt(vt + (size_t)(p0 + j) * 64);
+                if constexpr (FIRST) o[j] = pr;  // the message of sweep 0 is the prior (src/bec.py:86)
+                else o[j] = ld2_nt(vt + (size_t)(p0 + j) * 64);
             } else {
                 s[j] = P2{0u, 0u};  // a missing edge: "no message"
                 o[j] = P2{0u, 0u};
@@ -216,16 +236,23 @@ __global__ __launch_bounds__(256) void k_becs_vn(const int32_t* __restrict__ col
 
 // decisions -> [B, n] bytes {0, 1, 2 = still erased}; one thread per variable (coalesced along v)
 __global__ __launch_bounds__(256) void k_becs_unpack(const uint2* __restrict__ xhat, uint8_t* __restrict__ out, int64_t B, int n) {
-    const int T = blockIdx.y;
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= n) return;
+    // the reverse of k_becs_load: 512-byte lines in, an LDS tile [variable][lane word], then lane l writes variable v0 + l frame after
+    // frame (64 consecutive bytes per store instruction)
+    __shared__ uint2 tile[64][65];
+    const int T = blockIdx.y, v0 = blockIdx.x * 64;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t f0 = (int64_t)T * SUPER;
-    for (int lane = 0; lane < 64; ++lane) {
-        const int64_t fl = f0 + (int64_t)lane * 32;
+    for (int i = w; i < 64; i += 4)
+        if (v0 + i < n) tile[i][l] = xhat[((size_t)T * n + v0 + i) * 64 + l];
+    __syncthreads();
+    if (v0 + l >= n) return;
+    for (int L = w; L < 64; L += 4) {
+        const int64_t fl = f0 + (int64_t)L * 32;
         if (fl >= B) break;
-        const uint2 w = xhat[((size_t)T * n + v) * 64 + lane];
+        const uint2 e = tile[l][L];
         const int nb = (int)((B - fl) < 32 ? (B - fl) : 32);
-        for (int b = 0; b < nb; ++b) out[(fl + b) * n + v] = ((w.x >> b) & 1u) ? (uint8_t)2 : (uint8_t)((w.y >> b) & 1u);
+        uint8_t* op = out + fl * n + v0 + l;
+        for (int b = 0; b < nb; ++b) op[(int64_t)b * n] = ((e.x >> b) & 1u) ? (uint8_t)2 : (uint8_t)((e.y >> b) & 1u);
     }
 }
 
@@ -250,21 +277,19 @@ int becs_stream_decode(Decoder* d, const uint8_t* y0, int64_t B, int32_t max_ite
     }
     const bool early = !(flags_in & FLAG_NO_EARLY_EXIT);
     const int tiles = (int)((B + SUPER - 1) / SUPER);
-    // graph in variable-major order, once per decoder: edge_vpos[k] = position of row-major edge k in the CSC list, chk_of_pos / var_of_pos
+    // graph in variable-major order, once per decoder: edge_vpos[k] = position of row-major edge k in the CSC list, chk_of_pos
     if (!d->scratch.p) {
-        std::vector<int32_t> idx((size_t)3 * E);
+        std::vector<int32_t> idx((size_t)2 * E);
         for (int v = 0; v < n; ++v)
             for (int p = c->col_ptr[v]; p < c->col_ptr[v + 1]; ++p) {
                 const int k = c->col_edge[p];
                 idx[(size_t)k] = p;                        // edge_vpos
                 idx[(size_t)E + p] = c->edge_chk[k];       // chk_of_pos
-                idx[(size_t)2 * E + p] = v;                // var_of_pos
             }
         LDPC_TRY(upload_i32(idx, &d->scratch));
     }
     const int32_t* edge_vpos = (const int32_t*)d->scratch.p;
     const int32_t* chk_of_pos = edge_vpos + E;
-    const int32_t* var_of_pos = edge_vpos + 2 * E;
     LDPC_TRY(d->msg.reserve((size_t)tiles * E * 64 * 8));
     LDPC_TRY(d->marg.reserve((size_t)tiles * m * 64 * 8));
     LDPC_TRY(d->prior.reserve((size_t)tiles * n * 64 * 8));
@@ -282,8 +307,7 @@ int becs_stream_decode(Decoder* d, const uint8_t* y0, int64_t B, int32_t max_ite
 
     LDPC_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)tiles * 2 * 64 * 4 + 64, st));
     LDPC_HIP_TRY(hipMemsetAsync(iters, 0, (size_t)B * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_becs_load, dim3((n + 255) / 256, tiles), dim3(256), 0, st, y0, B, n, prior, xh, live, tflags);
-    hipLaunchKernelGGL(k_becs_init, dim3((unsigned)((E + 3) / 4), tiles), dim3(256), 0, st, var_of_pos, prior, v2c, n, E);
+    hipLaunchKernelGGL(k_becs_load, dim3((n + 63) / 64, tiles), dim3(256), 0, st, y0, B, n, prior, xh, live, tflags);
 
     const int cpw = 4, vpw = 8;  // nodes per wave task: short runs keep a supertile's summary lines on chip between the two passes
     const int cn_chunks = (m + cpw - 1) / cpw, vn_chunks = (n + vpw - 1) / vpw;
@@ -305,11 +329,17 @@ int becs_stream_decode(Decoder* d, const uint8_t* y0, int64_t B, int32_t max_ite
                 }
             }
         }
-        hipLaunchKernelGGL(k_becs_cn, dim3((unsigned)(((int64_t)tiles * cn_chunks + 3) / 4)), dim3(256), 0, st, c->d_row_ptr, edge_vpos, v2c, sum, live,
-                           m, E, tiles, cn_chunks, cpw);
+        const bool first = it == 0;
+        hipLaunchKernelGGL(k_becs_cn, dim3((unsigned)(((int64_t)tiles * cn_chunks + 3) / 4)), dim3(256), 0, st, c->d_row_ptr,
+                           first ? c->d_edge_var : edge_vpos, first ? prior : v2c, sum, live, m, first ? (int64_t)n : E, tiles, cn_chunks, cpw);
         const dim3 vgrid((unsigned)(((int64_t)tiles * vn_chunks + 3) / 4));
-#define LDPC_BECS_VN(DVM) \
-    hipLaunchKernelGGL((k_becs_vn<DVM>), vgrid, dim3(256), 0, st, c->d_col_ptr, chk_of_pos, sum, v2c, prior, xh, live, tflags, n, m, E, tiles, vn_chunks, vpw)
+#define LDPC_BECS_VN1(DVM, FIRST) \
+    hipLaunchKernelGGL((k_becs_vn<DVM, FIRST>), vgrid, dim3(256), 0, st, c->d_col_ptr, chk_of_pos, sum, v2c, prior, xh, live, tflags, n, m, E, tiles, vn_chunks, vpw)
+#define LDPC_BECS_VN(DVM)                   \
+    do {                                    \
+        if (first) LDPC_BECS_VN1(DVM, true); \
+        else LDPC_BECS_VN1(DVM, false);      \
+    } while (0)
         if (c->max_dv <= 3) LDPC_BECS_VN(3);
         else if (c->max_dv <= 4) LDPC_BECS_VN(4);
         else if (c->max_dv <= 8) LDPC_BECS_VN(8);
@@ -317,10 +347,11 @@ int becs_stream_decode(Decoder* d, const uint8_t* y0, int64_t B, int32_t max_ite
         else if (c->max_dv <= 32) LDPC_BECS_VN(32);
         else LDPC_BECS_VN(64);
 #undef LDPC_BECS_VN
+#undef LDPC_BECS_VN1
         ++sweeps;
     }
     hipLaunchKernelGGL(k_becs_finish, dim3(tiles), dim3(64), 0, st, live, iters, B, sweeps);
-    hipLaunchKernelGGL(k_becs_unpack, dim3((n + 255) / 256, tiles), dim3(256), 0, st, xh, xhat, B, n);
+    hipLaunchKernelGGL(k_becs_unpack, dim3((n + 63) / 64, tiles), dim3(256), 0, st, xh, xhat, B, n);
     LDPC_HIP_TRY(hipGetLastError());
     d->last_repacks = 0;
     d->last_sweeps = sweeps;

@@ -1,7 +1,7 @@
 """fp16 STORAGE mode of the streaming kernels (LDPC_DTYPE_F16; SURVEY 8(b) dtype list, 8(d) 31 200 B row): check messages kept as fp16,
 arithmetic and marginals fp32.  A throughput mode held to a STATED TOLERANCE, never the parity mode:
 
-  * per sweep, against the fp32 streaming kernels on identical priors (no early exit, sweeps 1..3): every marginal within
+  * per sweep, against the fp32 streaming kernels AND against the oracle on identical priors (no early exit, sweeps 1..3): every marginal within
     TOL * (1 + |fp32 marginal|), TOL = 1e-2 (measured maxima 2e-3 .. 5e-3) -- each stored message is rounded to 11 significant bits (relative 2^-11 = 4.9e-4), a
     marginal sums up to dv of them, and three sweeps compound it;
   * decisions of the first sweep identical wherever the fp32 marginal is not within the tolerance of zero;
@@ -50,6 +50,32 @@ def test_per_sweep_operator_tolerance_against_the_fp32_kernels(alg, name, B):
         if sweeps == 1:
             clear = np.abs(m32) > TOL * (1 + np.abs(m32))
             assert ((x16.cpu().numpy() == x32.cpu().numpy()) | ~clear).all()
+
+
+@pytest.mark.parametrize("alg", ["MSA", "SPA"])
+def test_per_sweep_operator_tolerance_against_the_oracle(alg):
+    # the same bound against the ORACLE (oracle/bp_oracle.py, fp64, the reference's own formulas: src/bpa.py:31-38): marginals of the frames
+    # still running after sweeps 1..3, on the fp32 priors the device is given
+    import torch
+    from ldpc_decoders_amd import _lib
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    g, code = _code()
+    B = 96
+    rng = np.random.RandomState(23)
+    y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(2.0)), (B, g.n))
+    pri32 = O.biawgn_priors(y, 2.0).astype(np.float32)
+    _, _, trace = O.bp_decode(g, alg, (pri32 < 0).astype(np.float64), pri32.astype(np.float64), 3, return_trace=True)
+    h16 = DecoderHandle(code, alg, "f16")
+    pri = torch.from_numpy(pri32).cuda()
+    for sweeps in (1, 2, 3):
+        _, _, m16 = h16.decode_soft_device(pri, None, sweeps, flags=_lib.FLAG_NO_EARLY_EXIT)
+        m16, ref = m16.cpu().numpy().astype(np.float64), trace[sweeps - 1]
+        running = ~np.isnan(ref).all(axis=1)          # frames the oracle was still decoding in this sweep
+        ok = np.isfinite(ref) & running[:, None]
+        err = np.abs(m16 - ref)[ok] / (1 + np.abs(ref[ok]))
+        print("%s, %d sweep(s): max |marg16 - oracle| / (1 + |oracle|) = %.2e over %d marginals of %d frames" % (alg, sweeps, err.max(), err.size, running.sum()))
+        assert running.sum() >= B // 2 and err.max() <= TOL
 
 
 @pytest.mark.parametrize("alg,max_iter,cw,snr", [("MSA", 10, 1, "2.0"), ("MSA", 10, 1, "2.25"), ("SPA", 10, 0, "2.0")])

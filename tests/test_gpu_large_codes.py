@@ -108,13 +108,6 @@ def test_config5_regular_n64800_msa_early_termination():
     assert done.any() and code.syndrome(xhat[done]).sum() == 0
 
 
-def _phi_chunk(task):
-    name, y, pri, max_iter = task
-    from helpers import golden_edges
-
-    return O.bp_decode(golden_edges(name), "SPA_PHI", y, pri, max_iter)
-
-
 def _published_point(channel, code_name, decoder, max_iter, codeword, param):
     """One point of a result file the reference publishes (data/output/*.json, kept as tests/golden/published_curves.json)."""
     import json
@@ -128,13 +121,14 @@ def _published_point(channel, code_name, decoder, max_iter, codeword, param):
     raise KeyError((channel, code_name, decoder, max_iter, codeword, param))
 
 
-def test_config3_spa_bsc_full_batch():
+def test_config3_spa_bsc_full_batch(tmp_path):
     # config 3: n = 1200 sum-product over the BSC, batch 65 536 on one GPU (device channel kernel, fp32 LDS kernel).
     # (1) size-independent properties on the whole batch; (2) ALL 65 536 frames re-decoded by the fp64 phi-domain oracle: identical decisions
     # (measured: all but a few non-converging frames, which are named below); (3) the reference's own arithmetic (fp64, formula
     # verbatim) at the reference's published operating point -- bsc-1200_3_6_rand_ldpc_1-SPA-10-0.json, p = 0.06, 581 frames upstream --
     # word-error rate within 4 sigma of the published value, bit-error rate within its spread.
-    import multiprocessing as mp
+    import subprocess
+    import sys
 
     import torch
     from helpers import golden_edges
@@ -152,10 +146,13 @@ def test_config3_spa_bsc_full_batch():
     assert done.mean() > 0.9 and code.syndrome(xh[done]).sum() == 0     # every frame that left early carries a codeword
     idx = np.arange(B)                                                   # EVERY frame of the batch (round 3 re-decoded 4 096 of them)
     yh, ph = y[idx].cpu().numpy().astype(float), pri[idx].double().cpu().numpy()
-    with mp.get_context("fork").Pool(min(os.cpu_count() or 16, 128)) as pool:
-        parts = pool.map(_phi_chunk, [("1200_3_6_rand_ldpc_1", yh[i:i + 256], ph[i:i + 256], 50) for i in range(0, len(idx), 256)])
-    xo = np.concatenate([p[0] for p in parts])
-    io = np.concatenate([p[1] for p in parts])
+    # the oracle runs in a fresh process (tests/phi_redecode.py forks its worker pool there, not under this process's GPU runtime)
+    src, dst = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(src, y=yh, pri=ph)
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "phi_redecode.py"), src, dst, "1200_3_6_rand_ldpc_1", "50",
+                    str(min(os.cpu_count() or 16, 128))], check=True, timeout=900)
+    res = np.load(dst)
+    xo, io = res["x"], res["it"]
     differ = np.flatnonzero(~(xh[idx] == xo).all(axis=1))
     print("config 3 sum-product / BSC: %d of %d re-decoded frames differ from the fp64 phi oracle: %s" % (len(differ), len(idx), idx[differ].tolist()))
     assert set(idx[differ].tolist()) <= CONFIG3_SPA_FRAMES_THAT_MAY_DIFFER
