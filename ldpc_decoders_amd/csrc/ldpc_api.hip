@@ -600,6 +600,14 @@ int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uin
         const int64_t cap = B < step ? B : step;
         // BI-AWGN on the streaming kernels: the noise is generated straight into the tile layout (no [B,n] prior array, no transposing load)
         const bool tiled_noise = channel == CH_BIAWGN && d->alg != ALG_BEC && pick_backend(d) == BK_STREAM && grid_k < 0;
+        // erasure decoder on the streaming kernels: received word drawn into the bit planes, decisions counted from them (no [B,n] bytes at all)
+        if (d->alg == ALG_BEC && pick_backend(d) == BK_STREAM) {
+            for (int64_t b0 = 0; b0 < B; b0 += step) {
+                const int64_t nb = (B - b0) < step ? (B - b0) : step;
+                LDPC_TRY(becs_stream_simulate(d, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, max_iter, flags, hist_bins, counters, st));
+            }
+            return LDPC_OK;
+        }
         if (channel != CH_BEC && !tiled_noise) LDPC_TRY(d->h_in.reserve((size_t)cap * n * esz));
         if (channel != CH_BIAWGN) LDPC_TRY(d->h_y0.reserve((size_t)cap * n));
         LDPC_TRY(d->h_out.reserve((size_t)cap * n));

@@ -18,6 +18,7 @@
 
 #include "ldpc_bec_planes.hpp"
 #include "ldpc_common.hpp"
+#include "ldpc_rng.hpp"
 
 namespace ldpc {
 
@@ -256,6 +257,140 @@ __global__ __launch_bounds__(256) void k_becs_unpack(const uint2* __restrict__ x
     }
 }
 
+// ---- Monte-Carlo path (ldpc_simulate): the received word is drawn straight into the planes and the decisions are counted straight from them --
+// no [B, n] byte array on either side of the decoder.
+
+// Erasure channel: the draws of k_discrete<float, CH_BEC> (ldpc_channel.hip) -- Philox block j of a frame holds the words of variables
+// 4j .. 4j+3, erased <=> word < thr -- so that counters equal the composed channel -> decode -> count path frame for frame.  One wave =
+// (supertile, run of blocks); lane l draws the 32 frames of its lane word.
+__global__ __launch_bounds__(256) void k_becs_channel(uint64_t thr, int codeword, uint64_t seed, uint32_t stream, uint64_t frame0, int64_t B, int n,
+                                                      int bpf, int qpw, uint2* __restrict__ prior, uint2* __restrict__ xhat,
+                                                      uint32_t* __restrict__ live, uint32_t* __restrict__ flags) {
+    const int T = blockIdx.y, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t fl = (int64_t)T * SUPER + (int64_t)l * 32;
+    const int64_t rem = B - fl;
+    const int nb = rem <= 0 ? 0 : (rem < 32 ? (int)rem : 32);
+    const uint32_t real = nb == 32 ? ~0u : ((1u << nb) - 1u);  // frames of this lane word that exist
+    const int j0 = (blockIdx.x * 4 + w) * qpw, j1 = j0 + qpw < bpf ? j0 + qpw : bpf;
+    uint32_t era = 0u;
+    for (int j = j0; j < j1; ++j) {
+        uint32_t hit[4] = {0u, 0u, 0u, 0u};
+        for (int b = 0; b < nb; ++b) {
+            const Philox4 ph = philox_word_block(seed, stream, frame0 + (uint64_t)(fl + b), (uint32_t)j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hit[q] |= ((uint64_t)ph.w[q] < thr ? 1u : 0u) << b;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int v = 4 * j + q;
+            if (v < n) {
+                const uint32_t kk = ~hit[q], vv = codeword ? (kk & real) : 0u;  // frames beyond the batch: a known 0
+                const size_t at = ((size_t)T * n + v) * 64 + l;
+                prior[at] = make_uint2(kk, vv);
+                xhat[at] = make_uint2(hit[q], vv);  // x_hat starts as the received word (src/bec.py:89)
+                era |= hit[q];
+            }
+        }
+    }
+    if (era) atomicOr(&flags[((size_t)T * 2 + 1) * 64 + l], era);
+    if (blockIdx.x == 0 && w == 0) live[(size_t)T * 64 + l] = real;
+}
+
+// Bit errors per frame from the decision planes: wrong = erased | (value ^ codeword bit).  A workgroup = (supertile, run of `vpb` variables);
+// every lane counts its 32 frames in bit-sliced vertical counters (15 variables ripple into a 4-plane counter, which is added into a
+// 12-plane one: vpb <= 4095), the four waves meet in LDS, one atomic per frame and workgroup.
+__global__ __launch_bounds__(256) void k_becs_errs(const uint2* __restrict__ xhat, int codeword, int n, int64_t B, int vpb, int32_t* __restrict__ errs) {
+    __shared__ uint32_t s_cnt[64][33];
+    const int T = blockIdx.y, l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 64 * 33; i += 256) (&s_cnt[0][0])[i] = 0u;
+    __syncthreads();
+    const int vb0 = blockIdx.x * vpb, vb1 = vb0 + vpb < n ? vb0 + vpb : n;
+    const uint2* xt = xhat + (size_t)T * n * 64 + l;
+    const uint32_t cw = codeword ? ~0u : 0u;
+    uint32_t big[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) big[k] = 0u;
+    for (int v0 = vb0 + w * 15; v0 < vb1; v0 += 60) {
+        uint2 e[15];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) e[i] = xt[(size_t)(v0 + i < vb1 ? v0 + i : v0) * 64];  // past the end: the first line again, not counted
+        uint32_t sm[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            uint32_t c = v0 + i < vb1 ? (e[i].x | (e[i].y ^ cw)) : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t t = sm[k] & c;
+                sm[k] ^= c;
+                c = t;
+            }
+        }
+        uint32_t carry = 0u;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t a = big[k], b = k < 4 ? sm[k] : 0u;
+            big[k] = a ^ b ^ carry;
+            carry = (a & b) | (carry & (a ^ b));
+        }
+    }
+    for (int b = 0; b < 32; ++b) {
+        uint32_t cnt = 0u;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) cnt |= ((big[k] >> b) & 1u) << k;
+        if (cnt) atomicAdd(&s_cnt[l][b], cnt);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256) {
+        const uint32_t c = s_cnt[i >> 5][i & 31];
+        const int64_t f = (int64_t)T * SUPER + i;
+        if (c && f < B) atomicAdd(&errs[f], (int32_t)c);
+    }
+}
+
+// the counters of main.test (src/main.py:41-45) from per-frame bit errors and iteration counts: tot, wec, bec, sweeps, histogram
+__global__ __launch_bounds__(256) void k_becs_tally(const int32_t* __restrict__ errs, const int32_t* __restrict__ iters, int64_t B, int hist_bins,
+                                                    unsigned long long* __restrict__ counters) {
+    extern __shared__ unsigned int s_hist[];  // [hist_bins]
+    __shared__ unsigned long long s_sum[4];
+    for (int i = threadIdx.x; i < hist_bins; i += 256) s_hist[i] = 0;
+    if (threadIdx.x < 4) s_sum[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned tot = 0, wec = 0, bec = 0, its = 0;
+    if (f < B) {
+        const int e = errs[f], it = iters[f];
+        tot = 1;
+        wec = e > 0;
+        bec = (unsigned)e;
+        its = (unsigned)it;
+        if (hist_bins > 0) atomicAdd(&s_hist[it < hist_bins ? it : hist_bins - 1], 1u);
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        tot += __shfl_xor(tot, o);
+        wec += __shfl_xor(wec, o);
+        bec += __shfl_xor(bec, o);
+        its += __shfl_xor(its, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_sum[0], (unsigned long long)tot);
+        atomicAdd(&s_sum[1], (unsigned long long)wec);
+        atomicAdd(&s_sum[2], (unsigned long long)bec);
+        atomicAdd(&s_sum[3], (unsigned long long)its);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_sum[threadIdx.x]) atomicAdd(&counters[threadIdx.x], s_sum[threadIdx.x]);
+    for (int i = threadIdx.x; i < hist_bins; i += 256)
+        if (s_hist[i]) atomicAdd(&counters[4 + i], (unsigned long long)s_hist[i]);
+}
+
+struct BecsSim {  // ldpc_simulate: where the received word comes from and where the counters go
+    uint64_t thr, seed, frame0;
+    uint32_t stream;
+    int codeword, hist_bins;
+    int64_t* counters;
+};
+
 template <typename T>
 int upload_i32(const std::vector<T>& h, DevBuf* buf) {
     LDPC_TRY(buf->reserve(h.size() * sizeof(T) + 16));
@@ -265,9 +400,10 @@ int upload_i32(const std::vector<T>& h, DevBuf* buf) {
 
 }  // namespace
 
-// Batched bec.SPA.decode (src/bec.py:83-122) on the streaming kernels.  y0 [B, n] symbols, xhat [B, n], iters [B] -- device buffers.
-int becs_stream_decode(Decoder* d, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags_in, uint8_t* xhat, int32_t* iters,
-                       hipStream_t st) {
+// Batched bec.SPA.decode (src/bec.py:83-122) on the streaming kernels.  y0 [B, n] symbols, xhat [B, n], iters [B] -- device buffers; or, with
+// `sim`, channel -> decode -> count on the planes (iters [B] is still needed: scratch of the caller).
+static int becs_run(Decoder* d, const uint8_t* y0, const BecsSim* sim, int64_t B, int32_t max_iter, uint32_t flags_in, uint8_t* xhat, int32_t* iters,
+                    hipStream_t st) {
     const Code* c = d->code;
     const int n = c->n, m = c->m;
     const int64_t E = c->E;
@@ -307,7 +443,13 @@ int becs_stream_decode(Decoder* d, const uint8_t* y0, int64_t B, int32_t max_ite
 
     LDPC_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)tiles * 2 * 64 * 4 + 64, st));
     LDPC_HIP_TRY(hipMemsetAsync(iters, 0, (size_t)B * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_becs_load, dim3((n + 63) / 64, tiles), dim3(256), 0, st, y0, B, n, prior, xh, live, tflags);
+    if (sim) {
+        const int bpf = (n + 3) / 4, qpw = 8;
+        hipLaunchKernelGGL(k_becs_channel, dim3((unsigned)((bpf + 4 * qpw - 1) / (4 * qpw)), tiles), dim3(256), 0, st, sim->thr, sim->codeword, sim->seed, sim->stream,
+                           sim->frame0, B, n, bpf, qpw, prior, xh, live, tflags);
+    } else {
+        hipLaunchKernelGGL(k_becs_load, dim3((n + 63) / 64, tiles), dim3(256), 0, st, y0, B, n, prior, xh, live, tflags);
+    }
 
     const int cpw = 4, vpw = 8;  // nodes per wave task: short runs keep a supertile's summary lines on chip between the two passes
     const int cn_chunks = (m + cpw - 1) / cpw, vn_chunks = (n + vpw - 1) / vpw;
@@ -351,12 +493,44 @@ int becs_stream_decode(Decoder* d, const uint8_t* y0, int64_t B, int32_t max_ite
         ++sweeps;
     }
     hipLaunchKernelGGL(k_becs_finish, dim3(tiles), dim3(64), 0, st, live, iters, B, sweeps);
-    hipLaunchKernelGGL(k_becs_unpack, dim3((n + 63) / 64, tiles), dim3(256), 0, st, xh, xhat, B, n);
+    if (sim) {
+        LDPC_TRY(d->h_out.reserve((size_t)B * sizeof(int32_t)));  // bit errors per frame
+        int32_t* errs = (int32_t*)d->h_out.p;
+        LDPC_HIP_TRY(hipMemsetAsync(errs, 0, (size_t)B * sizeof(int32_t), st));
+        const int vpb = 1020;
+        hipLaunchKernelGGL(k_becs_errs, dim3((n + vpb - 1) / vpb, tiles), dim3(256), 0, st, xh, sim->codeword, n, B, vpb, errs);
+        hipLaunchKernelGGL(k_becs_tally, dim3((unsigned)((B + 255) / 256)), dim3(256), (size_t)sim->hist_bins * sizeof(unsigned int), st, errs, iters, B,
+                           sim->hist_bins, (unsigned long long*)sim->counters);
+    } else {
+        hipLaunchKernelGGL(k_becs_unpack, dim3((n + 63) / 64, tiles), dim3(256), 0, st, xh, xhat, B, n);
+    }
     LDPC_HIP_TRY(hipGetLastError());
     d->last_repacks = 0;
     d->last_sweeps = sweeps;
     d->last_backend = BK_STREAM;
     return LDPC_OK;
+}
+
+int becs_stream_decode(Decoder* d, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags, uint8_t* xhat, int32_t* iters, hipStream_t st) {
+    return becs_run(d, y0, nullptr, B, max_iter, flags, xhat, iters, st);
+}
+
+// ldpc_simulate on the streaming erasure decoder: frames [frame0, frame0 + B) of the Philox stream, counters accumulated
+int becs_stream_simulate(Decoder* d, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B, int32_t max_iter,
+                         uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st) {
+    if (!(param >= 0.0 && param <= 1.0)) {
+        set_error("channel probability %g outside [0,1]", param);
+        return LDPC_E_ARG;
+    }
+    if (hist_bins > 8192) {
+        set_error("at most 8192 histogram bins");
+        return LDPC_E_ARG;
+    }
+    double t = ceil(param * 4294967296.0 - 0.5);  // (w + 0.5) * 2^-32 < p  <=>  w < ceil(p * 2^32 - 0.5), as channel_generate
+    if (t < 0) t = 0;
+    BecsSim sim{(uint64_t)t, seed, frame0, (uint32_t)stream_id, codeword, hist_bins, counters};
+    LDPC_TRY(d->h_iters.reserve((size_t)B * sizeof(int32_t)));
+    return becs_run(d, nullptr, &sim, B, max_iter, flags, nullptr, (int32_t*)d->h_iters.p, st);
 }
 
 }  // namespace ldpc

@@ -127,6 +127,8 @@ int stream_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, 
 
 // bit-sliced erasure decoder on the streaming kernels (ldpc_bec_stream.hip)
 int becs_stream_decode(Decoder* d, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags, uint8_t* xhat, int32_t* iters, hipStream_t st);
+int becs_stream_simulate(Decoder* d, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B, int32_t max_iter,
+                         uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st);
 
 int stream_simulate_biawgn(Decoder* d, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
                            int32_t max_iter, uint32_t flags, uint8_t* xhat, int32_t* iters, hipStream_t st);

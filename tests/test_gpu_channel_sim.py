@@ -83,6 +83,30 @@ def test_simulate_equals_channel_decode_count_and_oracle(alg, channel, param, pr
     assert (cnt[4:] == np.bincount(np.minimum(io, bins - 1), minlength=bins)).all()
 
 
+@pytest.mark.parametrize("name,codeword,B", [("1200_3_6_rand_ldpc_1", 0, 2048 + 700), ("1200_3_6_rand_ldpc_1", 1, 61), ("1200_rho_x5_rand_ldpc_5", 0, 4133)])
+def test_streaming_erasure_simulate_counts_on_the_bit_planes(name, codeword, B):
+    # ldpc_simulate on the streaming erasure decoder never forms a [B, n] byte array: the erasures are drawn straight into the bit planes and
+    # the bit errors are counted straight from them.  Counters and histogram must equal channel kernel -> C oracle on the same Philox frames
+    # (ragged batches: a partial lane word, a partial supertile; both codewords; regular and irregular degrees).
+    import torch
+
+    g, code, h = _setup(name=name, alg="BEC", backend="stream")
+    seed, stream, frame0, max_iter, bins = 77, 2, (1 << 32) + 5, 50, 51
+    cnt = torch.zeros(4 + bins, dtype=torch.int64, device="cuda")
+    h.simulate("bec", 0.41, codeword, seed, stream, frame0, B, max_iter, cnt, hist_bins=bins)
+    assert h.last_stats()[0] == "stream"
+    cnt = cnt.cpu().numpy()
+    _, y = h.channel_device("bec", 0.41, codeword, seed, stream, frame0, B)
+    xo, io = C.bec_decode(g, y.cpu().numpy(), max_iter)
+    err = (xo != codeword).sum(axis=1)
+    assert cnt[0] == B and cnt[1] == (err > 0).sum() and cnt[2] == err.sum() and cnt[3] == io.sum()
+    assert (cnt[4:] == np.bincount(np.minimum(io, bins - 1), minlength=bins)).all()
+    # accumulation: a second call adds to the same counters
+    cnt2 = torch.from_numpy(cnt.copy()).cuda()
+    h.simulate("bec", 0.41, codeword, seed, stream, frame0, B, max_iter, cnt2, hist_bins=bins)
+    assert (cnt2.cpu().numpy() == 2 * cnt).all()
+
+
 def test_shard_invariance_of_counters():
     import torch
 
