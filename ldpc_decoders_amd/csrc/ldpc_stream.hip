@@ -1022,6 +1022,56 @@ __global__ void k_soft_out16(const float2* __restrict__ soft_t, float* __restric
     if (fb < B) out[fb * n + v] = m.y;
 }
 
+// Frame repack of the fp16 storage mode (the policy and the ranking of ldpc_repack.hpp, as k_repack above).  The two halves of a pair-tile are
+// two 64-frame tiles (2P: the x components, 2P + 1: the y components), so a destination lane draws its two frames from two unrelated
+// (tile, lane) sources: component (tile & 1) of lane `lane` of pair tile >> 1.  What has to move after a variable pass: the variable -> check
+// lines, the priors, the decision planes, the live words and the frame map; the check -> variable lines are rewritten by the next check pass.
+__global__ __launch_bounds__(256) void k_repack16(const __half2* __restrict__ v2c_src, __half2* __restrict__ v2c_dst, const float2* __restrict__ prior_src,
+                                                  float2* __restrict__ prior_dst, const u64* __restrict__ xb_src, u64* __restrict__ xb_dst,
+                                                  const u64* __restrict__ live_src, u64* __restrict__ live_dst, const int32_t* __restrict__ base,
+                                                  const int32_t* __restrict__ frame_src, int32_t* __restrict__ frame_dst, int tiles_src, int n, int64_t E,
+                                                  int rows_per_wave) {
+    const int lane = threadIdx.x;
+    const int dp = blockIdx.y;  // destination pair
+    int sa, la, sb, lb;
+    const bool ha = repack_source(base, live_src, tiles_src, (2 * dp) * 64 + lane, &sa, &la);
+    const bool hb = repack_source(base, live_src, tiles_src, (2 * dp + 1) * 64 + lane, &sb, &lb);
+    const int chunk = blockIdx.x * 4 + threadIdx.y;
+    const int64_t rows = E + n;
+    const int64_t r0 = (int64_t)chunk * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
+    // a message line is 64 half2 = 128 halves, a prior line 64 float2 = 128 floats
+    const __half* va = reinterpret_cast<const __half*>(v2c_src + ((int64_t)(sa >> 1) * E * 64 + la)) + (sa & 1);
+    const __half* vb = reinterpret_cast<const __half*>(v2c_src + ((int64_t)(sb >> 1) * E * 64 + lb)) + (sb & 1);
+    const float* pa = reinterpret_cast<const float*>(prior_src + ((int64_t)(sa >> 1) * n * 64 + la)) + (sa & 1);
+    const float* pb = reinterpret_cast<const float*>(prior_src + ((int64_t)(sb >> 1) * n * 64 + lb)) + (sb & 1);
+    __half2* vd = v2c_dst + (int64_t)dp * E * 64 + lane;
+    float2* pd = prior_dst + (int64_t)dp * n * 64 + lane;
+    const __half hz = __float2half(0.0f);
+    for (int64_t r = r0; r < r1; ++r) {
+        if (r < E) {
+            vd[r * 64] = __halves2half2(ha ? va[r * 128] : hz, hb ? vb[r * 128] : hz);
+        } else {
+            const int64_t v = r - E;
+            pd[v * 64] = make_float2(ha ? pa[v * 128] : 0.0f, hb ? pb[v * 128] : 0.0f);
+            const u64 wa = ha ? xb_src[plane_at(sa, v, n)] : 0ull, wb = hb ? xb_src[plane_at(sb, v, n)] : 0ull;
+            const u64 plane_a = __ballot(ha && ((wa >> la) & 1ull)), plane_b = __ballot(hb && ((wb >> lb) & 1ull));
+            if (lane == 0) {
+                xb_dst[plane_at(2 * dp, v, n)] = plane_a;
+                xb_dst[plane_at(2 * dp + 1, v, n)] = plane_b;
+            }
+        }
+    }
+    if (chunk == 0) {
+        frame_dst[(int64_t)(2 * dp) * 64 + lane] = ha ? (frame_src ? frame_src[(int64_t)sa * 64 + la] : sa * 64 + la) : -1;
+        frame_dst[(int64_t)(2 * dp + 1) * 64 + lane] = hb ? (frame_src ? frame_src[(int64_t)sb * 64 + lb] : sb * 64 + lb) : -1;
+        const u64 lva = __ballot(ha), lvb = __ballot(hb);
+        if (lane == 0) {
+            live_dst[2 * dp] = lva;
+            live_dst[2 * dp + 1] = lvb;
+        }
+    }
+}
+
 #ifndef LDPC_CN16_UNR
 #define LDPC_CN16_UNR 2
 #endif
@@ -1035,10 +1085,25 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
         set_error("streaming backend supports node degrees up to 64 (max_dc=%d, max_dv=%d)", c->max_dc, c->max_dv);
         return LDPC_E_UNSUPPORTED;
     }
-    const int tiles = (int)((B + 63) / 64), pairs = (tiles + 1) / 2;
+    const int tiles0 = (int)((B + 63) / 64), pairs0 = (tiles0 + 1) / 2;
+    int tiles = tiles0, pairs = pairs0;  // shrink when the live frames are repacked into dense pair-tiles
     const bool early = !(flags_in & FLAG_NO_EARLY_EXIT);
     LDPC_TRY(d->msg.reserve((size_t)pairs * E * 64 * sizeof(__half2)));
     LDPC_TRY(d->msg2.reserve((size_t)pairs * E * 64 * sizeof(__half2)));  // variable -> check lines, variable-major
+    // Frame repack (k_repack16; policy of the fp32 passes): at a poll, when the live frames would fill less than `fill` of the tiles that
+    // still hold one, they are gathered into dense pair-tiles.  Second state set: variable -> check lines, priors, planes, live words, map.
+    bool repack_ok = early && soft_out == nullptr && tiles0 >= 4;
+    double repack_fill = 0.75;
+    if (const char* e = std::getenv("LDPC_STREAM_REPACK")) repack_ok = repack_ok && atoi(e) != 0;
+    if (const char* e = std::getenv("LDPC_STREAM_REPACK_FILL")) repack_fill = atof(e);
+    if (repack_fill > 0.95) repack_fill = 0.95;
+    if (repack_ok) {
+        const size_t np2 = ((size_t)(repack_fill * tiles0) + 2 + 1) / 2;  // pairs of the second set: the first repack fires at <= fill * tiles
+        if (d->marg2.reserve(np2 * E * 64 * sizeof(__half2)) || d->prior2.reserve(np2 * n * 64 * sizeof(float2)) ||
+            d->xbits2.reserve(plane_words((int)(2 * np2), n) * 8) || d->live2.reserve(2 * np2 * 8) || d->fmap2.reserve(2 * np2 * 64 * sizeof(int32_t)) ||
+            d->fmap.reserve(2 * np2 * 64 * sizeof(int32_t)) || d->rbase.reserve(((size_t)tiles0 + 2) * sizeof(int32_t)))
+            repack_ok = false;  // no room for a second set: decode without repacking
+    }
     if (soft_out) LDPC_TRY(d->marg.reserve((size_t)pairs * n * 64 * sizeof(float2)));
     if (!d->scratch.p) {  // row-major edge k -> its position in the CSC edge list (where the variable pass writes its v2c line)
         std::vector<int32_t> vpos((size_t)E);
@@ -1071,6 +1136,13 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
         hipLaunchKernelGGL(k_load_tile16, dim3((n + 63) / 64, pairs), dim3(256), 0, st, priors, y0, B, n, prior, xbits);
     }
     hipLaunchKernelGGL(k_init_live, dim3((tiles + 255) / 256), dim3(256), 0, st, live, B, tiles);
+    DevBuf* set_v2c[2] = {&d->msg2, &d->marg2};
+    DevBuf* set_prior[2] = {&d->prior, &d->prior2};
+    DevBuf* set_xbits[2] = {&d->xbits, &d->xbits2};
+    DevBuf* set_live[2] = {&d->live, &d->live2};
+    DevBuf* set_fmap[2] = {&d->fmap, &d->fmap2};
+    int32_t* fmap = nullptr;  // frame of (tile, lane); null = identity (never repacked)
+    int cur = 0, repacks = 0;
 
     const int cpw = env_int("LDPC_STREAM_CPW", 4), vpw = env_int("LDPC_STREAM_VPW", 16);
     const int cn_chunks = (m + cpw - 1) / cpw, vn_chunks = (n + vpw - 1) / vpw;
@@ -1093,13 +1165,34 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
             sblocks = sblocks < 1 ? 1 : (sblocks > smax ? smax : sblocks);
             hipLaunchKernelGGL(k_syndrome_part, dim3(sblocks, groups), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, xbits, live, tflags, m, n, tiles,
                                (m + sblocks - 1) / sblocks);
-            hipLaunchKernelGGL(k_syndrome_fin, dim3(tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr, B, sweeps, (const int32_t*)nullptr);
+            hipLaunchKernelGGL(k_syndrome_fin, dim3(tiles), dim3(64), 0, st, tflags, live, iters, poll ? live_tiles : nullptr, B, sweeps, (const int32_t*)fmap);
             if (poll) {
-                LDPC_HIP_TRY(hipMemcpyAsync((void*)poll_host, live_tiles, sizeof(int), hipMemcpyDeviceToHost, st));
+                LDPC_HIP_TRY(hipMemcpyAsync((void*)poll_host, live_tiles, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
                 LDPC_HIP_TRY(hipStreamSynchronize(st));
-                if (poll_host[0] == 0) {
+                const int lt = poll_host[0], lf = poll_host[1];  // tiles that still hold a live frame, live frames
+                if (lt == 0) {
                     all_left = true;
                     break;
+                }
+                if (repack_ok && it > 0 && lt >= 2 && (double)lf <= repack_fill * 64.0 * lt && it + 1 < cap) {
+                    const int nt = (lf + 63) / 64, np = (nt + 1) / 2, nx = 1 - cur;
+                    // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs at the end)
+                    hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256, tiles), dim3(256), 0, st, xbits, xhat, B, n, (const int32_t*)fmap);
+                    hipLaunchKernelGGL(k_repack_plan, dim3(1), dim3(1024), 0, st, live, tiles, (int32_t*)d->rbase.p);
+                    const int rows_per_wave = 128;
+                    const int chunks = (int)((E + n + rows_per_wave - 1) / rows_per_wave);
+                    hipLaunchKernelGGL(k_repack16, dim3((chunks + 3) / 4, np), dim3(64, 4), 0, st, v2c, (__half2*)set_v2c[nx]->p, prior, (float2*)set_prior[nx]->p,
+                                       xbits, (u64*)set_xbits[nx]->p, live, (u64*)set_live[nx]->p, (const int32_t*)d->rbase.p, (const int32_t*)fmap,
+                                       (int32_t*)set_fmap[nx]->p, tiles, n, E, rows_per_wave);
+                    cur = nx;
+                    v2c = (__half2*)set_v2c[cur]->p;
+                    prior = (float2*)set_prior[cur]->p;
+                    xbits = (u64*)set_xbits[cur]->p;
+                    live = (u64*)set_live[cur]->p;
+                    fmap = (int32_t*)set_fmap[cur]->p;
+                    pairs = np;
+                    tiles = 2 * np;  // (an odd tile count leaves the last pair's second tile without a live frame)
+                    ++repacks;
                 }
             }
         }
@@ -1144,15 +1237,15 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
         }
         ++sweeps;
     }
-    hipLaunchKernelGGL(k_finish_iters, dim3(tiles), dim3(64), 0, st, live, iters, B, sweeps, (const int32_t*)nullptr);
-    hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256, tiles), dim3(256), 0, st, xbits, xhat, B, n, (const int32_t*)nullptr);
-    if (soft_out) hipLaunchKernelGGL(k_soft_out16, dim3((n + 3) / 4, pairs), dim3(256), 0, st, marg, soft_out, B, n);
+    hipLaunchKernelGGL(k_finish_iters, dim3(tiles), dim3(64), 0, st, live, iters, B, sweeps, (const int32_t*)fmap);
+    hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256, tiles), dim3(256), 0, st, xbits, xhat, B, n, (const int32_t*)fmap);
+    if (soft_out) hipLaunchKernelGGL(k_soft_out16, dim3((n + 3) / 4, pairs), dim3(256), 0, st, marg, soft_out, B, n);  // (no repack with a soft output)
     LDPC_HIP_TRY(hipGetLastError());
     if (d->profile) {
         LDPC_HIP_TRY(hipStreamSynchronize(st));
         LDPC_TRY(prof_collect(d, spans));
     }
-    d->last_repacks = 0;
+    d->last_repacks = repacks;
     d->last_sweeps = sweeps;
     d->last_backend = BK_STREAM;
     return LDPC_OK;

@@ -48,6 +48,36 @@ def test_repack_is_bit_transparent(monkeypatch, prec, dt, alg):
     assert (x2 == x0).all() and (i2 == i0).all()
 
 
+@pytest.mark.parametrize("alg", ["MSA", "SPA"])
+@pytest.mark.parametrize("name,B", [("1200_3_6_rand_ldpc_1", 64 * 41 + 17), ("1200_rho_x5_rand_ldpc_5", 64 * 12 + 3)])
+def test_repack_of_the_fp16_storage_mode_is_bit_transparent(monkeypatch, alg, name, B):
+    # the fp16 storage mode works on pair-tiles of 128 frames; its repack draws the two halves of a destination lane from two unrelated
+    # (tile, lane) sources.  Moving state must not change a single decision or iteration count (odd tile counts, a ragged last tile,
+    # irregular degrees, several repacks in one decode, and the Monte-Carlo entry point).
+    import torch
+    from ldpc_decoders_amd._device import DecoderHandle
+    from ldpc_decoders_amd.codes import Code
+
+    g = golden_edges(name)
+    code = Code.from_edges(g.m, g.n, g.chk, g.var)
+    pri = torch.from_numpy(_priors(5, B, g.n, 2.3).astype(np.float32)).cuda()
+    h = DecoderHandle(code, alg, "f16")
+    monkeypatch.setenv("LDPC_STREAM_REPACK", "0")
+    x0, i0 = h.decode_device(pri, None, 50)
+    assert h.last_stats()[0] == "stream" and h.last_repacks() == 0
+    cnt0 = torch.zeros(4 + 51, dtype=torch.int64, device="cuda")
+    h.simulate("biawgn", 2.3, 0, 9, 1, 0, B, 50, cnt0, hist_bins=51)
+    monkeypatch.setenv("LDPC_STREAM_REPACK", "1")
+    monkeypatch.setenv("LDPC_STREAM_REPACK_FILL", "0.97")  # eager: several repacks in one decode
+    x1, i1 = h.decode_device(pri, None, 50)
+    assert h.last_repacks() >= 2
+    assert (x1 == x0).all() and (i1 == i0).all()
+    assert 0 < (i0.cpu().numpy() < 50).mean()  # frames did leave early
+    cnt1 = torch.zeros_like(cnt0)
+    h.simulate("biawgn", 2.3, 0, 9, 1, 0, B, 50, cnt1, hist_bins=51)
+    assert h.last_repacks() >= 1 and (cnt1 == cnt0).all()
+
+
 def test_repack_with_received_word(monkeypatch):
     # BSC: the iteration-0 exit of the received word (src/bpa.py:20,29) happens before any repack
     from ldpc_decoders_amd import bpa
