@@ -806,7 +806,8 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
 // (SURVEY 8(d)'s all-fp16 figure 2(4E + n) differs only by the fp32 priors).
 // A throughput mode, NOT the parity mode: messages are rounded to 11 significant bits each sweep (and saturate at +-65504 where the fp32
 // mode would carry larger finite values); tests hold it to a stated per-sweep tolerance against the fp32 kernels and to the published
-// curves.  No frame repack; the soft output is that of the last sweep of the BATCH (frames that have left keep evolving).
+// curves.  Frame repack on pair-tiles (k_repack16); with a soft output there is none, and the soft output is that of the last sweep of the
+// BATCH (frames that have left keep evolving).
 namespace {
 
 // the load and the conversion are separate so that a kernel can issue all its line loads before it touches the first result
