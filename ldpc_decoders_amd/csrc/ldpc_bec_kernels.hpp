@@ -140,7 +140,10 @@ __device__ __forceinline__ void becs_var_phase(const unsigned char* smem, const 
     constexpr int DV = SH::DV, VRW = SH::VRW, VRX = SH::VRX, DVX = SH::DVX, VN0 = SH::VN0;
     constexpr bool OWN_REGS = SH::OWN_REGS;
     auto vn_addr = [&](int k) -> uint32_t { return half_of<SH::VNK>(vn_idx, k) << 3; };
-    auto var_round = [&](auto Q_, auto WD_, const P2 (&sm)[decltype(WD_)::value]) {
+    // own_at(q): first own-message row of variable round q.  Where the wave re-reads its own last messages from its rows (Monte-Carlo kernel),
+    // those reads travel with the summary gathers of the round -- one round ahead -- instead of in front of their first use
+    auto own_row0 = [&](int q) -> int { return q < VRX ? q * DVX : VN0 + (q - VRX) * DV; };
+    auto var_round = [&](auto Q_, auto WD_, const P2 (&sm)[decltype(WD_)::value], const P2 (&own)[decltype(WD_)::value]) {
         constexpr int q = decltype(Q_)::value, wd = decltype(WD_)::value;
         constexpr int g0 = q < VRX ? q * DVX : VN0 + (q - VRX) * DV;
         uint32_t ck[wd], cv[wd];
@@ -151,7 +154,7 @@ __device__ __forceinline__ void becs_var_phase(const unsigned char* smem, const 
             constexpr int j = decltype(J_)::value;
             uint32_t k0, v0;
             if constexpr (OWN_REGS) { k0 = ok[g0 + j]; v0 = ov[g0 + j]; }
-            else { const P2 o = lds_ld2(smem, own_off + (g0 + j) * 512); k0 = o.k; v0 = o.v; }
+            else { k0 = own[j].k; v0 = own[j].v; }
             const uint32_t a = sm[j].k, b = sm[j].v;
             ck[j] = B3(a, b, k0, (X1 & ~X0) | (X0 & ~X2));            // echo of a known message, or the one erased edge of its check
             cv[j] = b & B3(a, k0, v0, (X0 & ~X1) | (~X0 & X2));       // b & (a ? ~k0 : v0)
@@ -178,32 +181,44 @@ __device__ __forceinline__ void becs_var_phase(const unsigned char* smem, const 
         });
     };
     if constexpr (VRX > 0) {
-        P2 sw[2][DVX];
+        P2 sw[2][DVX], ow[2][DVX];
 #pragma unroll
-        for (int j = 0; j < DVX; ++j) sw[0][j] = lds_ld2(smem, vn_addr(j));
+        for (int j = 0; j < DVX; ++j) {
+            sw[0][j] = lds_ld2(smem, vn_addr(j));
+            if constexpr (!OWN_REGS) ow[0][j] = lds_ld2(smem, own_off + (own_row0(0) + j) * 512);
+        }
         static_for<0, VRX>([&](auto Q_) {
             constexpr int q = decltype(Q_)::value;
             if constexpr (q + 1 < VRX) {
 #pragma unroll
-                for (int j = 0; j < DVX; ++j) sw[(q + 1) & 1][j] = lds_ld2(smem, vn_addr((q + 1) * DVX + j));
+                for (int j = 0; j < DVX; ++j) {
+                    sw[(q + 1) & 1][j] = lds_ld2(smem, vn_addr((q + 1) * DVX + j));
+                    if constexpr (!OWN_REGS) ow[(q + 1) & 1][j] = lds_ld2(smem, own_off + (own_row0(q + 1) + j) * 512);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            var_round(Q_, std::integral_constant<int, DVX>{}, sw[q & 1]);
+            var_round(Q_, std::integral_constant<int, DVX>{}, sw[q & 1], ow[q & 1]);
         });
     }
     constexpr int VRN = VRW - VRX;
     if constexpr (VRN > 0) {
-        P2 sn[2][DV];
+        P2 sn[2][DV], on[2][DV];
 #pragma unroll
-        for (int j = 0; j < DV; ++j) sn[0][j] = lds_ld2(smem, vn_addr(VN0 + j));
+        for (int j = 0; j < DV; ++j) {
+            sn[0][j] = lds_ld2(smem, vn_addr(VN0 + j));
+            if constexpr (!OWN_REGS) on[0][j] = lds_ld2(smem, own_off + (own_row0(VRX) + j) * 512);
+        }
         static_for<0, VRN>([&](auto U_) {
             constexpr int u = decltype(U_)::value;
             if constexpr (u + 1 < VRN) {
 #pragma unroll
-                for (int j = 0; j < DV; ++j) sn[(u + 1) & 1][j] = lds_ld2(smem, vn_addr(VN0 + (u + 1) * DV + j));
+                for (int j = 0; j < DV; ++j) {
+                    sn[(u + 1) & 1][j] = lds_ld2(smem, vn_addr(VN0 + (u + 1) * DV + j));
+                    if constexpr (!OWN_REGS) on[(u + 1) & 1][j] = lds_ld2(smem, own_off + (own_row0(VRX + u + 1) + j) * 512);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            var_round(std::integral_constant<int, VRX + u>{}, std::integral_constant<int, DV>{}, sn[u & 1]);
+            var_round(std::integral_constant<int, VRX + u>{}, std::integral_constant<int, DV>{}, sn[u & 1], on[u & 1]);
         });
     }
 }
