@@ -42,6 +42,8 @@ def test(args, comm=None):
     # tie-dominated and only the reference's fp64 arithmetic reproduces its curves
     tie_dominated = args.channel == "bsc" and args.decoder == "MSA"
     kwargs["precision"] = args.precision or ("f64" if (exact or tie_dominated) else "f32")
+    if kwargs["precision"] == "f16" and (args.decoder not in ("SPA", "MSA") or args.channel == "bec" or exact):
+        raise SystemExit("--precision f16 (fp16 storage of the messages): the LLR decoders SPA / MSA over biawgn / bsc, device-noise mode")
     results = OrderedDict()
 
     for pi, param in enumerate(args.params):

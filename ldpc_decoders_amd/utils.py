@@ -51,8 +51,9 @@ def setup_parser(code_names, channel_names, decoder_names):
     p = argparse.ArgumentParser()
     _reference_flags(p, channel_names, code_names, decoder_names)
     g = p.add_argument_group("GPU build")
-    g.add_argument("--precision", choices=["f32", "f64"], default=None,
-                   help="message arithmetic (default: f32 with device noise; f64 with --exact and for min-sum over the BSC, which is tie-dominated)")
+    g.add_argument("--precision", choices=["f32", "f64", "f16"], default=None,
+                   help="message arithmetic (default: f32 with device noise; f64 with --exact and for min-sum over the BSC, which is tie-dominated); "
+                        "f16: fp16 STORAGE of the messages on the streaming kernels, fp32 arithmetic -- a tolerance mode for codes whose state lives in HBM")
     g.add_argument("--backend", choices=["auto", "stream", "fused"], default="auto", help="kernel family")
     g.add_argument("--batch", type=int, default=65536, help="frames per round and per GPU (device-noise mode)")
     g.add_argument("--seed", type=int, default=0x5EED1200, help="Philox seed of the device noise")

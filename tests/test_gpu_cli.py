@@ -111,6 +111,19 @@ def test_device_mode_schema_and_rates(tmp_path, monkeypatch):
     assert res[2.0]["wer"] == data["wer"]["2.0"]
 
 
+def test_fp16_storage_mode_through_the_cli(tmp_path, monkeypatch):
+    # `--precision f16` (an addition): the same run on the fp16-storage streaming kernels -- a tolerance mode; the rates must sit where
+    # the fp32 run's do (same published curve as above)
+    from ldpc_decoders_amd import codes, main
+
+    monkeypatch.setenv(codes.file_codes_dir_string, CODES_DIR)
+    argv = "biawgn 1200_3_6_rand_ldpc_1 MSA --codeword 0 --min-wec 200 --max-iter 10 --params 2.0 2.5 --batch 8192 --precision f16".split()
+    main.main(argv + ["--data_dir", str(tmp_path), "--console"])
+    data = json.load(open(os.path.join(str(tmp_path), "biawgn-1200_3_6_rand_ldpc_1-MSA-0-200-10.json")))
+    assert 0.012 < data["ber"]["2.0"] < 0.035 and 0.0012 < data["ber"]["2.5"] < 0.0045
+    assert data["wec"]["2.0"] >= 200 and data["tot"]["2.0"] % 8192 == 0
+
+
 def test_curves_overlap_the_published_reference_results(tmp_path):
     # device Monte-Carlo against the reference's own published result files for the fixture codes (a subset here; the full
     # table is profiles/curves_vs_reference.md, tools/compare_curves.py): every curve agrees or is a documented deviation
