@@ -14,6 +14,8 @@ __global__ __launch_bounds__(256) void k(double* out, int iters) {
     const uint32_t a_lin = base + lane * 8, a_perm = base + ((lane & 32) | ((lane * 5 + 3) & 31)) * 8;
     typedef double d2 __attribute__((ext_vector_type(2)));
     const uint32_t a_lin2 = base + lane * 16;
+    const uint32_t a_p64 = base + ((lane * 37 + 11) & 63) * 4;
+    asm volatile("s_mov_b32 m0, %0" ::"s"(__builtin_amdgcn_readfirstlane(base)) : "memory");
     double v = (double)lane, acc = 0.0, v2 = v + 1.0;
     d2 q = {v, v2};
     for (int i = lane; i < 1024; i += 64) reinterpret_cast<double*>(smem + w * 8192)[i] = 0.0;
@@ -32,6 +34,16 @@ __global__ __launch_bounds__(256) void k(double* out, int iters) {
             if (KIND == 7 && (r & 1) == 0) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a_lin2), "v"(q), "n"(r * 512) : "memory");
             if (KIND == 8 && (r & 1) == 0) { d2 t; asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(t) : "v"(a_perm), "n"(r), "n"(r + 1) : "memory"); acc += t.x + t.y; }
             if (KIND == 9 && (r & 1) == 0) { d2 t; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(a_lin2), "n"(r * 512) : "memory"); acc += t.x + t.y; }
+            // split planes (lo / hi dwords of a double in two 256-byte rows): one ds_read2_b32 gathers a double, two ds_write_addtid_b32 store a row of
+            // doubles without an address register (the fp32 kernel's store).  a_p64: a permutation of all 64 lanes (64 distinct banks)
+            if (KIND == 11) { double t; asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(t) : "v"(a_p64), "n"((r & 1) * 128), "n"((r & 1) * 128 + 64) : "memory"); acc += t; }
+            if (KIND == 12) { double t; asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(t) : "v"(a_p64), "n"((r & 1) * 128), "n"((r & 1) * 128 + 65) : "memory"); acc += t; }
+            if (KIND == 13) asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"((float)v), "n"(r * 256) : "memory");
+            if (KIND == 14) {  // the would-be kernel's mix per 7 slots: 3 gathers of doubles + 4 half-row stores
+                if ((r % 7) < 3) { double t; asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(t) : "v"(a_p64), "n"(0), "n"(64) : "memory"); acc += t; }
+                else if (r < 14) asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"((float)v), "n"(r * 256) : "memory");
+            }
+            if (KIND == 15) { float t; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(t) : "v"(a_p64), "n"(r * 256) : "memory"); acc += t; }
             // the kernel's mix: are loads and stores additive on the path?  per group of 4 slots: 2 gathers + 1 row store (3 instructions)
             if (KIND == 10 && (r & 3) != 3) {
                 if ((r & 3) == 2) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a_lin), "v"(v), "n"(r * 512) : "memory");
@@ -60,11 +72,13 @@ int main() {
     const int iters = 20000;
     const char* names[] = {"ds_write_b64 lane-contiguous", "ds_write_b64 permuted", "ds_add_f64 permuted", "ds_read_b64 permuted", "ds_write_b32 permuted",
                            "ds_write2st64_b64 (2 rows)", "ds_write2_b64 (16 B per lane)", "ds_write_b128 (16 B per lane)", "ds_read2st64_b64 (2 rows)", "ds_read_b128 (16 B per lane)",
-                           "mix: 2 ds_read_b64 + 1 ds_write_b64"};
-    const double per16[] = {16, 16, 16, 16, 16, 8, 8, 8, 8, 8, 12};  // instructions issued per 16 slots
-    double t[11] = {run<0>(out, iters), run<1>(out, iters), run<2>(out, iters), run<3>(out, iters), run<4>(out, iters), run<5>(out, iters),
-                    run<6>(out, iters), run<7>(out, iters), run<8>(out, iters), run<9>(out, iters), run<10>(out, iters)};
-    for (int i = 0; i < 11; ++i) {
+                           "mix: 2 ds_read_b64 + 1 ds_write_b64", "ds_read2_b32 rows 256 B apart (same bank)", "ds_read2_b32 rows 260 B apart", "ds_write_addtid_b32",
+                           "mix: 3 ds_read2_b32 + 4 ds_write_addtid_b32", "ds_read_b32 permuted (64 banks)"};
+    const double per16[] = {16, 16, 16, 16, 16, 8, 8, 8, 8, 8, 12, 16, 16, 16, 14, 16};  // instructions issued per 16 slots
+    double t[16] = {run<0>(out, iters), run<1>(out, iters), run<2>(out, iters), run<3>(out, iters), run<4>(out, iters), run<5>(out, iters),
+                    run<6>(out, iters), run<7>(out, iters), run<8>(out, iters), run<9>(out, iters), run<10>(out, iters), run<11>(out, iters),
+                    run<12>(out, iters), run<13>(out, iters), run<14>(out, iters), run<15>(out, iters)};
+    for (int i = 0; i < 16; ++i) {
         const double ti = t[i] * 16.0 / per16[i];
         printf("%-36s %.2f ns per wave-instruction per CU = %.2f cycles at 2.4 GHz\n", names[i], ti * 1e9, ti * 2.4e9);
     }
