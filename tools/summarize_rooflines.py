@@ -144,6 +144,10 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
                 # ds_write_b64 6.3 cycles per wave-instruction per CU, ds_add_f64 8.07; a 2-load + 1-store mix runs at their sum: the path is additive)
                 if fam[0] in ("k_fused_f64", "k_fused_becs"):
                     e["lds_path_cycles_per_frame_sweep_measured_constants"] = round(ld * 2.55 + st_ * 6.3 + at * 8.07, 1)
+                    e["lds_path_measured_constants"] = "ds_read_b64 2.55, ds_write_b64 6.3"
+                elif fam[0] == "k_fused_bp":  # 4-byte elements: ds_read_b32 2.88, ds_write_addtid_b32 2.2 (third run of the same file)
+                    e["lds_path_cycles_per_frame_sweep_measured_constants"] = round(ld * 2.88 + st_ * 2.2 + at * 8.0, 1)
+                    e["lds_path_measured_constants"] = "ds_read_b32 2.88, ds_write_addtid_b32 2.2"
                 e.update(lds_loads_per_frame_sweep=round(ld, 2), lds_stores_per_frame_sweep=round(st_, 2), lds_atomics_per_frame_sweep=round(at, 2),
                          lds_path_cycles_per_frame_sweep=round(path, 1), lds_path_model=fam[3],
                          lds_data_fifo_full_per_frame_sweep=round(t4.get("SQ_LDS_DATA_FIFO_FULL", 0.0), 2),
@@ -179,9 +183,9 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
                               e["lds_path_model"], pth, arr, val, e["binding_unit"], e["lds_data_fifo_full_per_frame_sweep"],
                               e["lds_cmd_fifo_full_per_frame_sweep"], e["lds_addr_conflict_per_frame_sweep"], e["wait_inst_lds_quad_cycles_per_frame_sweep"]))
                 if "lds_path_frac_measured_constants" in e:
-                    md.append("With the per-instruction cycles MEASURED on this chip (profiles/r04_lds_store_path.txt: ds_read_b64 2.55, ds_write_b64 6.3, additive "
-                              "in a mixed stream) the same split is %.1f cycles per frame-sweep = **%.3f** of the path's capacity." % (
-                                  e["lds_path_cycles_per_frame_sweep_measured_constants"], e["lds_path_frac_measured_constants"]))
+                    md.append("With the per-instruction cycles MEASURED on this chip (profiles/r04_lds_store_path.txt: %s) the same split is %.1f cycles per "
+                              "frame-sweep = **%.3f** of the path's capacity." % (
+                                  e.get("lds_path_measured_constants", ""), e["lds_path_cycles_per_frame_sweep_measured_constants"], e["lds_path_frac_measured_constants"]))
             if "wait_any_share" in e:
                 md.append("Wave time: %.0f %% waiting (s_waitcnt / barrier), %.0f %% issue stalls, %.0f %% issuing." % (
                     100 * (e["wait_any_share"] or 0), 100 * (e["wait_inst_any_share"] or 0), 100 * (e["active_inst_any_share"] or 0)))
