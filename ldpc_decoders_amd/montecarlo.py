@@ -83,25 +83,46 @@ class DeviceSimulator:
                             host=torch.zeros(k, dtype=torch.int64).pin_memory() if on_gpu else torch.zeros(k, dtype=torch.int64),
                             done=torch.cuda.Event() if on_gpu else None, busy=False) for _ in range(self.DEPTH + 1)]
         self._next = 0
+        # lanes = (decoder, HIP stream) pairs that rounds alternate over.  One lane (default): everything on the caller's stream.  Two
+        # (LDPC_SIM_STREAMS=2, pipelined rounds of the in-kernel path): consecutive rounds run on two streams with two decoders (own frame
+        # dispensers), so the tail of one launch -- CUs idling while its last frames finish -- is filled by the head of the next.  Measured
+        # (round 4, same box): 65 536-frame rounds of the n = 1200 kernels +0.35 % (fp64, 5.28 ms per round) and +0.85 % (fp32, 2.75 ms), but
+        # the 0.25 ms rounds of the erasure decoder -15 %: an opt-in, not the default.
+        self._lanes = [(handle, None)]
+        self._round = 0
+
+    def _lane(self):
+        import os
+
+        if len(self._lanes) == 1 and self.device == "cuda" and hasattr(self.h, "twin") and os.environ.get("LDPC_SIM_STREAMS", "1") == "2" \
+                and self.pipeline_depth() >= 2:
+            self._lanes.append((self.h.twin(), self.torch.cuda.Stream()))
+        lane = self._lanes[self._round % len(self._lanes)]
+        self._round += 1
+        return lane
 
     def launch_round(self, param, stream_id, frame0, frames_total, flags=0):
         """Enqueue the decode of global frames [frame0, frame0+frames_total), split over ranks; returns a ticket for finish_round."""
+        import contextlib
+
         slot = self._slots[self._next]
         if slot["busy"]:
             raise RuntimeError("more than %d rounds in flight" % len(self._slots))
         self._next = (self._next + 1) % len(self._slots)
         start, cnt = self.comm.shard(frame0, frames_total)
-        slot["dev"].zero_()
-        if cnt > 0 and self.prior_grid is not None:
-            self.redone += self.h.simulate_exact_fp32(param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
-                                                      self.prior_grid, hist_bins=self.hist_bins)  # (reads its redo list: synchronous)
-        elif cnt > 0:
-            self.h.simulate(self.channel, param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
-                            flags=flags, hist_bins=self.hist_bins)
-        self.comm.all_reduce_sum(slot["dev"], async_on_stream=True)
-        slot["host"].copy_(slot["dev"], non_blocking=True)
-        if slot["done"] is not None:
-            slot["done"].record()
+        h, stream = self._lane()
+        with (self.torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            slot["dev"].zero_()
+            if cnt > 0 and self.prior_grid is not None:
+                self.redone += h.simulate_exact_fp32(param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
+                                                     self.prior_grid, hist_bins=self.hist_bins)  # (reads its redo list: synchronous)
+            elif cnt > 0:
+                h.simulate(self.channel, param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
+                           flags=flags, hist_bins=self.hist_bins)
+            self.comm.all_reduce_sum(slot["dev"], async_on_stream=True)
+            slot["host"].copy_(slot["dev"], non_blocking=True)
+            if slot["done"] is not None:
+                slot["done"].record()
         slot["busy"] = True
         return slot
 
