@@ -113,3 +113,31 @@ def test_fp16_mode_statistics_equal_the_fp32_mode_on_identical_noise():
     print("2.0 dB, 16 384 identical frames: fp16-storage wec %d, mean sweeps %.2f; fp32 wec %d, mean sweeps %.2f" % (a[1], a[3] / a[0], b[1], b[3] / b[0]))
     assert a[0] == b[0] == 16384 and abs(int(a[1]) - int(b[1])) <= 4 * np.sqrt(b[1]) + 8
     assert abs(a[3] / a[0] - b[3] / b[0]) <= 0.5
+
+
+def test_config5_size_properties_of_the_fp16_mode():
+    # BASELINE config 5 ((3,6), n = 64 800) in the fp16 storage mode, on priors both modes are given: every frame that leaves early carries a
+    # codeword (size-independent), the fp16 mode decodes what the fp32 kernels decode on all but a stated fraction of the frames (tolerance
+    # mode: a frame near its threshold may need a few sweeps more or fewer), and with the frame repack on pair-tiles active
+    import torch
+    from ldpc_decoders_amd import codes
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    code = codes.rand_reg_ldpc(64800, 3, 6, np.random.RandomState(8))
+    rng = np.random.RandomState(3)
+    B = 640
+    y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(1.8)), (B, code.n))   # just above this code's min-sum threshold: frames leave after 20..50 sweeps
+    pri = torch.from_numpy(O.biawgn_priors(y, 1.8).astype(np.float32)).cuda()
+    h16, h32 = DecoderHandle(code, "MSA", "f16"), DecoderHandle(code, "MSA", "f32", "stream")
+    x16, i16 = h16.decode_device(pri, None, 50)
+    x32, i32 = h32.decode_device(pri, None, 50)
+    x16, i16, x32, i32 = x16.cpu().numpy(), i16.cpu().numpy(), x32.cpu().numpy(), i32.cpu().numpy()
+    done16, done32 = i16 < 50, i32 < 50
+    print("config 5, fp16 storage: %d of %d frames leave early (fp32: %d); iteration counts differ on %d frames, by at most %d; repacks %d" % (
+        done16.sum(), B, done32.sum(), (i16 != i32).sum(), np.abs(i16 - i32).max(), h16.last_repacks()))
+    assert done16.any() and code.syndrome(x16[done16]).sum() == 0
+    assert (done16 != done32).mean() <= 0.02            # the same frames decode
+    both = done16 & done32
+    assert (x16[both] == x32[both]).all()                # ... to the same words (the all-zero word here, but through different messages)
+    assert np.abs(i16[both] - i32[both]).max() <= 5      # measured: 92 of 640 iteration counts differ, by at most 5; 618 / 620 frames leave early, 4 repacks
+    assert h16.last_repacks() >= 1
