@@ -67,12 +67,59 @@ def load_code(name):
     return codes.load_parity_mtx(os.path.join(codes.PACKAGE_CODES_DIR, name + ".txt"))
 
 
-def cpu_baseline(code, snr, max_iter, precision="f64", budget_s=10.0):
+def physical_cores():
+    """Distinct (package, core) pairs of /proc/cpuinfo -- os.cpu_count() counts hardware THREADS."""
+    try:
+        seen, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as fp:
+            for ln in fp:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip() and phys is not None and core is not None:
+                    seen.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def resolve_workload(decoder, channel, param, snr):
+    """The selectors of the reference's CLI (src/main.py:11-12, src/models.py:3) -> (algorithm of the C ABI, channel, channel parameter).
+    The `bec` selector pairs with the ternary erasure decoder whatever SPA / MSA says (src/bec.py:70-125), as in the registry."""
+    alg = "BEC" if (channel == "bec" or decoder == "BEC") else decoder
+    channel = "bec" if alg == "BEC" else channel
+    if param is None:
+        param = snr if channel == "biawgn" else {"bsc": 0.07, "bec": 0.40}[channel]
+    return alg, channel, float(param)
+
+
+def bytes_per_frame_sweep(code, alg, precision):
+    """Algorithmic bytes of one frame-sweep with the state resident in HBM.  LLR decoders: SURVEY.md 8(d), s(4E + n); fp16 storage
+    (2-byte messages, 4-byte priors): 8E + 4n; erasure decoder: 2-bit messages in bit planes of 32 frames, one summary element per
+    check -- (4E + m + 3n) / 4 bytes (erasure decoder)."""
+    if alg == "BEC":
+        return (4 * code.E + code.m + 3 * code.n) / 4.0
+    if precision == "f16":
+        return 8 * code.E + 4 * code.n
+    return (8 if precision == "f64" else 4) * (4 * code.E + code.n)
+
+
+def param_label(channel, param):
+    return "%.1f dB" % param if channel == "biawgn" else ("p = %g" % param if channel == "bsc" else "eps = %g" % param)
+
+
+def cpu_baseline(code, alg, channel, param, max_iter, precision="f64", budget_s=10.0):
     """CPU baselines on THIS host, on a bounded sample of the same workload (the only leg of this file that touches oracle/):
-      "port"   oracle/bp_oracle.c -- a plain-C port of the reference algorithm, OpenMP over frames, every host thread;
+      "port"   oracle/bp_oracle.c -- a plain-C port of the reference algorithm (min-sum, sum-product, erasure decoder; sparse, so it
+               also runs the codes the reference's dense H cannot hold), OpenMP over frames, every host thread;
       "scipy"  oracle/scipy_baseline.py -- per-frame scipy.sparse decoding, the reference's class of implementation, one
-               process per host core; with the calibration measured where the true reference can run (tests/golden/reference_timing.json:
-               reference frames/s / scipy-baseline frames/s on identical frames) it estimates the reference's own rate on this host."""
+               process per host core (LLR decoders); with the calibration measured where the true reference can run
+               (tests/golden/reference_timing.json: reference frames/s / scipy-baseline frames/s on identical frames) it estimates the
+               reference's own rate on this host."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import multiprocessing as mp
 
@@ -81,56 +128,74 @@ def cpu_baseline(code, snr, max_iter, precision="f64", budget_s=10.0):
 
     g = O.Edges(code.m, code.n, code.edge_chk, code.edge_var)
     cores = os.cpu_count() or 1
-    dt_np = np.float64 if precision == "f64" else np.float32
+    dt_np = np.float64 if precision == "f64" else np.float32  # (fp16 storage has no CPU counterpart: its arithmetic is fp32)
     rng = np.random.RandomState(2024)
-    var = O.biawgn_noise_var(snr)
+    zero = np.zeros(g.n, dtype=np.int64)
 
-    def sample(nf):
-        y = -1 + rng.normal(0, np.sqrt(var), (nf, g.n))
-        return O.biawgn_priors(y, snr).astype(dt_np)
+    def decode(nf):
+        """Draw nf frames of the all-zero word through the channel (not timed), decode them (timed) -> (seconds, iters)."""
+        X = np.broadcast_to(zero, (nf, g.n))
+        if channel == "bec":
+            y = O.bec_send(X, param, rng).astype(np.uint8)
+            t0 = time.time()
+            _, it = C.bec_decode(g, y, max_iter, nthreads=cores)
+        elif channel == "bsc":
+            y = O.bsc_send(X, param, rng)
+            pri = O.bsc_priors(y, param).astype(dt_np)
+            y = y.astype(dt_np)
+            t0 = time.time()
+            _, it = C.bp_decode(g, alg, y, pri, max_iter, dtype=dt_np, nthreads=cores)
+        else:
+            pri = O.biawgn_priors(O.biawgn_send(X, param, rng), param).astype(dt_np)
+            t0 = time.time()
+            _, it = C.bp_decode(g, alg, None, pri, max_iter, dtype=dt_np, nthreads=cores)
+        return time.time() - t0, it
 
-    pri = sample(64 * cores)
-    t0 = time.time()
-    C.bp_decode(g, "MSA", None, pri, max_iter, dtype=dt_np, nthreads=cores)
-    rate = len(pri) / max(time.time() - t0, 1e-6)
-    nf = int(max(64 * cores, min(rate * budget_s, 400000)))
-    pri = sample(nf)
-    t0 = time.time()
-    _, it = C.bp_decode(g, "MSA", None, pri, max_iter, dtype=dt_np, nthreads=cores)
-    dt = time.time() - t0
-    out = {"value": round(nf / dt, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": "%d frames, same H / SNR %.1f dB / max_iter %d, %s C port of the reference algorithm (oracle/bp_oracle.c), "
-                     "%d OpenMP threads, %.1f s, mean %.1f sweeps/frame" % (nf, snr, max_iter, "fp64" if precision == "f64" else "fp32", cores, dt,
+    mem_frames = max(cores, int(2e9 // (16 * g.n)))                  # the sample's arrays stay below ~2 GB whatever n is
+    probe = max(cores, min(64 * cores, 20_000_000 // g.n, mem_frames))
+    rate = probe / max(decode(probe)[0], 1e-6)
+    nf = int(max(probe, min(rate * budget_s, 400000, mem_frames)))
+    dt, it = decode(nf)
+    arith = "erasure decoder (integer)" if alg == "BEC" else ("fp64" if precision == "f64" else "fp32")
+    out = {"value": round(nf / dt, 1), "unit": "frames/s", "cores": cores, "physical_cores": physical_cores(), "kind": "port",
+           "sample": "%d frames, same H / %s over %s at %s / max_iter %d, %s C port of the reference algorithm (oracle/bp_oracle.c), "
+                     "%d OpenMP threads, %.1f s, mean %.1f sweeps/frame" % (nf, alg, channel, param_label(channel, param), max_iter, arith, cores, dt,
                                                                              float(it.mean()))}
+    if alg == "BEC":
+        out["scipy"] = {"skipped": "the scipy.sparse leg restates the LLR decoders (src/bpa.py); the erasure decoder's CPU figure is the C port"}
+        return out
     # per-frame scipy.sparse baseline, one process per core, each decoding its own frame stream for about budget_s seconds
     try:
         procs = cores  # one single-thread process per host core (SURVEY 8(d)); forked BEFORE this process initialises a GPU runtime
+        task = (code.m, code.n, code.edge_chk, code.edge_var, alg, channel, param, max_iter)
         with mp.get_context("fork").Pool(procs) as pool:
             # a short pass of every process sizes the sample (the rate per process UNDER LOAD, not that of one process alone)
-            pool.map(_scipy_probe, [(code.m, code.n, code.edge_chk, code.edge_var, snr, max_iter, 1, 10 + i) for i in range(procs)])  # imports, warm-up
+            pool.map(_scipy_probe, [task + (1, 10 + i) for i in range(procs)])  # imports, warm-up
             t0 = time.time()
-            pool.map(_scipy_probe, [(code.m, code.n, code.edge_chk, code.edge_var, snr, max_iter, 3, 50 + i) for i in range(procs)])
-            per = 3.0 / max(time.time() - t0, 1e-3)
-            frames_each = max(3, int(per * budget_s))
+            pool.map(_scipy_probe, [task + (2, 50 + i) for i in range(procs)])
+            per = 2.0 / max(time.time() - t0, 1e-3)
+            frames_each = max(2, int(per * budget_s))
             t0 = time.time()
-            res = pool.map(_scipy_probe, [(code.m, code.n, code.edge_chk, code.edge_var, snr, max_iter, frames_each, 100 + i) for i in range(procs)])
+            res = pool.map(_scipy_probe, [task + (frames_each, 100 + i) for i in range(procs)])
             wall = time.time() - t0
         frames = sum(r["frames"] for r in res)
-        sc = {"value": round(frames / wall, 2), "unit": "frames/s", "cores": procs, "kind": "scipy",
+        sc = {"value": round(frames / wall, 2), "unit": "frames/s", "cores": procs, "physical_cores": physical_cores(), "kind": "scipy",
               "per_core_frames_per_s": round(frames / wall / procs, 3),
-              "sample": "%d frames (%d per process), same H / SNR %.1f dB / max_iter %d, fp64 per-frame scipy.sparse decoder "
-                        "(oracle/scipy_baseline.py), %d single-thread processes, %.1f s, mean %.1f sweeps/frame" % (
-                            frames, frames_each, snr, max_iter, procs, wall, sum(r["iters"] for r in res) / max(frames, 1))}
+              "sample": "%d frames (%d per process), same H / %s over %s at %s / max_iter %d, fp64 per-frame scipy.sparse decoder "
+                        "(oracle/scipy_baseline.py), %d single-thread processes (one per hardware thread: with SMT the per-process rate is that "
+                        "of a shared core), %.1f s, mean %.1f sweeps/frame" % (
+                            frames, frames_each, alg, channel, param_label(channel, param), max_iter, procs, wall,
+                            sum(r["iters"] for r in res) / max(frames, 1))}
         with open(os.path.join(ROOT, "tests", "golden", "reference_timing.json")) as fp:
             tj = json.load(fp)
         for pt in tj["points"]:
-            if pt["decoder"] == "MSA" and abs(pt["snr_db"] - snr) < 1e-9:
+            if channel == "biawgn" and code.n == 1200 and pt["decoder"] == alg and abs(pt["snr_db"] - param) < 1e-9:
                 sc.update(calibration_reference_over_scipy=round(pt["calibration"], 4),
                           calibration_measured_on="%s, %d frames: reference %.2f frames/s, scipy baseline %.2f frames/s" % (
                               tj["host"], pt["frames"], pt["frames_per_s"], pt["baseline_frames_per_s"]),
                           reference_estimate_frames_per_s=round(frames / wall * pt["calibration"], 2),
                           reference_estimate_note="scipy-baseline rate on this host x calibration: what the reference's own Python would "
-                                                  "reach here with one process per core (it is single-threaded)")
+                                                  "reach here with one process per hardware thread (it is single-threaded)")
         out["scipy"] = sc
     except Exception as e:  # the baseline is a report, never a reason to lose the benchmark line
         out["scipy"] = {"error": repr(e)}
@@ -138,19 +203,24 @@ def cpu_baseline(code, snr, max_iter, precision="f64", budget_s=10.0):
 
 
 def _scipy_probe(task):
-    m, n, chk, var_idx, snr, max_iter, frames, seed = task
+    m, n, chk, var_idx, alg, channel, param, max_iter, frames, seed = task
     os.environ["OMP_NUM_THREADS"] = "1"
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from scipy_baseline import ScipyBP
 
-    dec = ScipyBP(m, n, chk, var_idx, "MSA", max_iter)
+    dec = ScipyBP(m, n, chk, var_idx, alg, max_iter)
     rng = np.random.RandomState(seed)
-    var = 10 ** (-snr / 10)
+    var = 10 ** (-param / 10)
+    llr = np.log(1 - param) - np.log(param) if channel == "bsc" else 0.0
     t0 = time.time()
     iters = 0
     for _ in range(frames):
-        y = -1 + rng.normal(0, np.sqrt(var), n)
-        dec.decode(y, -2 * y / var)
+        if channel == "bsc":  # src/bsc.py:16,21-25
+            y = (rng.random(n) < param).astype(np.int64)
+            dec.decode(y, llr * (1 - 2 * y))
+        else:                 # src/biawgn.py:17-18,28
+            y = -1 + rng.normal(0, np.sqrt(var), n)
+            dec.decode(y, -2 * y / var)
         iters += dec.iterations
     dt = time.time() - t0
     return {"frames": frames, "iters": iters, "frames_per_s": frames / max(dt, 1e-9)}
@@ -161,10 +231,10 @@ def _sync(device, torch):
         torch.cuda.synchronize()
 
 
-def run_point(sim, handle, comm, snr, steps, warmup, batch, stream_id, torch, kernel_pass=True, repeats=1, device="cuda"):
-    """`repeats` timed blocks of `steps` steps at one SNR (uninstrumented, pipelined), then -- separately -- the steps of one block again
-    with the library's HIP-event kernel timing switched on.  Returns dict(seconds (median block), blocks, counters (one block), profile)."""
-    per_round = batch * comm.world
+def run_point(sim, handle, comm, snr, steps, warmup, per_round, stream_id, torch, kernel_pass=True, repeats=1, device="cuda"):
+    """`repeats` timed blocks of `steps` steps at one channel parameter (uninstrumented, pipelined), then -- separately -- the steps of one
+    block again with the library's HIP-event kernel timing switched on.  `per_round` = frames of one step over ALL ranks (each rank
+    decodes its shard of the global frame range).  Returns dict(seconds (median block), blocks, counters (one block), profile)."""
     frame0 = 0
     if kernel_pass:
         handle.set_profiling(False)
@@ -220,8 +290,7 @@ def fused_roofline(kernel_name, frame_sweeps_per_s, cus, counters=None):
         return None
     lds = frame_sweeps_per_s * e["lds_idx_active_per_frame_sweep"] / (cus * NOMINAL_CLOCK_HZ)
     valu = frame_sweeps_per_s * e["valu_active_cycles_per_frame_sweep"] / (cus * 4 * NOMINAL_CLOCK_HZ)
-    bound = "lds" if lds >= valu else "valu"
-    peak = NOMINAL_CLOCK_HZ * cus * 256 / 1e9  # the LDS array is 64 banks x 4 B wide per clock and CU
+    array_peak = NOMINAL_CLOCK_HZ * cus * 256 / 1e9  # the LDS array is 64 banks x 4 B wide per clock and CU
     useful = frame_sweeps_per_s * (e["lds_idx_active_per_frame_sweep"] - e["bank_conflict_per_frame_sweep"]) / (cus * NOMINAL_CLOCK_HZ)
     # the unit of the LDS pipeline that binds an 8-byte-element kernel is the store (issue / transfer) path, not the array the counter above
     # sees: measured load / store instruction counts x per-instruction cycles -- the hardware guide's (2 / 6) and the ones measured on this
@@ -231,11 +300,24 @@ def fused_roofline(kernel_name, frame_sweeps_per_s, cus, counters=None):
                       ("lds_path_cycles_per_frame_sweep_measured_constants", "lds_store_path_frac_measured_constants")):
         if e.get(key):
             path[name] = round(frame_sweeps_per_s * e[key] / (cus * NOMINAL_CLOCK_HZ), 4)
-    if path:
-        path["binding_unit"] = max((("lds_array", lds), ("valu", valu), ("lds_store_path", max(path.values()))), key=lambda t: t[1])[0]
-    return dict(bound=bound, frac=round(max(lds, valu), 4), lds_frac=round(lds, 4), lds_frac_without_bank_conflicts=round(useful, 4), valu_frac=round(valu, 4), **path,
-                achieved=round(lds * peak, 1) if bound == "lds" else round(valu * 100, 2), peak=round(peak, 1) if bound == "lds" else 100.0,
-                unit="GB/s" if bound == "lds" else "% of VALU issue cycles",
+    # `frac` is ONE thing: busy cycles of the BINDING unit / cycles available at 2.4 GHz.  Candidates: the LDS array (SQ_LDS_IDX_ACTIVE), the
+    # LDS issue / transfer path (instruction counts x the hardware guide's per-instruction cycles; the constants measured on this chip stay
+    # a second field), the VALU (issue model on the measured instruction mix).  `achieved` / `peak` are that unit's, so frac == achieved / peak.
+    units = [("lds_array", lds), ("valu", valu)]
+    if "lds_store_path_frac_guide_constants" in path:
+        units.append(("lds_store_path", path["lds_store_path_frac_guide_constants"]))
+    binding, frac = max(units, key=lambda t: t[1])
+    if binding == "lds_array":
+        achieved, peak, unit = lds * array_peak, array_peak, "GB/s"
+    elif binding == "lds_store_path":
+        peak = cus * NOMINAL_CLOCK_HZ / 1e9
+        achieved, unit = frac * peak, "G cycles/s of the LDS issue/transfer path (all CUs)"
+    else:
+        peak = cus * 4 * NOMINAL_CLOCK_HZ / 1e9
+        achieved, unit = frac * peak, "G VALU issue cycles/s (all SIMDs)"
+    return dict(bound="valu" if binding == "valu" else "lds", binding_unit=binding, frac=round(frac, 4), achieved=round(achieved, 1), peak=round(peak, 1), unit=unit,
+                lds_frac=round(lds, 4), lds_array_GBps=round(lds * array_peak, 1), lds_array_peak_GBps=round(array_peak, 1),
+                lds_frac_without_bank_conflicts=round(useful, 4), valu_frac=round(valu, 4), **path,
                 lds_cycles_per_frame_sweep=e["lds_idx_active_per_frame_sweep"], bank_conflict_cycles_per_frame_sweep=e["bank_conflict_per_frame_sweep"],
                 valu_busy_cycles_per_frame_sweep=e["valu_active_cycles_per_frame_sweep"], valu_insts_per_frame_sweep=e["insts_valu_per_frame_sweep"],
                 lds_insts_per_frame_sweep=e["insts_lds_per_frame_sweep"], frame_sweeps_per_s=round(frame_sweeps_per_s, 1),
@@ -261,59 +343,69 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
     if make_handle is None:
         from ldpc_decoders_amd._device import DecoderHandle as make_handle  # noqa: N813
     code = load_code(args.code)
-    handle = make_handle(code, "MSA", args.precision, args.backend)
-    sim = DeviceSimulator(handle, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=min(args.max_iter + 1, 60), device=device)
-    s = 8 if args.precision == "f64" else 4
-    bytes_per_frame_iter = s * (4 * code.E + code.n)
-    f16 = args.precision == "f16"
-    if f16:  # fp16 storage, two-array sweep: 2-byte messages, 4-byte priors -- 2 (4E) + 4n (8(d) prices an all-fp16 path at 2 (4E + n))
-        bytes_per_frame_iter = 8 * code.E + 4 * code.n
+    alg, channel, param = resolve_workload(args.decoder, args.channel, args.param, args.snr)
+    precision = "f32" if alg == "BEC" else args.precision  # the erasure decoder has no floating-point state (2-bit messages in bit planes)
+    points = args.points if args.points is not None else {"biawgn": [2.0, 3.0], "bsc": [0.05], "bec": [0.35]}[channel]
+    hist_bins = min(args.max_iter + 1, 60)  # the in-kernel histogram has 60 bins: sweeps >= 59 share the last one (reported on the line)
+    msa_biawgn = alg == "MSA" and channel == "biawgn"
+    handle = make_handle(code, alg, precision, args.backend)
+    sim = DeviceSimulator(handle, channel, args.max_iter, 0, 0x5EED1200, comm, hist_bins=hist_bins, device=device)
+    s = 8 if precision == "f64" else 4
+    bytes_per_frame_iter = bytes_per_frame_sweep(code, alg, precision)  # SURVEY.md 8(d) for the LLR decoders
+    f16 = precision == "f16"
     side_legs = not args.no_profile and comm.world == 1 and device == "cuda"
     kernel_pass = not args.no_profile and device == "cuda"
+    # frames of one step over all ranks: weak scaling (--batch frames per GPU, the default) or strong (--total-batch frames per step
+    # whatever N is -- BASELINE configs 4 and 5 state their batch for the whole 8-GPU node; a total that N does not divide is split
+    # as evenly as possible by Comm.shard)
+    strong = args.total_batch is not None
+    per_round = int(args.total_batch) if strong else args.batch * comm.world
+    rank_batch = comm.shard(0, per_round)[1]  # this rank's frames per step (rank 0: the largest shard)
 
-    res = run_point(sim, handle, comm, args.snr, args.steps, args.warmup, args.batch, 0, torch, kernel_pass, args.repeats, device)
+    res = run_point(sim, handle, comm, param, args.steps, args.warmup, per_round, 0, torch, kernel_pass, args.repeats, device)
     backend_used, _ = handle.last_stats()
     extra = []
-    for i, snr in enumerate(args.points):
-        r = run_point(sim, handle, comm, snr, max(4, args.steps), 1, args.batch, 1 + i, torch, kernel_pass, 1, device)
+    for i, snr in enumerate(points):
+        r = run_point(sim, handle, comm, snr, max(4, args.steps), 1, per_round, 1 + i, torch, kernel_pass, 1, device)
         extra.append((snr, r))
 
     # HBM-bound reading of the same workload: the streaming backend (state resident in HBM, [tile, edge, 64] layout), N = 1
     stream_res = None
-    if backend_used == "fused" and side_legs:
-        h2 = make_handle(code, "MSA", args.precision, "stream")
-        sim2 = DeviceSimulator(h2, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=min(args.max_iter + 1, 60))
-        stream_res = run_point(sim2, h2, comm, args.snr, 2, 1, args.batch, 0, torch)
+    if backend_used == "fused" and side_legs and msa_biawgn:
+        h2 = make_handle(code, "MSA", precision, "stream")
+        sim2 = DeviceSimulator(h2, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=hist_bins)
+        stream_res = run_point(sim2, h2, comm, param, 2, 1, per_round, 0, torch)
         del sim2, h2
 
-    # Same frames with the priors RESIDENT IN HBM when the timed region starts (channel kernel run beforehand): decode + count
+    # Same frames with the channel output RESIDENT IN HBM when the timed region starts (channel kernel run beforehand): decode + count
     # only, rank 0's shard.  Reported beside `value` (which times the whole hot path: channel + decode + count).
     hbm_leg = None
     if side_legs:
         from ldpc_decoders_amd import _lib
 
-        pri, _y = handle.channel_device("biawgn", args.snr, 0, 0x5EED1200, 0, 0, args.batch)
-        xh, it = handle.decode_device(pri, None, args.max_iter)
+        pri, y0 = handle.channel_device(channel, param, 0, 0x5EED1200, 0, 0, rank_batch)
+        xh, it = handle.decode_device(pri, y0, args.max_iter)
         cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            handle.decode_device(pri, None, args.max_iter, xhat=xh, iters=it)
-            _lib.check(_lib.load().ldpc_count_errors(xh.data_ptr(), None, 0, it.data_ptr(), args.batch, code.n, 0, cnt.data_ptr(), st))
+            handle.decode_device(pri, y0, args.max_iter, xhat=xh, iters=it)
+            _lib.check(_lib.load().ldpc_count_errors(xh.data_ptr(), None, 0, it.data_ptr(), rank_batch, code.n, 0, cnt.data_ptr(), st))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        hbm_leg = {"frames_per_s": round(args.steps * args.batch / dt, 1), "ms_per_step": round(1e3 * dt / args.steps, 3),
+        hbm_leg = {"frames_per_s": round(args.steps * rank_batch / dt, 1), "ms_per_step": round(1e3 * dt / args.steps, 3),
                    "mean_sweeps": round(float(cnt[3]) / float(cnt[0]), 3),
-                   "note": "priors [B,n] %s resident in HBM before the timed region; decode (ldpc_decode) + error counting (ldpc_count_errors)" % args.precision}
-        del pri, xh, it
+                   "note": "%s resident in HBM before the timed region; decode (ldpc_decode) + error counting (ldpc_count_errors)" % (
+                       "received symbols [B,n] u8" if alg == "BEC" else "priors [B,n] %s%s" % (precision, " + received word [B,n] u8" if y0 is not None else ""))}
+        del pri, y0, xh, it
 
     # the fp32 throughput mode of the same workload (statistically identical curves, not bit-identical frame by frame), N = 1
     f32_res = None
-    if args.precision == "f64" and side_legs:
+    if precision == "f64" and side_legs and msa_biawgn:
         h3 = make_handle(code, "MSA", "f32", args.backend)
-        sim3 = DeviceSimulator(h3, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=min(args.max_iter + 1, 60))
-        f32_res = run_point(sim3, h3, comm, args.snr, args.steps, 1, args.batch, 0, torch, True, 3)
+        sim3 = DeviceSimulator(h3, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=hist_bins)
+        f32_res = run_point(sim3, h3, comm, param, args.steps, 1, per_round, 0, torch, True, 3)
         f32_res["backend"] = h3.last_stats()[0]
         f32_res["kernel"] = h3.kernel_name(True) if f32_res["backend"] == "fused" else ""
         del sim3
@@ -321,9 +413,10 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
         # it are decoded again in fp64 -- every counted frame is what the fp64 reference returns for those priors (never `value`)
         exact_res = None
         try:
-            sim4 = DeviceSimulator(h3, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=min(args.max_iter + 1, 60), prior_grid=8)
-            exact_res = run_point(sim4, h3, comm, args.snr, max(4, args.steps // 4), 1, args.batch, 0, torch, False, 1)
+            sim4 = DeviceSimulator(h3, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=hist_bins, prior_grid=8)
+            exact_res = run_point(sim4, h3, comm, param, max(4, args.steps // 4), 1, per_round, 0, torch, False, 1)
             exact_res["redone"], exact_res["steps"] = sim4.redone, max(4, args.steps // 4)
+            exact_res["depth"] = sim4.pipeline_depth()
             del sim4
         except Exception as e:  # a side leg must not cost the benchmark line
             exact_res = {"error": repr(e)}
@@ -332,10 +425,10 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
     # fp16 STORAGE mode of the streaming kernels (2-byte messages, fp32 arithmetic): the same workload, where the headline runs on the
     # streaming kernels in fp32 (codes that do not fit the LDS: config 5).  A tolerance mode -- its own block, never `value`.
     f16_res = None
-    if backend_used == "stream" and args.precision == "f32" and side_legs:
+    if backend_used == "stream" and precision == "f32" and side_legs and msa_biawgn:
         h5 = make_handle(code, "MSA", "f16", "stream")
-        sim5 = DeviceSimulator(h5, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=min(args.max_iter + 1, 60))
-        f16_res = run_point(sim5, h5, comm, args.snr, args.steps, 1, args.batch, 0, torch, True, 1)
+        sim5 = DeviceSimulator(h5, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=hist_bins)
+        f16_res = run_point(sim5, h5, comm, param, args.steps, 1, per_round, 0, torch, True, 1)
         del sim5, h5
 
     def kernel_ms(r):
@@ -346,7 +439,7 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
         frames, iter_sum = int(c[0]), int(c[3])
         fps = frames / r["seconds"]
         per_step = [1e3 * b / steps for b in r["blocks"]]
-        out = {"snr_db": snr, "frames_per_s": round(fps, 1), "ms_per_step": round(1e3 * r["seconds"] / steps, 4),
+        out = {("snr_db" if channel == "biawgn" else "param"): snr, "frames_per_s": round(fps, 1), "ms_per_step": round(1e3 * r["seconds"] / steps, 4),
                "ms_per_step_min": round(min(per_step), 4), "ms_per_step_max": round(max(per_step), 4), "timed_blocks": len(per_step),
                "mean_sweeps": round(iter_sum / max(frames, 1), 3), "wer": round(int(c[1]) / max(frames, 1), 6),
                "ber": float(c[2]) / max(frames * code.n, 1),
@@ -367,7 +460,7 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
 
     if not comm.is_root:
         return None
-    head = summarise(args.snr, res, args.steps)
+    head = summarise(param, res, args.steps)
     c = res["counters"]
     iter_sum_rank0_share = int(c[3]) / comm.world  # the profile is rank 0's; counters are whole-job
     roof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
@@ -406,6 +499,8 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
                 share = {"stream_check_pass": (2 * code.E + code.n) * s, "stream_variable_pass": (code.E + 2 * code.n) * s}
                 if f16:
                     share = {"stream_check_pass": 4 * code.E, "stream_variable_pass": 4 * code.E + 4 * code.n}
+                if alg == "BEC":  # bit planes: check pass E reads + m summary writes, variable pass 3E + 3n, 8-byte elements per 32 frames
+                    share = {"stream_check_pass": (code.E + code.m) / 4.0, "stream_variable_pass": (3 * code.E + 3 * code.n) / 4.0}
                 legs = {}
                 for kname in ("stream_check_pass", "stream_variable_pass"):
                     kms, kl = prof[kname]
@@ -416,30 +511,49 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
                 pair_ms = prof["stream_check_pass"][0] + prof["stream_variable_pass"][0]
                 sweep_gbs = iter_sum_rank0_share * bytes_per_frame_iter / (pair_ms * 1e-3) / 1e9
                 traffic = None
-                pref = "k_cn<" if kind == "stream_check_pass" else "k_vn<"
+                pref = ("k_becs_cn" if kind == "stream_check_pass" else "k_becs_vn<") if alg == "BEC" else \
+                       ("k_cn16<" if kind == "stream_check_pass" else "k_vn16<") if f16 else \
+                       ("k_cn<" if kind == "stream_check_pass" else "k_vn<") + ("double" if s == 8 else "float")
                 for k, v in committed("roofline_counters.json").items():
-                    if k.startswith("hbm:") and (":" + pref + ("double" if s == 8 else "float")) in k and v.get("workload", "").startswith(args.code + " "):
+                    if k.startswith("hbm:") and (":" + pref) in k and v.get("workload", "").startswith(args.code + " "):
                         traffic = v["hbm_bytes_per_launch"]
                 roof = dict(bound="hbm", achieved=round(sweep_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(sweep_gbs / HBM_PEAK_GBS, 4),
-                            algorithmic_bytes_per_frame_sweep=bytes_per_frame_iter, kernel="k_cn + k_vn (one sweep)", passes=legs, traffic=traffic,
-                            note="streaming backend: achieved = executed frame-sweeps x s(4E+n) (SURVEY 8(d)) / HIP-event time of the two passes; "
+                            algorithmic_bytes_per_frame_sweep=bytes_per_frame_iter, passes=legs, traffic=traffic,
+                            kernel="k_becs_cn + k_becs_vn (one sweep)" if alg == "BEC" else "k_cn16 + k_vn16 (one sweep)" if f16 else "k_cn + k_vn (one sweep)",
+                            note="streaming backend: achieved = executed frame-sweeps x algorithmic bytes (SURVEY 8(d): s(4E+n); fp16 storage 8E+4n; "
+                                 "erasure bit planes (4E+m+3n)/4) / HIP-event time of the two passes; "
                                  "`passes` prices each kernel with its own compulsory bytes (check pass: c2v in + out + each marginal once = s(2E+n); "
                                  "variable pass: c2v in + prior in + marginal out = s(E+2n)); `traffic` = PMC HBM bytes per launch of the dominant "
                                  "pass on this code (profiles/roofline_counters.json)", **common)
+    if prof is not None and roof.get("frac") is None and device == "cuda" and backend_used == "stream":
+        # a streaming decode without per-pass HIP events: the WHOLE step (channel + every kernel + host gaps) against the HBM peak
+        gbs = head["algorithmic_GBps"] / comm.world
+        roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                    algorithmic_bytes_per_frame_sweep=bytes_per_frame_iter, kernel="whole step",
+                    note="no per-pass HIP events on this backend: executed frame-sweeps x algorithmic bytes / WALL time of the step")
+    decoder_name = {"MSA": "min-sum", "SPA": "sum-product", "BEC": "erasure decoder"}[alg]
+    channel_name = {"biawgn": "BI-AWGN", "bsc": "BSC", "bec": "BEC"}[channel]
     out = {
         "metric": ("decoded frames/s, n=1200 (3,6) min-sum max_iter=50 (+ roofline of the dominant kernel)"
-                   if args.code == "1200_3_6_rand_ldpc_1" and args.max_iter == 50 else
-                   "decoded frames/s, %s min-sum max_iter=%d (+ roofline of the dominant kernel)" % (args.code, args.max_iter)),
+                   if args.code == "1200_3_6_rand_ldpc_1" and args.max_iter == 50 and msa_biawgn else
+                   "decoded frames/s, %s %s over %s max_iter=%d (+ roofline of the dominant kernel)" % (args.code, decoder_name, channel_name, args.max_iter)),
         "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "ms_per_step_min": head["ms_per_step_min"], "ms_per_step_max": head["ms_per_step_max"],
         "timed_blocks": head["timed_blocks"], "blocks_ms_per_step": [round(1e3 * b / args.steps, 4) for b in res["blocks"]],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 arithmetic, f16 message storage" if f16 else args.precision, "data": "synthetic",
-        "config": {"workload": "%s MSA over BI-AWGN, max_iter=%d, batch=%d frames/GPU, %.1f dB (mean %.2f sweeps/frame), "
-                               "all-zero word + Philox noise on device" % (args.code, args.max_iter, args.batch, args.snr, head["mean_sweeps"]),
-                   "code": args.code, "n": code.n, "m": code.m, "E": code.E, "decoder": "MSA", "channel": "biawgn", "snr_db": args.snr,
-                   "max_iter": args.max_iter, "batch_per_gpu": args.batch, "backend": backend_used,
-                   "parallelism": "frames sharded over %d GPU(s), 1 all-reduce of counters per step, %d steps in flight" % (comm.world, sim.DEPTH)},
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "u64 bit planes (2-bit messages, 32 frames per word pair)" if alg == "BEC" else "f32 arithmetic, f16 message storage" if f16 else precision,
+        "data": "synthetic",
+        "config": {"workload": "%s %s (%s) over %s, max_iter=%d, %s, %s (mean %.2f sweeps/frame), all-zero word + Philox noise on device" % (
+                       args.code, args.decoder if alg != "BEC" else "%s = the ternary erasure decoder of the bec selector" % args.decoder, decoder_name,
+                       channel_name, args.max_iter,
+                       ("batch=%d frames per step over all GPUs" % per_round) if strong else ("batch=%d frames/GPU" % args.batch),
+                       param_label(channel, param), head["mean_sweeps"]),
+                   "code": args.code, "n": code.n, "m": code.m, "E": code.E, "decoder": args.decoder if alg != "BEC" else alg, "channel": channel,
+                   ("snr_db" if channel == "biawgn" else "param"): param,
+                   "max_iter": args.max_iter, "batch_per_gpu": rank_batch if strong else args.batch, "total_batch": per_round, "backend": backend_used,
+                   "sweep_histogram_bins": hist_bins,
+                   "parallelism": "frames sharded over %d GPU(s) by global frame index, 1 all-reduce of counters per step, %d step(s) in flight" % (
+                       comm.world, sim.DEPTH)},
         "mean_sweeps": head["mean_sweeps"], "wer": head["wer"], "ber": head["ber"],
         "frames_counted": int(c[0]), "word_errors": int(c[1]), "bit_errors": int(c[2]),
         "kernel_ms_per_step": head.get("kernel_ms_per_step"), "host_overhead_ms_per_step": head.get("host_overhead_ms_per_step"),
@@ -452,7 +566,7 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
         "points": [summarise(snr, r, max(4, args.steps)) for snr, r in extra],
     }
     if f32_res is not None:
-        f32 = dict(summarise(args.snr, f32_res, args.steps), backend=f32_res["backend"], kernel=f32_res["kernel"],
+        f32 = dict(summarise(param, f32_res, args.steps), backend=f32_res["backend"], kernel=f32_res["kernel"],
                    note="same workload with fp32 message arithmetic (bench.py --precision f32)")
         fp = f32_res["profile"]
         if fp and fp["fused_decode"][1] > 0:
@@ -466,8 +580,8 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
                 "mean_sweeps": round(int(ec[3]) / max(int(ec[0]), 1), 3), "wer": round(int(ec[1]) / max(int(ec[0]), 1), 6),
                 "note": "fp32 LDS kernel (k_fused_bp_grid) on LLRs rounded to multiples of 2^-8 with the in-kernel exactness guard; frames whose "
                         "messages leave the exact range are decoded again in fp64: decisions, iteration counts and counters equal the fp64 "
-                        "reference's on the same priors for EVERY frame (tests/test_gpu_exact_fp32.py).  Synchronous rounds (the redo list is "
-                        "read after each).  Not `value`: the priors differ from the unquantised workload's."}
+                        "reference's on the same priors for EVERY frame (tests/test_gpu_exact_fp32.py).  %d round(s) in flight.  "
+                        "Not `value`: the priors differ from the unquantised workload's." % exact_res.get("depth", 1)}
         elif exact_res is not None:
             out["exact_fp32_mode"] = exact_res
     if f16_res is not None:
@@ -514,7 +628,13 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; ms_per_step is the median block")
-    ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step (weak scaling: the whole job decodes N x this per step)")
+    ap.add_argument("--total-batch", type=int, default=None,
+                    help="frames per step over ALL GPUs (strong scaling: each rank decodes its shard; BASELINE configs 4 / 5 state 2^20 / 2^18 for 8 GPUs)")
+    ap.add_argument("--decoder", default="MSA", choices=["MSA", "SPA", "BEC"], help="decoder selector of the reference's CLI (src/main.py:12, src/utils.py:16)")
+    ap.add_argument("--channel", default="biawgn", choices=["biawgn", "bsc", "bec"],
+                    help="channel selector (src/models.py:3); `bec` pairs with the ternary erasure decoder whatever --decoder says, as in the registry")
+    ap.add_argument("--param", type=float, default=None, help="channel parameter: SNR in dB / crossover probability / erasure probability (default: --snr, 0.07, 0.40)")
     ap.add_argument("--snr", type=float, default=1.0)
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--code", default="1200_3_6_rand_ldpc_1")
@@ -522,7 +642,7 @@ def parse_args(argv=None):
                     help="message arithmetic; f64 is the reference's own (hard decisions bit-identical to it), f32 the throughput mode, f16 = fp16 "
                          "STORAGE of the streaming messages with fp32 arithmetic (codes whose state lives in HBM; a tolerance mode)")
     ap.add_argument("--backend", default="auto", choices=["auto", "stream", "fused"])
-    ap.add_argument("--points", type=float, nargs="*", default=[2.0, 3.0], help="extra SNR points reported under 'points'")
+    ap.add_argument("--points", type=float, nargs="*", default=None, help="extra channel parameters reported under 'points' (default: 2.0 3.0 dB / p = 0.05 / eps = 0.35)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0, help="CPU work per baseline leg (C port, scipy processes)")
     ap.add_argument("--no-profile", action="store_true", help="headline only: skip the HIP-event kernel pass and the side legs")
@@ -535,7 +655,8 @@ def main():
     # leg may fork its workers, and at N > 1 the other ranks simply wait at the rendezvous meanwhile
     cpu_base = None
     if int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu_baseline:
-        cpu_base = cpu_baseline(load_code(args.code), args.snr, args.max_iter, args.precision, args.cpu_baseline_seconds)
+        alg, channel, param = resolve_workload(args.decoder, args.channel, args.param, args.snr)
+        cpu_base = cpu_baseline(load_code(args.code), alg, channel, param, args.max_iter, args.precision, args.cpu_baseline_seconds)
     from ldpc_decoders_amd import dist
 
     comm = dist.init_from_env()

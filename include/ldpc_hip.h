@@ -42,7 +42,9 @@ enum { LDPC_FLAG_NO_EARLY_EXIT = 1 };                                /* NOT refe
  * multiples of 2^-k.  Min-sum only adds, subtracts and compares, so on such priors fp32 arithmetic reproduces the fp64 reference BIT FOR
  * BIT for as long as every message stays below 2^(24-k) / 8; the LDS-resident fp32 kernels check exactly that and count the frames
  * that do not (ldpc_decoder_grid_violations -- a run is exact iff the count is 0).  k = 0..23.
- *   ldpc_simulate / ldpc_decode: flags | LDPC_FLAG_PRIOR_GRID(k)   (simulate: quantises the generated priors AND arms the guard; decode: arms the guard)
+ *   ldpc_simulate / ldpc_decode: flags | LDPC_FLAG_PRIOR_GRID(k)   (simulate: quantises the generated priors AND arms the guard; decode: arms the guard;
+ *                                both return LDPC_E_UNSUPPORTED for an fp32 / fp16 decoder that runs on the streaming kernels, which have no guard;
+ *                                fp64 decoders need none: the flag is a no-op there)
  *   ldpc_channel:                channel | LDPC_CH_PRIOR_GRID(k)   (quantises the LLRs it writes; any dtype) */
 #define LDPC_FLAG_PRIOR_GRID(k) ((((uint32_t)(k)) + 1u) << 8)
 #define LDPC_FLAG_PRIOR_GRID_OF(flags) ((int)(((flags) >> 8) & 0x1fu) - 1) /* -1: off */
@@ -120,15 +122,29 @@ int ldpc_decoder_profile_read(ldpc_decoder_t dec, double* ms4, int64_t* launches
  *   iters_dev   [B]  int32 out: sweeps executed by each frame (0 = left at the iteration-0 check, x_hat = y0) */
 int ldpc_decode(ldpc_decoder_t dec, const void* priors_dev, const uint8_t* y0_dev, int64_t B, int32_t max_iter,
                 uint32_t flags, uint8_t* xhat_dev, int32_t* iters_dev, void* stream);
+/* The same decode with PACKED decisions -- the information BPA.decode returns (src/bpa.py:62: n hard decisions) in n bits instead of n
+ * bytes:
+ *   xhat_bits_dev    [B, W] uint32, W = ceil(n / 32): bit (v & 31) of word (v >> 5) of row f = decision of variable v of frame f
+ *                    (little-endian bit order: np.unpackbits(words.view(np.uint8), bitorder="little")[:, :n] gives the bytes of ldpc_decode);
+ *                    padding bits of the last word are 0
+ *   erased_bits_dev  [B, W] uint32: LDPC_ALG_BEC (required there): bit set = the symbol is still erased (x_hat = 2, src/bec.py:120), its
+ *                    decision bit is then 0.  LLR decoders: may be NULL; written as all-zero when given.
+ * The LLR decoders on the streaming kernels write the words straight from their decision bit planes (no [B,n] byte array exists). */
+int ldpc_decode_bits(ldpc_decoder_t dec, const void* priors_dev, const uint8_t* y0_dev, int64_t B, int32_t max_iter, uint32_t flags,
+                     uint32_t* xhat_bits_dev, uint32_t* erased_bits_dev, int32_t* iters_dev, void* stream);
 /* Same (on whichever backend the decoder uses: streaming or fused), additionally returning the soft output:
  * marginals_dev [B,n] (`dtype`) = the marginal LLRs (prior + sum of check messages, src/bpa.py:35 -- a local of the
  * reference's loop, captured upstream only through its sum_cols hook) of each frame's LAST executed sweep (0 where a
  * frame never swept).  LLR decoders only; B <= 2^17. */
 int ldpc_decode_soft(ldpc_decoder_t dec, const void* priors_dev, const uint8_t* y0_dev, int64_t B, int32_t max_iter,
                      uint32_t flags, uint8_t* xhat_dev, int32_t* iters_dev, void* marginals_dev, void* stream);
-/* Same with host buffers (numpy ndpointer style, as exact.proj_csr); copies in, decodes, copies out, synchronises. */
+/* Same with host buffers (numpy ndpointer style, as exact.proj_csr); copies in, decodes, copies out, synchronises.  The decisions cross
+ * PCIe PACKED (ldpc_decode_bits: n / 8 bytes per frame) and are expanded to bytes on the host. */
 int ldpc_decode_host(ldpc_decoder_t dec, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
                      uint8_t* xhat, int32_t* iters);
+/* Host buffers in, packed decisions out (layout of ldpc_decode_bits; erased_bits required for LDPC_ALG_BEC, optional otherwise). */
+int ldpc_decode_host_bits(ldpc_decoder_t dec, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
+                          uint32_t* xhat_bits, uint32_t* erased_bits, int32_t* iters);
 
 /* Channel.send + LLR for frames [frame0, frame0+B) of the all-`codeword` word, Philox4x32-10 keyed by
  * (seed, stream_id, global frame index) -- biawgn.Channel.send/LLR.decode (src/biawgn.py:13-28),
@@ -149,6 +165,11 @@ int ldpc_channel_words(int channel, int dtype, double param, const uint8_t* code
  * `sent_dev` is the transmitted word [n] or NULL for the all-`codeword` word; iters_dev may be NULL. */
 int ldpc_count_errors(const uint8_t* xhat_dev, const uint8_t* sent_dev, int codeword, const int32_t* iters_dev, int64_t B,
                       int32_t n, int32_t hist_bins, int64_t* counters_dev, void* stream);
+
+/* The same counters from PACKED decisions (ldpc_decode_bits): errors of a frame = popcount((xhat_bits ^ sent) | erased) over its n bits.
+ * sent_bits_dev [W] = the transmitted word, packed, or NULL for the all-`codeword` word; erased_bits_dev may be NULL (LLR decoders). */
+int ldpc_count_errors_bits(const uint32_t* xhat_bits_dev, const uint32_t* erased_bits_dev, const uint32_t* sent_bits_dev, int codeword,
+                           const int32_t* iters_dev, int64_t B, int32_t n, int32_t hist_bins, int64_t* counters_dev, void* stream);
 
 /* The same against one sent word PER FRAME: sent_dev [B,n] (ldpc_channel_words). */
 int ldpc_count_errors_words(const uint8_t* xhat_dev, const uint8_t* sent_dev, const int32_t* iters_dev, int64_t B, int32_t n,

@@ -27,6 +27,16 @@ def current_device():
     return 0
 
 
+def unpack_bits(bits, n, erased=None):
+    """Packed decisions (uint32 / int32 words, numpy) -> bytes [B,n] in {0,1} ({0,1,2} with the erased mask), as ldpc_decode returns them."""
+    words = np.ascontiguousarray(bits).view(np.uint8)
+    x = np.unpackbits(words, axis=1, bitorder="little")[:, :n]
+    if erased is not None:
+        e = np.unpackbits(np.ascontiguousarray(erased).view(np.uint8), axis=1, bitorder="little")[:, :n]
+        x = np.where(e == 1, np.uint8(2), x)
+    return x
+
+
 class CodeHandle:
     def __init__(self, code, device):
         lib = _lib.load()
@@ -120,6 +130,51 @@ class DecoderHandle:
                                    B, int(max_iter), flags, xhat.data_ptr(), iters.data_ptr(), st))
         return xhat, iters
 
+    def decode_device_bits(self, priors, y0, max_iter, flags=0):
+        """``ldpc_decode_bits``: packed decisions.  -> (xhat_bits int32 [B, ceil(n/32)] viewed as uint32 words, erased_bits or None, iters);
+        bit (v & 31) of word (v >> 5) = decision of variable v.  ``unpack_bits`` expands them."""
+        import torch
+
+        ref = y0 if priors is None else priors
+        B, W = ref.shape[0], (self.code.n + 31) // 32
+        bits = torch.empty((B, W), dtype=torch.int32, device=ref.device)
+        era = torch.empty((B, W), dtype=torch.int32, device=ref.device) if self.alg == "BEC" else None
+        iters = torch.empty((B,), dtype=torch.int32, device=ref.device)
+        if B == 0:
+            return bits, era, iters
+        st = torch.cuda.current_stream(ref.device).cuda_stream
+        _lib.check(_lib.load().ldpc_decode_bits(self.h, None if priors is None else priors.data_ptr(), None if y0 is None else y0.data_ptr(),
+                                                B, int(max_iter), flags, bits.data_ptr(), None if era is None else era.data_ptr(),
+                                                iters.data_ptr(), st))
+        return bits, era, iters
+
+    def decode_host_bits(self, priors, y0, max_iter, flags=0):
+        """``ldpc_decode_host_bits``: numpy in, packed decisions out -> (xhat_bits uint32 [B,W], erased_bits uint32 [B,W] or None, iters)."""
+        n = self.code.n
+        W = (n + 31) // 32
+        if self.alg == "BEC":
+            y0 = np.ascontiguousarray(np.atleast_2d(y0), dtype=np.uint8)
+            B, pri_ptr = y0.shape[0], None
+        else:
+            priors = np.ascontiguousarray(np.atleast_2d(priors), dtype=self.np_dtype)
+            B, pri_ptr = priors.shape[0], priors.ctypes.data
+            if y0 is not None:
+                y0 = np.ascontiguousarray(np.atleast_2d(y0), dtype=np.uint8)
+        bits = np.zeros((B, W), dtype=np.uint32)
+        era = np.zeros((B, W), dtype=np.uint32) if self.alg == "BEC" else None
+        iters = np.empty(B, dtype=np.int32)
+        _lib.check(_lib.load().ldpc_decode_host_bits(self.h, pri_ptr, None if y0 is None else y0.ctypes.data, B, int(max_iter), flags,
+                                                     bits.ctypes.data, None if era is None else era.ctypes.data, iters.ctypes.data))
+        return bits, era, iters
+
+    def count_errors_bits(self, bits, era, iters, counters, codeword=0, hist_bins=0):
+        import torch
+
+        st = torch.cuda.current_stream(counters.device).cuda_stream
+        _lib.check(_lib.load().ldpc_count_errors_bits(bits.data_ptr(), None if era is None else era.data_ptr(), None, int(codeword),
+                                                      None if iters is None else iters.data_ptr(), bits.shape[0], self.code.n, hist_bins,
+                                                      counters.data_ptr(), st))
+
     def decode_soft_device(self, priors, y0, max_iter, flags=0):
         """Streaming backend with soft output: returns (xhat, iters, marginals) CUDA tensors."""
         import torch
@@ -178,7 +233,7 @@ class DecoderHandle:
             pri = None if channel == "bec" else torch.empty((nb, n), dtype=dt, device="cuda")
             y = None if channel == "biawgn" else torch.empty((nb, n), dtype=torch.uint8, device="cuda")
             sent = torch.empty((nb, n), dtype=torch.uint8, device="cuda")
-            _lib.check(lib.ldpc_channel_words(_lib.CHANNEL[channel], _lib.DTYPE[self.precision], float(param), self._cb_dev.data_ptr(), K,
+            _lib.check(lib.ldpc_channel_words(_lib.CHANNEL[channel], _lib.IO_DTYPE[self.precision], float(param), self._cb_dev.data_ptr(), K,
                                               int(seed), int(stream_id), int(frame0) + b0, nb, n, None if pri is None else pri.data_ptr(),
                                               None if y is None else y.data_ptr(), sent.data_ptr(), st))
             xhat, iters = self.decode_device(pri, y, max_iter, flags)

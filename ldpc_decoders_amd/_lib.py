@@ -54,6 +54,9 @@ SIGNATURES = {
     "ldpc_decoder_profile_read": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.c_int]),
     "ldpc_decoder_kernel_name": (_c.c_int, [_P, _c.c_int, _c.c_char_p, _c.c_int64]),
     "ldpc_decode": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P, _P]),
+    "ldpc_decode_bits": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P, _P, _P]),
+    "ldpc_decode_host_bits": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P, _P]),
+    "ldpc_count_errors_bits": (_c.c_int, [_P, _P, _P, _c.c_int, _P, _c.c_int64, _c.c_int32, _c.c_int32, _P, _P]),
     "ldpc_decode_soft": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P, _P, _P]),
     "ldpc_decode_host": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int32, _c.c_uint32, _P, _P]),
     "ldpc_channel": (_c.c_int, [_c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_int64,

@@ -1,8 +1,11 @@
 // extern "C" surface of libldpc_hip.so (declared in include/ldpc_hip.h).
+#include <array>
 #include <cstring>
 #include <memory>
 #include <new>
 #include <stdexcept>
+#include <thread>
+#include <vector>
 
 #include "../../include/ldpc_hip.h"
 #include "ldpc_common.hpp"
@@ -77,8 +80,8 @@ int upload(const std::vector<T>& h, T** d) {
 // (three quarters of the first) -- into 80 % of the memory that is free now.  n = 64 800 in fp32 is 1.3 MB of state per frame: 2^17
 // frames would want 297 GB with the repack set; 98 304 take 223 GB.
 int64_t stream_chunk_frames(Decoder* d) {
-    // decided once per decoder (a driver query per call, and a chunking that followed the allocator state of the moment):
-    // the workspaces a decoder reserved stay reserved, so the first answer remains valid for its lifetime
+    // decided once per decoder (a driver query per call would make the chunking follow the allocator state of the moment); when a later
+    // reservation fails all the same -- other allocations took the memory in between -- the caller halves it (decode_dev)
     if (d->stream_chunk > 0) return d->stream_chunk;
     const size_t esz = d->alg == ALG_BEC ? 1 : (d->dtype == DT_F64 ? 8 : 4);
     const double n = (double)d->code->n, E = (double)d->code->E;
@@ -96,6 +99,16 @@ int64_t stream_chunk_frames(Decoder* d) {
     }
     d->stream_chunk = step;
     return step;
+}
+
+// LDPC_FLAG_PRIOR_GRID arms the exactness guard of the LDS-resident fp32 min-sum kernels.  The streaming kernels have no such guard:
+// a call that asks for it there is refused (as ldpc_simulate refuses it) instead of returning frames nobody vouched for.  fp64 decoders
+// need no guard (their arithmetic IS the reference's), the flag is then a no-op.
+int grid_guard_available(const Decoder* d, int bk, uint32_t flags, const char* who) {
+    if (LDPC_FLAG_PRIOR_GRID_OF(flags) < 0 || d->dtype == DT_F64) return LDPC_OK;
+    if (bk == BK_FUSED && d->alg == ALG_MSA) return LDPC_OK;
+    set_error("%s: prior grid: the exactness guard lives in the LDS-resident fp32 min-sum kernels; this decoder runs on the streaming kernels", who);
+    return LDPC_E_UNSUPPORTED;
 }
 
 int pick_backend(Decoder* d) {
@@ -181,7 +194,7 @@ static int guarded(const char* who, F&& f) noexcept {
 extern "C" {
 
 const char* ldpc_last_error(void) { return last_error(); }
-int ldpc_abi_version(void) { return 3; }
+int ldpc_abi_version(void) { return 4; }
 
 int ldpc_device_count(int* count) {
     return guarded("ldpc_device_count", [&]() -> int {
@@ -304,7 +317,7 @@ int ldpc_decoder_destroy(ldpc_decoder_t h) {
         (void)hipSetDevice(d->code->device);
         fused_plan_destroy(d);
         for (DevBuf* b : {&d->msg, &d->marg, &d->marg2, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->gridviol, &d->msg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap, &d->fmap2, &d->rbase, &d->h_in, &d->h_y0, &d->h_out,
-                          &d->h_iters})
+                          &d->h_iters, &d->h_bits, &d->h_era})
             b->release();
         if (d->pinned) (void)hipHostFree(d->pinned);
         if (d->lat_pin) (void)hipHostFree(d->lat_pin);
@@ -395,6 +408,47 @@ int ldpc_decoder_profile_read(ldpc_decoder_t h, double* ms, int64_t* launches, i
     });
 }
 
+// Body of ldpc_decode / ldpc_decode_bits: decisions as bytes [B,n] (xhat) or as packed words [B,W] (bits; erased: the erasure
+// decoder's "still erased" mask).  The LLR decoders on the streaming kernels write the words straight from their decision planes; the
+// LDS-resident kernels and the erasure decoder produce bytes in the decoder's staging buffer, packed by one more kernel.
+static int decode_dev(Decoder* d, const char* who, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags, uint8_t* xhat,
+                      uint32_t* bits, uint32_t* erased, int32_t* iters, hipStream_t st) {
+    LDPC_HIP_TRY(hipSetDevice(d->code->device));
+    const int bk = pick_backend(d);
+    if (bk < 0) return bk;
+    LDPC_TRY(grid_guard_available(d, bk, flags, who));
+    // bound the workspace: at most 2^17 frames per pass through a backend, fewer where the streaming state would not fit the HBM
+    int64_t step = bk == BK_STREAM ? stream_chunk_frames(d) : (int64_t)1 << 17;
+    const size_t esz = d->dtype == DT_F64 ? 8 : 4, n = (size_t)d->code->n, W = (n + 31) / 32;
+    const bool planes_direct = bits && bk == BK_STREAM && d->alg != ALG_BEC;
+    if (bits && !planes_direct) LDPC_TRY(d->h_out.reserve((size_t)(B < step ? B : step) * n));
+    int sweeps = 0;
+    for (int64_t b0 = 0; b0 < B;) {
+        const int64_t nb = (B - b0) < step ? (B - b0) : step;
+        const void* p = priors ? (const char*)priors + (size_t)b0 * n * esz : nullptr;
+        const uint8_t* y = y0 ? y0 + (size_t)b0 * n : nullptr;
+        uint8_t* xh = bits ? (planes_direct ? nullptr : (uint8_t*)d->h_out.p) : xhat + (size_t)b0 * n;
+        d->out_bits = planes_direct ? bits + (size_t)b0 * W : nullptr;
+        int rc = bk == BK_FUSED ? fused_decode(d, p, y, nb, max_iter, flags, xh, iters + b0, nullptr, st)
+                                : stream_decode(d, p, y, nb, max_iter, flags, xh, iters + b0, nullptr, st);
+        d->out_bits = nullptr;
+        if (rc == LDPC_E_NOMEM && bk == BK_STREAM && nb > 64) {
+            // the chunk was sized from the memory that was free when this decoder first asked (stream_chunk_frames); other allocations
+            // since (a twin decoder, torch tensors) may have taken it: halve the chunk -- for this decoder's lifetime -- and try again
+            step = ((nb / 2 + 63) / 64) * 64;
+            d->stream_chunk = step;
+            continue;
+        }
+        if (rc) return rc;
+        if (bits && !planes_direct) LDPC_TRY(pack_bits(xh, nb, (int32_t)n, bits + (size_t)b0 * W, erased ? erased + (size_t)b0 * W : nullptr, st));
+        sweeps = d->last_sweeps > sweeps ? d->last_sweeps : sweeps;
+        b0 += nb;
+    }
+    if (planes_direct && erased) LDPC_HIP_TRY(hipMemsetAsync(erased, 0, (size_t)B * W * 4, st));  // an LLR decoder never leaves a bit erased
+    d->last_sweeps = sweeps;
+    return LDPC_OK;
+}
+
 int ldpc_decode(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
                 uint8_t* xhat, int32_t* iters, void* stream) {
     return guarded("ldpc_decode", [&]() -> int {
@@ -403,25 +457,23 @@ int ldpc_decode(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t
             set_error("ldpc_decode: bad arguments");
             return LDPC_E_ARG;
         }
-        LDPC_HIP_TRY(hipSetDevice(d->code->device));
-        const int bk = pick_backend(d);
-        if (bk < 0) return bk;
-        hipStream_t st = (hipStream_t)stream;
-        // bound the workspace: at most 2^17 frames per pass through a backend, fewer where the streaming state would not fit the HBM
-        const int64_t step = bk == BK_STREAM ? stream_chunk_frames(d) : (int64_t)1 << 17;
-        const size_t esz = d->dtype == DT_F64 ? 8 : 4;
-        int sweeps = 0;
-        for (int64_t b0 = 0; b0 < B; b0 += step) {
-            const int64_t nb = (B - b0) < step ? (B - b0) : step;
-            const void* p = priors ? (const char*)priors + (size_t)b0 * d->code->n * esz : nullptr;
-            const uint8_t* y = y0 ? y0 + (size_t)b0 * d->code->n : nullptr;
-            int rc = bk == BK_FUSED ? fused_decode(d, p, y, nb, max_iter, flags, xhat + (size_t)b0 * d->code->n, iters + b0, nullptr, st)
-                                    : stream_decode(d, p, y, nb, max_iter, flags, xhat + (size_t)b0 * d->code->n, iters + b0, nullptr, st);
-            if (rc) return rc;
-            sweeps = d->last_sweeps > sweeps ? d->last_sweeps : sweeps;
+        return decode_dev(d, "ldpc_decode", priors, y0, B, max_iter, flags, xhat, nullptr, nullptr, iters, (hipStream_t)stream);
+    });
+}
+
+int ldpc_decode_bits(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
+                     uint32_t* xhat_bits, uint32_t* erased_bits, int32_t* iters, void* stream) {
+    return guarded("ldpc_decode_bits", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !xhat_bits || !iters || B < 0) {
+            set_error("ldpc_decode_bits: bad arguments");
+            return LDPC_E_ARG;
         }
-        d->last_sweeps = sweeps;
-        return LDPC_OK;
+        if (d->alg == ALG_BEC && !erased_bits) {
+            set_error("ldpc_decode_bits: the erasure decoder needs erased_bits (a bit it could not resolve is neither 0 nor 1)");
+            return LDPC_E_ARG;
+        }
+        return decode_dev(d, "ldpc_decode_bits", priors, y0, B, max_iter, flags, nullptr, xhat_bits, erased_bits, iters, (hipStream_t)stream);
     });
 }
 
@@ -436,9 +488,132 @@ int ldpc_decode_soft(ldpc_decoder_t h, const void* priors, const uint8_t* y0, in
         LDPC_HIP_TRY(hipSetDevice(d->code->device));
         const int bk = pick_backend(d);
         if (bk < 0) return bk;
+        LDPC_TRY(grid_guard_available(d, bk, flags, "ldpc_decode_soft"));
         if (bk == BK_FUSED) return fused_decode(d, priors, y0, B, max_iter, flags, xhat, iters, marginals, (hipStream_t)stream);
         return stream_decode(d, priors, y0, B, max_iter, flags, xhat, iters, marginals, (hipStream_t)stream);
     });
+}
+
+// packed words -> bytes on the host: 8 decisions per table look-up, rows split over a few threads for large batches
+static void unpack_bits_host(const uint32_t* bits, const uint32_t* era, int64_t B, size_t n, uint8_t* xhat) {
+    static const std::array<uint64_t, 256> lut = [] {
+        std::array<uint64_t, 256> t{};
+        for (int b = 0; b < 256; ++b)
+            for (int k = 0; k < 8; ++k) t[b] |= (uint64_t)((b >> k) & 1) << (8 * k);
+        return t;
+    }();
+    const size_t W = (n + 31) / 32;
+    auto rows = [&](int64_t f0, int64_t f1) {
+        for (int64_t f = f0; f < f1; ++f) {
+            const uint8_t* src = (const uint8_t*)(bits + (size_t)f * W);
+            const uint8_t* se = era ? (const uint8_t*)(era + (size_t)f * W) : nullptr;
+            uint8_t* dst = xhat + (size_t)f * n;
+            size_t v = 0;
+            for (; v + 8 <= n; v += 8) {
+                uint64_t w = lut[src[v >> 3]];
+                if (se) {
+                    const uint64_t e = lut[se[v >> 3]];
+                    w = (w & ~e) | (e << 1);  // erased -> symbol 2
+                }
+                memcpy(dst + v, &w, 8);
+            }
+            for (; v < n; ++v) dst[v] = se && ((se[v >> 3] >> (v & 7)) & 1) ? 2 : (uint8_t)((src[v >> 3] >> (v & 7)) & 1);
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (size_t)B * n < ((size_t)1 << 22) ? 1 : (int)(hw < 2 ? 1 : (hw > 8 ? 8 : hw));
+    if (nt == 1) {
+        rows(0, B);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) pool.emplace_back(rows, B * t / nt, B * (t + 1) / nt);
+    for (std::thread& t : pool) t.join();
+}
+
+// host buffers in, decode on the device, PACKED decisions back over PCIe (n / 8 bytes per frame instead of n); xhat (bytes) and / or
+// xhat_bits + erased_bits (packed) are filled on the host side
+static int decode_host_impl(Decoder* d, ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
+                            uint8_t* xhat, uint32_t* out_bits, uint32_t* out_era, int32_t* iters) {
+    if (B == 0) return LDPC_OK;
+    LDPC_HIP_TRY(hipSetDevice(d->code->device));
+    const size_t n = (size_t)d->code->n, esz = d->dtype == DT_F64 ? 8 : 4, W = (n + 31) / 32;
+    void* dp = nullptr;
+    uint8_t* dy = nullptr;
+    if (d->alg != ALG_BEC && !priors) {
+        set_error("ldpc_decode_host: priors is null");
+        return LDPC_E_ARG;
+    }
+    if (d->alg == ALG_BEC && !y0) {
+        set_error("erasure decoder needs the received symbols (y0)");
+        return LDPC_E_ARG;
+    }
+    // A few frames on the LDS-resident kernels: ONE kernel launch and one event wait.  The kernel reads the priors from, and writes
+    // the decisions to, page-locked host memory mapped into the device (a frame is 5-10 KB: a few microseconds over PCIe, less than
+    // starting a copy engine twice); no allocation, no memset in front of the launch, no device-wide synchronisation.
+    const size_t in_bytes = (size_t)B * n * esz, y_bytes = (size_t)B * n;
+    if (xhat && B <= 64 && in_bytes <= ((size_t)256 << 10) && pick_backend(d) == BK_FUSED && !d->profile) {
+        const size_t off_y = (in_bytes + 255) & ~(size_t)255, off_out = off_y + ((y_bytes + 255) & ~(size_t)255);
+        const size_t off_it = off_out + ((y_bytes + 255) & ~(size_t)255), need = off_it + 64 * sizeof(int32_t);
+        if (d->lat_bytes < need) {
+            if (d->lat_pin) (void)hipHostFree(d->lat_pin);
+            d->lat_pin = nullptr;
+            d->lat_bytes = 0;
+            LDPC_HIP_TRY(hipHostMalloc(&d->lat_pin, need, hipHostMallocMapped));
+            d->lat_bytes = need;
+        }
+        if (!d->lat_stream) LDPC_HIP_TRY(hipStreamCreateWithFlags(&d->lat_stream, hipStreamNonBlocking));
+        if (!d->lat_event) LDPC_HIP_TRY(hipEventCreateWithFlags(&d->lat_event, hipEventDisableTiming));
+        char* hp = (char*)d->lat_pin;
+        void* devp = nullptr;
+        LDPC_HIP_TRY(hipHostGetDevicePointer(&devp, d->lat_pin, 0));
+        char* gp = (char*)devp;
+        if (d->alg != ALG_BEC) memcpy(hp, priors, in_bytes);
+        if (y0) memcpy(hp + off_y, y0, y_bytes);
+        d->after_kernel_event = d->lat_event;
+        const int rc = fused_decode(d, d->alg == ALG_BEC ? nullptr : gp, y0 ? (const uint8_t*)(gp + off_y) : nullptr, B, max_iter, flags,
+                                    (uint8_t*)(gp + off_out), (int32_t*)(gp + off_it), nullptr, d->lat_stream);
+        d->after_kernel_event = nullptr;
+        if (rc) return rc;
+        LDPC_HIP_TRY(hipEventSynchronize(d->lat_event));
+        memcpy(xhat, hp + off_out, y_bytes);
+        memcpy(iters, hp + off_it, (size_t)B * sizeof(int32_t));
+        return LDPC_OK;
+    }
+    if (d->alg != ALG_BEC) {
+        LDPC_TRY(d->h_in.reserve((size_t)B * n * esz));
+        dp = d->h_in.p;
+        LDPC_HIP_TRY(hipMemcpyAsync(dp, priors, (size_t)B * n * esz, hipMemcpyHostToDevice, nullptr));
+    }
+    if (y0) {
+        LDPC_TRY(d->h_y0.reserve((size_t)B * n));
+        dy = (uint8_t*)d->h_y0.p;
+        LDPC_HIP_TRY(hipMemcpyAsync(dy, y0, (size_t)B * n, hipMemcpyHostToDevice, nullptr));
+    }
+    const bool era = d->alg == ALG_BEC;
+    LDPC_TRY(d->h_bits.reserve((size_t)B * W * 4));
+    if (era) LDPC_TRY(d->h_era.reserve((size_t)B * W * 4));
+    LDPC_TRY(d->h_iters.reserve((size_t)B * sizeof(int32_t)));
+    LDPC_TRY(ldpc_decode_bits(h, dp, dy, B, max_iter, flags, (uint32_t*)d->h_bits.p, era ? (uint32_t*)d->h_era.p : nullptr, (int32_t*)d->h_iters.p, nullptr));
+    // packed words land in the caller's buffer if there is one, otherwise in a scratch vector that is unpacked into xhat
+    std::vector<uint32_t> tmp_bits, tmp_era;
+    uint32_t* hb = out_bits;
+    uint32_t* he = out_era;
+    if (!hb) {
+        tmp_bits.resize((size_t)B * W);
+        hb = tmp_bits.data();
+    }
+    if (era && !he) {
+        tmp_era.resize((size_t)B * W);
+        he = tmp_era.data();
+    }
+    LDPC_HIP_TRY(hipMemcpyAsync(hb, d->h_bits.p, (size_t)B * W * 4, hipMemcpyDeviceToHost, nullptr));
+    if (era) LDPC_HIP_TRY(hipMemcpyAsync(he, d->h_era.p, (size_t)B * W * 4, hipMemcpyDeviceToHost, nullptr));
+    else if (he) memset(he, 0, (size_t)B * W * 4);
+    LDPC_HIP_TRY(hipMemcpyAsync(iters, d->h_iters.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
+    LDPC_HIP_TRY(hipStreamSynchronize(nullptr));
+    if (xhat) unpack_bits_host(hb, era ? he : nullptr, B, n, xhat);
+    return LDPC_OK;
 }
 
 int ldpc_decode_host(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
@@ -449,68 +624,19 @@ int ldpc_decode_host(ldpc_decoder_t h, const void* priors, const uint8_t* y0, in
             set_error("ldpc_decode_host: bad arguments");
             return LDPC_E_ARG;
         }
-        if (B == 0) return LDPC_OK;
-        LDPC_HIP_TRY(hipSetDevice(d->code->device));
-        const size_t n = (size_t)d->code->n, esz = d->dtype == DT_F64 ? 8 : 4;
-        void* dp = nullptr;
-        uint8_t* dy = nullptr;
-        if (d->alg != ALG_BEC && !priors) {
-            set_error("ldpc_decode_host: priors is null");
+        return decode_host_impl(d, h, priors, y0, B, max_iter, flags, xhat, nullptr, nullptr, iters);
+    });
+}
+
+int ldpc_decode_host_bits(ldpc_decoder_t h, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,
+                          uint32_t* xhat_bits, uint32_t* erased_bits, int32_t* iters) {
+    return guarded("ldpc_decode_host_bits", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !xhat_bits || !iters || B < 0 || (d->alg == ALG_BEC && !erased_bits)) {
+            set_error("ldpc_decode_host_bits: bad arguments (the erasure decoder needs erased_bits)");
             return LDPC_E_ARG;
         }
-        if (d->alg == ALG_BEC && !y0) {
-            set_error("erasure decoder needs the received symbols (y0)");
-            return LDPC_E_ARG;
-        }
-        // A few frames on the LDS-resident kernels: ONE kernel launch and one event wait.  The kernel reads the priors from, and writes
-        // the decisions to, page-locked host memory mapped into the device (a frame is 5-10 KB: a few microseconds over PCIe, less than
-        // starting a copy engine twice); no allocation, no memset in front of the launch, no device-wide synchronisation.
-        const size_t in_bytes = (size_t)B * n * esz, y_bytes = (size_t)B * n;
-        if (B <= 64 && in_bytes <= ((size_t)256 << 10) && pick_backend(d) == BK_FUSED && !d->profile) {
-            const size_t off_y = (in_bytes + 255) & ~(size_t)255, off_out = off_y + ((y_bytes + 255) & ~(size_t)255);
-            const size_t off_it = off_out + ((y_bytes + 255) & ~(size_t)255), need = off_it + 64 * sizeof(int32_t);
-            if (d->lat_bytes < need) {
-                if (d->lat_pin) (void)hipHostFree(d->lat_pin);
-                d->lat_pin = nullptr;
-                d->lat_bytes = 0;
-                LDPC_HIP_TRY(hipHostMalloc(&d->lat_pin, need, hipHostMallocMapped));
-                d->lat_bytes = need;
-            }
-            if (!d->lat_stream) LDPC_HIP_TRY(hipStreamCreateWithFlags(&d->lat_stream, hipStreamNonBlocking));
-            if (!d->lat_event) LDPC_HIP_TRY(hipEventCreateWithFlags(&d->lat_event, hipEventDisableTiming));
-            char* hp = (char*)d->lat_pin;
-            void* devp = nullptr;
-            LDPC_HIP_TRY(hipHostGetDevicePointer(&devp, d->lat_pin, 0));
-            char* gp = (char*)devp;
-            if (d->alg != ALG_BEC) memcpy(hp, priors, in_bytes);
-            if (y0) memcpy(hp + off_y, y0, y_bytes);
-            d->after_kernel_event = d->lat_event;
-            const int rc = fused_decode(d, d->alg == ALG_BEC ? nullptr : gp, y0 ? (const uint8_t*)(gp + off_y) : nullptr, B, max_iter, flags,
-                                        (uint8_t*)(gp + off_out), (int32_t*)(gp + off_it), nullptr, d->lat_stream);
-            d->after_kernel_event = nullptr;
-            if (rc) return rc;
-            LDPC_HIP_TRY(hipEventSynchronize(d->lat_event));
-            memcpy(xhat, hp + off_out, y_bytes);
-            memcpy(iters, hp + off_it, (size_t)B * sizeof(int32_t));
-            return LDPC_OK;
-        }
-        if (d->alg != ALG_BEC) {
-            LDPC_TRY(d->h_in.reserve((size_t)B * n * esz));
-            dp = d->h_in.p;
-            LDPC_HIP_TRY(hipMemcpyAsync(dp, priors, (size_t)B * n * esz, hipMemcpyHostToDevice, nullptr));
-        }
-        if (y0) {
-            LDPC_TRY(d->h_y0.reserve((size_t)B * n));
-            dy = (uint8_t*)d->h_y0.p;
-            LDPC_HIP_TRY(hipMemcpyAsync(dy, y0, (size_t)B * n, hipMemcpyHostToDevice, nullptr));
-        }
-        LDPC_TRY(d->h_out.reserve((size_t)B * n));
-        LDPC_TRY(d->h_iters.reserve((size_t)B * sizeof(int32_t)));
-        LDPC_TRY(ldpc_decode(h, dp, dy, B, max_iter, flags, (uint8_t*)d->h_out.p, (int32_t*)d->h_iters.p, nullptr));
-        LDPC_HIP_TRY(hipMemcpyAsync(xhat, d->h_out.p, (size_t)B * n, hipMemcpyDeviceToHost, nullptr));
-        LDPC_HIP_TRY(hipMemcpyAsync(iters, d->h_iters.p, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
-        LDPC_HIP_TRY(hipStreamSynchronize(nullptr));
-        return LDPC_OK;
+        return decode_host_impl(d, h, priors, y0, B, max_iter, flags, nullptr, xhat_bits, erased_bits, iters);
     });
 }
 
@@ -562,6 +688,17 @@ int ldpc_count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, co
             return LDPC_E_ARG;
         }
         return count_errors(xhat, sent, codeword, iters, B, n, hist_bins, counters, (hipStream_t)stream);
+    });
+}
+
+int ldpc_count_errors_bits(const uint32_t* xhat_bits, const uint32_t* erased_bits, const uint32_t* sent_bits, int codeword, const int32_t* iters,
+                           int64_t B, int32_t n, int32_t hist_bins, int64_t* counters, void* stream) {
+    return guarded("ldpc_count_errors_bits", [&]() -> int {
+        if (!xhat_bits || !counters || B < 0 || n <= 0 || hist_bins < 0) {
+            set_error("ldpc_count_errors_bits: bad arguments");
+            return LDPC_E_ARG;
+        }
+        return count_errors_bits(xhat_bits, erased_bits, sent_bits, codeword, iters, B, n, hist_bins, counters, (hipStream_t)stream);
     });
 }
 

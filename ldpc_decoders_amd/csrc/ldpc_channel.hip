@@ -155,6 +155,71 @@ __global__ __launch_bounds__(256) void k_count(const uint8_t* __restrict__ xhat,
         if (s_hist[i]) atomicAdd(&counters[4 + i], (unsigned long long)s_hist[i]);
 }
 
+// decisions [B,n] bytes -> packed words [B,W] (bit v & 31 of word v >> 5); `erased` (erasure decoder: symbol 2) optional.  One wave
+// per 64 variables of a frame: two ballots.
+__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ xhat, int64_t B, int n, int W, uint32_t* __restrict__ bits,
+                                                   uint32_t* __restrict__ erased) {
+    const int lane = threadIdx.x & 63;
+    const int nvb = (n + 63) / 64;
+    const int64_t tasks = B * nvb;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tasks; t += (int64_t)gridDim.x * 4) {
+        const int64_t f = t / nvb;
+        const int vb = (int)(t - f * nvb), v = vb * 64 + lane;
+        const uint8_t x = v < n ? xhat[f * n + v] : (uint8_t)0;
+        const unsigned long long one = __ballot(x == 1), era = __ballot(x == 2);
+        if (lane < 2 && 2 * vb + lane < W) {
+            bits[f * W + 2 * vb + lane] = (uint32_t)(lane ? one >> 32 : one);
+            if (erased) erased[f * W + 2 * vb + lane] = (uint32_t)(lane ? era >> 32 : era);
+        }
+    }
+}
+
+// the counters of k_count from packed decisions: errors of a frame = popcount((bits ^ sent) | erased) over its W words
+__global__ __launch_bounds__(256) void k_count_bits(const uint32_t* __restrict__ bits, const uint32_t* __restrict__ erased,
+                                                    const uint32_t* __restrict__ sent, int codeword, const int32_t* __restrict__ iters, int64_t B,
+                                                    int n, int W, int hist_bins, unsigned long long* __restrict__ counters) {
+    extern __shared__ unsigned int s_hist[];  // [hist_bins]
+    __shared__ unsigned long long s_cnt[4];
+    for (int i = threadIdx.x; i < hist_bins; i += 256) s_hist[i] = 0;
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    unsigned long long tot = 0, wec = 0, bec = 0, itsum = 0;
+    for (int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); f < B; f += (int64_t)gridDim.x * 4) {
+        int err = 0;
+        for (int w = lane; w < W; w += 64) {
+            const int left = n - 32 * w;
+            const uint32_t mask = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+            const uint32_t want = sent ? sent[w] : (codeword ? 0xffffffffu : 0u);
+            uint32_t diff = bits[f * W + w] ^ want;
+            if (erased) diff |= erased[f * W + w];
+            err += __popc(diff & mask);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) err += __shfl_xor(err, off, 64);
+        if (lane == 0) {
+            tot += 1;
+            wec += err > 0;
+            bec += (unsigned long long)err;
+            if (iters) {
+                const int it = iters[f];
+                itsum += (unsigned long long)it;
+                if (hist_bins > 0) atomicAdd(&s_hist[it < hist_bins ? it : hist_bins - 1], 1u);
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&s_cnt[0], tot);
+        atomicAdd(&s_cnt[1], wec);
+        atomicAdd(&s_cnt[2], bec);
+        atomicAdd(&s_cnt[3], itsum);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], s_cnt[threadIdx.x]);
+    for (int i = threadIdx.x; i < hist_bins; i += 256)
+        if (s_hist[i]) atomicAdd(&counters[4 + i], (unsigned long long)s_hist[i]);
+}
+
 // 4-byte-per-lane coalesced copy with a known byte count: calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE for the access
 // width the streaming kernels use (MI355X_MICROARCH.md: the counters are only calibrated for 16-byte-per-lane streams)
 __global__ __launch_bounds__(256) void k_copy4(const float* __restrict__ src, float* __restrict__ dst, int64_t nwords) {
@@ -247,6 +312,30 @@ int channel_generate_words(int channel, int dtype, double param, int codeword, c
         set_error("unknown channel id %d", channel);
         return LDPC_E_ARG;
     }
+    LDPC_HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+int pack_bits(const uint8_t* xhat, int64_t B, int32_t n, uint32_t* bits, uint32_t* erased, hipStream_t st) {
+    if (B <= 0) return LDPC_OK;
+    const int64_t want = (B * ((n + 63) / 64) + 3) / 4;
+    const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(k_pack_bits, dim3(grid), dim3(256), 0, st, xhat, B, n, (n + 31) / 32, bits, erased);
+    LDPC_HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+int count_errors_bits(const uint32_t* bits, const uint32_t* erased, const uint32_t* sent_bits, int codeword, const int32_t* iters, int64_t B,
+                      int32_t n, int32_t hist_bins, int64_t* counters, hipStream_t st) {
+    if (B <= 0) return LDPC_OK;
+    if (hist_bins > 8192) {
+        set_error("at most 8192 histogram bins");
+        return LDPC_E_ARG;
+    }
+    const int64_t want = (B + 3) / 4;
+    const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(k_count_bits, dim3(grid), dim3(256), (size_t)hist_bins * sizeof(unsigned int), st, bits, erased, sent_bits, codeword, iters, B,
+                       n, (n + 31) / 32, hist_bins, (unsigned long long*)counters);
     LDPC_HIP_TRY(hipGetLastError());
     return LDPC_OK;
 }

@@ -110,6 +110,10 @@ struct Decoder {
     int last_repacks = 0;  // frame repacks of the last streaming decode
     // exact-in-fp32 mode: device counter of guard events (LDPC_FLAG_PRIOR_GRID, ldpc_decoder_grid_violations)
     DevBuf gridviol;
+    // ldpc_decode_bits: for the duration of that call the streaming kernels write their decisions here as packed words [B, ceil(n/32)]
+    // instead of bytes (null otherwise)
+    uint32_t* out_bits = nullptr;
+    DevBuf h_bits, h_era;  // packed staging of ldpc_decode_host (decisions, erased mask)
     int64_t stream_chunk = 0;  // frames per pass through the streaming kernels (0: not decided yet; ldpc_api.hip stream_chunk_frames)
 };
 
@@ -172,6 +176,11 @@ void admm_destroy(AdmmDecoder* d);
 int admm_last_repacks(const AdmmDecoder* d);
 int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, double eps, int32_t max_iter, double* x_out, int32_t* iters,
                 uint8_t* converged, hipStream_t st);
+
+// packed decisions: bit (v & 31) of word (v >> 5) of frame row f = decision of variable v; W = ceil(n / 32) words per frame
+int pack_bits(const uint8_t* xhat, int64_t B, int32_t n, uint32_t* bits, uint32_t* erased, hipStream_t st);
+int count_errors_bits(const uint32_t* bits, const uint32_t* erased, const uint32_t* sent_bits, int codeword, const int32_t* iters, int64_t B,
+                      int32_t n, int32_t hist_bins, int64_t* counters, hipStream_t st);
 
 int debug_copy4(const void* src, void* dst, int64_t nbytes, hipStream_t st);
 

@@ -210,6 +210,32 @@ ShapeChoice choose_shape(const Code* c, int alg, int dtype) {
 
 // Layout of a chosen shape: a stored plan (a long annealing run done once, ldpc_layout.hpp "plan store") or an annealing run now
 // (`moves` <= 0: $LDPC_FUSED_PLAN_MOVES / $LDPC_FUSED_PLAN_MS / the default), which is then kept in `save_dir` (if not empty).
+// who holds a plan-store lock: "<pid> <host> <boot id> <pid namespace>\n".  A waiter trusts the pid (kill(pid, 0)) only when everything
+// behind it equals its own.
+static std::string read_small_file(const std::string& path) {
+    std::string out;
+    if (FILE* f = fopen(path.c_str(), "r")) {
+        char buf[512];
+        const size_t got = fread(buf, 1, sizeof(buf), f);
+        out.assign(buf, got);
+        fclose(f);
+    }
+    return out;
+}
+static const std::string& lock_identity() {
+    static const std::string id = [] {
+        char host[256] = "?";
+        (void)gethostname(host, sizeof(host) - 1);
+        std::string boot = read_small_file("/proc/sys/kernel/random/boot_id");
+        while (!boot.empty() && (boot.back() == '\n' || boot.back() == ' ')) boot.pop_back();
+        char ns[128] = "?";
+        const ssize_t len = readlink("/proc/self/ns/pid", ns, sizeof(ns) - 1);
+        if (len > 0) ns[len] = 0;
+        return std::to_string((long)getpid()) + " " + host + " " + (boot.empty() ? "?" : boot) + " " + ns + "\n";
+    }();
+    return id;
+}
+
 bool obtain_layout(const Code* c, const ShapeChoice& ch, bool use_store, long moves, const std::string& save_dir, FusedLayout* L) {
     const ShapeEntry& shape = all_shapes()[ch.si];
     const int CR = fused_check_rows(shape);
@@ -237,9 +263,8 @@ bool obtain_layout(const Code* c, const ShapeChoice& ch, bool use_store, long mo
         if (stat(lock.c_str(), &sb) == 0 && time(nullptr) - sb.st_mtime > 600) (void)unlink(lock.c_str());
         const int fd = open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0600);
         if (fd >= 0) {
-            char pidbuf[32];
-            const int len = snprintf(pidbuf, sizeof(pidbuf), "%ld\n", (long)getpid());
-            if (write(fd, pidbuf, (size_t)len) != len) { /* the lock works without the pid; waiters then fall back to its age */ }
+            const std::string me = lock_identity();
+            if (write(fd, me.data(), me.size()) != (ssize_t)me.size()) { /* the lock works without the identity; waiters then fall back to its age */ }
             (void)close(fd);
         } else if (errno == EEXIST) {
             owner = false;
@@ -248,11 +273,12 @@ bool obtain_layout(const Code* c, const ShapeChoice& ch, bool use_store, long mo
                 if (layout_load(save_dir + "/" + name, key, *c, shape.DC, CR, ch.vr, L)) return true;
                 if (stat(lock.c_str(), &sb) != 0) break;  // the lock is gone: published in between (checked below), or the owner died
                 // the owner wrote its pid into the lock: a dead owner is not waited for (it would hold every newcomer for the full wait)
+                // -- but a pid only means something in the owner's own pid namespace on the owner's own boot of the owner's own host (the plan
+                // directory may be shared over NFS or between containers): anywhere else the waiter falls back to the lock's age
                 long pid = 0;
-                if (FILE* lf = fopen(lock.c_str(), "r")) {
-                    if (fscanf(lf, "%ld", &pid) != 1) pid = 0;
-                    fclose(lf);
-                }
+                const std::string theirs = read_small_file(lock);
+                const size_t sp = theirs.find(' ');
+                if (sp != std::string::npos && theirs.substr(sp) == lock_identity().substr(lock_identity().find(' '))) pid = atol(theirs.c_str());
                 if (pid > 0 && kill((pid_t)pid, 0) != 0 && errno == ESRCH) {
                     (void)unlink(lock.c_str());
                     break;
@@ -272,7 +298,8 @@ bool obtain_layout(const Code* c, const ShapeChoice& ch, bool use_store, long mo
         const std::string tmp = save_dir + "/." + name + "." + std::to_string((long)getpid());
         if (layout_save(tmp, key, *c, *L)) (void)rename(tmp.c_str(), (save_dir + "/" + name).c_str());  // atomic: readers never see half a file
     }
-    if (owner && !lock.empty()) (void)unlink(lock.c_str());
+    // remove the lock only if it is still OURS (a waiter that judged us dead may have removed it and a newcomer taken a fresh one)
+    if (owner && !lock.empty() && read_small_file(lock) == lock_identity()) (void)unlink(lock.c_str());
     return false;
 }
 

@@ -483,6 +483,36 @@ __global__ __launch_bounds__(256) void k_unpack(const u64* __restrict__ xbits, u
     for (int f = 0; f < fmax; ++f) xhat[(f0 + f) * n + v] = (uint8_t)((one >> f) & 1ull);
 }
 
+// planes -> PACKED decisions [B, W] u32 (bit v & 31 of word v >> 5 = decision of variable v; W = ceil(n / 32)): the form
+// ldpc_decode_bits returns (SURVEY 8(a2) "packed x_hat bits").  One wave per (tile, 64 variables): the 64 x 64 bit block is
+// transposed with 64 ballots (lane = variable on the way in, lane = frame on the way out).
+__global__ __launch_bounds__(256) void k_unpack_bits(const u64* __restrict__ xbits, uint32_t* __restrict__ bits, int64_t B, int n, int W,
+                                                     const int32_t* __restrict__ frame_of) {
+    const int tile = blockIdx.y, lane = threadIdx.x;
+    const int vb = blockIdx.x * 4 + threadIdx.y, v0 = vb * 64;
+    if (v0 >= n) return;
+    const u64 col = v0 + lane < n ? xbits[plane_at(tile, v0 + lane, n)] : 0ull;
+    u64 row = 0;
+    for (int f = 0; f < 64; ++f) {
+        const u64 b = __ballot((col >> f) & 1ull);
+        if (lane == f) row = b;
+    }
+    const int64_t fr = frame_of ? (int64_t)frame_of[(int64_t)tile * 64 + lane] : (int64_t)tile * 64 + lane;
+    if (fr >= 0 && fr < B) {
+        uint32_t* out = bits + fr * W + 2 * vb;
+        out[0] = (uint32_t)row;
+        if (2 * vb + 1 < W) out[1] = (uint32_t)(row >> 32);
+    }
+}
+
+// decisions of the frames of `tiles` tiles in the form the caller asked for: bytes [B,n] (ldpc_decode) or packed words (ldpc_decode_bits)
+void launch_unpack(const Decoder* d, const u64* xbits, uint8_t* xhat, int64_t B, int n, int tiles, const int32_t* fmap, hipStream_t st) {
+    if (d->out_bits)
+        hipLaunchKernelGGL(k_unpack_bits, dim3(((n + 63) / 64 + 3) / 4, tiles), dim3(64, 4), 0, st, xbits, d->out_bits, B, n, (n + 31) / 32, fmap);
+    else
+        hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256, tiles), dim3(256), 0, st, xbits, xhat, B, n, fmap);
+}
+
 int pick_pow2_ge(int x, int lo, int hi) {
     int p = lo;
     while (p < x && p < hi) p <<= 1;
@@ -728,7 +758,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                         const int nt = (lf + 63) / 64;
                         const int nx = 1 - cur;
                         // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs later)
-                        hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256, cur_tiles), dim3(256), 0, st, xbits, xhat, B, n, fmap);
+                        launch_unpack(d, xbits, xhat, B, n, cur_tiles, fmap, st);
                         hipLaunchKernelGGL(k_repack_plan, dim3(1), dim3(1024), 0, st, live, cur_tiles, (int32_t*)d->rbase.p);
                         const int rows_per_wave = 128;
                         const int chunks = (int)((E + n + rows_per_wave - 1) / rows_per_wave);
@@ -770,7 +800,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
         ++sweeps;
     }
     hipLaunchKernelGGL(k_finish_iters, dim3(cur_tiles), dim3(64), 0, st, live, iters, B, sweeps, fmap);
-    hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256, cur_tiles), dim3(256), 0, st, xbits, xhat, B, n, fmap);
+    launch_unpack(d, xbits, xhat, B, n, cur_tiles, fmap, st);
     if (soft_out)
         hipLaunchKernelGGL(k_soft_out<T>, dim3((n + 3) / 4, tiles), dim3(256), 0, st, marg, (T*)soft_out, B, n);
     LDPC_HIP_TRY(hipGetLastError());
@@ -994,7 +1024,15 @@ __global__ __launch_bounds__(256) void k_vn16(const int32_t* __restrict__ col_pt
                     sy += c[u][j].y;
                 }
             const float2 marg = make_float2(pr[u].x + sx, pr[u].y + sy);
-            if (mt) mt[(int64_t)(vbase + u) * 64] = marg;
+            if (mt) {  // soft output (diagnostic path): a frame that has left keeps the marginal of ITS last sweep, as the fp32 / fp64 kernels do
+                float2 w = marg;
+                if (lva != ~0ull || lvb != ~0ull) {
+                    const float2 old = mt[(int64_t)(vbase + u) * 64];
+                    if (!((lva >> lane) & 1ull)) w.x = old.x;
+                    if (!((lvb >> lane) & 1ull)) w.y = old.y;
+                }
+                mt[(int64_t)(vbase + u) * 64] = w;
+            }
 #pragma unroll
             for (int j = 0; j < DVMAX; ++j)
                 if (FIXED_DV > 0 || j < deg[u]) msg16_st<ALG>(vt + (int64_t)(p0[u] + j) * 64, marg.x - c[u][j].x, marg.y - c[u][j].y);
@@ -1011,8 +1049,8 @@ __global__ __launch_bounds__(256) void k_vn16(const int32_t* __restrict__ col_pt
     }
 }
 
-// marginal pair-tile [n][64] float2 -> [B,n] (diagnostic / tolerance tests; frames that have left keep evolving in this mode, so the
-// soft output is meaningful for runs without early exit)
+// marginal pair-tile [n][64] float2 -> [B,n] (diagnostic / tolerance tests; the MESSAGES of a frame that has left keep evolving in this
+// mode, its stored marginal and decisions do not: k_vn16 masks both by the live words)
 __global__ void k_soft_out16(const float2* __restrict__ soft_t, float* __restrict__ out, int64_t B, int n) {
     const int P = blockIdx.y, lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1130,6 +1168,7 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
     LDPC_HIP_TRY(hipMemsetAsync(tflags, 0, (size_t)2 * pairs * 16 + 64, st));
     LDPC_HIP_TRY(hipMemsetAsync(live, 0, (size_t)2 * pairs * 8, st));
     LDPC_HIP_TRY(hipMemsetAsync(iters, 0, (size_t)B * sizeof(int32_t), st));
+    if (marg) LDPC_HIP_TRY(hipMemsetAsync(marg, 0, (size_t)pairs * n * 64 * sizeof(float2), st));  // frames that never sweep report 0
     if (sim) {
         const int bpf = (n + 3) / 4, bpw = 16;
         hipLaunchKernelGGL(k_biawgn_tile16, dim3(((bpf + bpw - 1) / bpw + 3) / 4, pairs), dim3(64, 4), 0, st, *sim, B, n, bpf, bpw, prior);
@@ -1178,7 +1217,7 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
                 if (repack_ok && it > 0 && lt >= 2 && (double)lf <= repack_fill * 64.0 * lt && it + 1 < cap) {
                     const int nt = (lf + 63) / 64, np = (nt + 1) / 2, nx = 1 - cur;
                     // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs at the end)
-                    hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256, tiles), dim3(256), 0, st, xbits, xhat, B, n, (const int32_t*)fmap);
+                    launch_unpack(d, xbits, xhat, B, n, tiles, fmap, st);
                     hipLaunchKernelGGL(k_repack_plan, dim3(1), dim3(1024), 0, st, live, tiles, (int32_t*)d->rbase.p);
                     const int rows_per_wave = 128;
                     const int chunks = (int)((E + n + rows_per_wave - 1) / rows_per_wave);
@@ -1239,7 +1278,7 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
         ++sweeps;
     }
     hipLaunchKernelGGL(k_finish_iters, dim3(tiles), dim3(64), 0, st, live, iters, B, sweeps, (const int32_t*)fmap);
-    hipLaunchKernelGGL(k_unpack, dim3((n + 255) / 256, tiles), dim3(256), 0, st, xbits, xhat, B, n, (const int32_t*)fmap);
+    launch_unpack(d, xbits, xhat, B, n, tiles, fmap, st);
     if (soft_out) hipLaunchKernelGGL(k_soft_out16, dim3((n + 3) / 4, pairs), dim3(256), 0, st, marg, soft_out, B, n);  // (no repack with a soft output)
     LDPC_HIP_TRY(hipGetLastError());
     if (d->profile) {

@@ -118,10 +118,12 @@ class OracleHandle:
         return ""
 
 
-args = bench.parse_args(["--gpus", os.environ["WORLD_SIZE"], "--steps", "3", "--warmup", "1", "--repeats", "2", "--batch", str(768 // int(os.environ["WORLD_SIZE"])),
-                         "--code", "7_4_hamming", "--snr", "2.0", "--max-iter", "10", "--points", "--no-profile", "--cpu-baseline-seconds", "0.2"])
+batch_flags = %(batch_flags)s  # weak: --batch (768 / N per rank); strong: --total-batch (one fixed total, split by Comm.shard)
+args = bench.parse_args(["--gpus", os.environ["WORLD_SIZE"], "--steps", "3", "--warmup", "1", "--repeats", "2"] + batch_flags +
+                        ["--code", "7_4_hamming", "--snr", "2.0", "--max-iter", "10", "--points", "--no-profile", "--cpu-baseline-seconds", "0.2"])
 # as bench.main(): rank 0 times the CPU baselines BEFORE it joins the process group (the other ranks wait at the rendezvous)
-cpu_base = bench.cpu_baseline(bench.load_code(args.code), args.snr, args.max_iter, args.precision, args.cpu_baseline_seconds) if os.environ["RANK"] == "0" else None
+alg, channel, param = bench.resolve_workload(args.decoder, args.channel, args.param, args.snr)
+cpu_base = bench.cpu_baseline(bench.load_code(args.code), alg, channel, param, args.max_iter, args.precision, args.cpu_baseline_seconds) if os.environ["RANK"] == "0" else None
 comm = dist.init_from_env(prefer_gpu=False)
 out = bench.run_bench(args, comm, make_handle=OracleHandle, device="cpu", cpu_base=cpu_base)
 if out is not None:
@@ -131,9 +133,10 @@ dist.finalize()
 '''
 
 
-def _run_bench_layer(world, tmp_path, port):
-    code = BENCH_WORKER % {"root": ROOT}
-    base = str(tmp_path / ("bench_w%d" % world))
+def _run_bench_layer(world, tmp_path, port, total_batch=None):
+    flags = ["--total-batch", str(total_batch)] if total_batch is not None else ["--batch", str(768 // world)]
+    code = BENCH_WORKER % {"root": ROOT, "batch_flags": repr(flags)}
+    base = str(tmp_path / ("bench_w%d_%s" % (world, total_batch)))
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
@@ -177,3 +180,35 @@ def test_bench_driver_layer_on_eight_ranks(tmp_path):
             assert stream == logs1[0][i][0] and start == pos and cnt == 96
             pos += cnt
         assert pos == logs1[0][i][1] + 768
+
+
+@pytest.mark.timeout(900)
+def test_bench_strong_scaling_split_on_1_2_4_8_ranks(tmp_path):
+    """`bench.py --total-batch T` (BASELINE configs 4 and 5 state their batch for the whole 8-GPU node): ONE fixed total per step, each rank
+    its shard -- T = 763 is divisible by none of 2, 4, 8.  Whole-job counters must be identical for every N; the shards tile every round."""
+    T = 763
+    got = {}
+    for i, world in enumerate((1, 2, 4, 8)):
+        lines, logs = _run_bench_layer(world, tmp_path, 29631 + i, total_batch=T)
+        assert len(lines) == 1
+        got[world] = (json.loads(lines[0]), logs)
+    one = got[1][0]
+    assert one["frames_counted"] == 3 * T and one["scaling"] == "strong" and one["config"]["total_batch"] == T
+    for world in (2, 4, 8):
+        line, logs = got[world]
+        assert line["n_gpus"] == world and line["scaling"] == "strong" and line["config"]["total_batch"] == T
+        assert line["config"]["batch_per_gpu"] == -(-T // world)   # rank 0 holds the largest shard
+        for k in ("frames_counted", "word_errors", "bit_errors", "mean_sweeps", "wer", "ber"):
+            assert one[k] == line[k], (world, k)
+        assert line["collective"]["ranks_seen"] == world and line["cpu_baseline"]["value"] > 0
+        rounds = len(logs[0])
+        assert rounds == 1 + 2 * 3
+        for i in range(rounds):
+            stream1, start1, cnt1 = got[1][1][0][i]
+            assert cnt1 == T
+            pos = start1
+            for r in range(world):
+                stream, start, cnt = logs[r][i]
+                assert stream == stream1 and start == pos and cnt in (T // world, T // world + 1)
+                pos += cnt
+            assert pos == start1 + T

@@ -32,7 +32,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), "symbol %s declared in include/ldpc_hip.h but not exported" % name
     # the ctypes binding covers the same set
     assert set(_lib.SIGNATURES) == set(names)
-    assert _lib.load().ldpc_abi_version() == 3
+    assert _lib.load().ldpc_abi_version() == 4
 
 
 def test_argument_errors_are_reported_not_thrown():
