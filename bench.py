@@ -243,6 +243,7 @@ def run_point(sim, handle, comm, snr, steps, warmup, per_round, stream_id, torch
         frame0 += per_round
     first = frame0
     blocks, tot = [], None
+    rpl = sim.rounds_per_launch() if hasattr(sim, "rounds_per_launch") else 1
     for _rep in range(max(1, repeats)):
         frame0 = first  # every block decodes the same frames: identical work, identical counters
         tot = np.zeros(4 + sim.hist_bins, dtype=np.int64)
@@ -250,7 +251,20 @@ def run_point(sim, handle, comm, snr, steps, warmup, per_round, stream_id, torch
         _sync(device, torch)
         t0 = time.perf_counter()
         inflight = []
-        for _ in range(steps):
+        if rpl > 1:
+            # the erasure decoder's rounds are 0.2 ms launches: up to `rpl` steps travel in ONE launch, each step with its own counter row
+            # (ldpc_simulate_rounds) -- the same K steps, the same frames, the same per-step counters
+            left = steps
+            while left > 0:
+                if len(inflight) == sim.DEPTH:
+                    tot += sim.finish_rounds(inflight.pop(0)).sum(axis=0)
+                r = min(rpl, left)
+                inflight.append(sim.launch_rounds(snr, stream_id, frame0, per_round, r))
+                frame0 += per_round * r
+                left -= r
+            while inflight:
+                tot += sim.finish_rounds(inflight.pop(0)).sum(axis=0)
+        for _ in range(steps if rpl == 1 else 0):
             if len(inflight) == sim.DEPTH:
                 tot += sim.finish_round(inflight.pop(0))
             inflight.append(sim.launch_round(snr, stream_id, frame0, per_round))
@@ -265,9 +279,15 @@ def run_point(sim, handle, comm, snr, steps, warmup, per_round, stream_id, torch
         handle.set_profiling(True)
         handle.read_profile(reset=True)
         f = first
-        for _ in range(steps):
-            sim.run_round(snr, stream_id, f, per_round)
-            f += per_round
+        left = steps
+        while left > 0:  # the same launches as the timed region (several steps per launch where the decoder takes them), one at a time
+            r = min(rpl, left)
+            if rpl > 1:
+                sim.finish_rounds(sim.launch_rounds(snr, stream_id, f, per_round, r))
+            else:
+                sim.run_round(snr, stream_id, f, per_round)
+            f += per_round * r
+            left -= r
         prof = handle.read_profile(reset=True)
         handle.set_profiling(False)
     return dict(seconds=statistics.median(blocks), blocks=blocks, counters=tot, profile=prof)
@@ -551,7 +571,7 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
                    "code": args.code, "n": code.n, "m": code.m, "E": code.E, "decoder": args.decoder if alg != "BEC" else alg, "channel": channel,
                    ("snr_db" if channel == "biawgn" else "param"): param,
                    "max_iter": args.max_iter, "batch_per_gpu": rank_batch if strong else args.batch, "total_batch": per_round, "backend": backend_used,
-                   "sweep_histogram_bins": hist_bins,
+                   "sweep_histogram_bins": hist_bins, "steps_per_launch": sim.rounds_per_launch() if hasattr(sim, "rounds_per_launch") else 1,
                    "parallelism": "frames sharded over %d GPU(s) by global frame index, 1 all-reduce of counters per step, %d step(s) in flight" % (
                        comm.world, sim.DEPTH)},
         "mean_sweeps": head["mean_sweeps"], "wer": head["wer"], "ber": head["ber"],

@@ -227,6 +227,16 @@ int ldpc_simulate(ldpc_decoder_t dec, int channel, double param, int codeword, u
                   uint64_t frame0, int64_t B, int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters_dev,
                   void* stream);
 
+/* `rounds` passes of ldpc_simulate in ONE call: round r decodes frames frame0 + r * round_stride + [0, B) (round_stride >= B: the
+ * distance between the rounds of one rank when a round of the whole job is sharded over ranks; = B on a single GPU) and accumulates into
+ * its own counter row counters_dev + r * (4 + hist_bins).  Each row is exactly what ldpc_simulate would have produced for that round --
+ * the caller applies the stopping rule of `while wec < min_wec` (src/main.py:37) to the rows in order, so the counters stay a function
+ * of the round size, not of how many rounds travelled together.  The LDS-resident erasure decoder runs all rounds as ONE launch (its
+ * frame positions are refilled across round boundaries, no drain between rounds); every other decoder is called round by round. */
+int ldpc_simulate_rounds(ldpc_decoder_t dec, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0,
+                         int64_t B, int32_t rounds, uint64_t round_stride, int32_t max_iter, uint32_t flags, int32_t hist_bins,
+                         int64_t* counters_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,6 +214,28 @@ class DecoderHandle:
         _lib.check(_lib.load().ldpc_simulate(self.h, _lib.CHANNEL[channel], float(param), int(codeword), int(seed), int(stream_id),
                                              int(frame0), int(B), int(max_iter), flags, hist_bins, counters.data_ptr(), st))
 
+    def simulate_rounds(self, channel, param, codeword, seed, stream_id, frame0, B, rounds, round_stride, max_iter, counters, flags=0, hist_bins=0):
+        """``rounds`` passes of ``simulate`` in one call (``ldpc_simulate_rounds``): round r decodes frames frame0 + r * round_stride + [0, B)
+        into row r of ``counters`` (CUDA int64 [rounds, 4 + hist_bins], accumulated into).  The LDS-resident erasure decoder runs them as
+        ONE launch; every row equals what ``simulate`` gives for that round."""
+        import torch
+
+        assert counters.shape == (rounds, 4 + hist_bins) and counters.is_contiguous()
+        st = torch.cuda.current_stream(counters.device).cuda_stream
+        if int(codeword) == -1:
+            for r in range(rounds):
+                self._simulate_random_words(channel, param, seed, stream_id, frame0 + r * round_stride, B, max_iter, counters[r], flags, hist_bins, st)
+            return
+        _lib.check(_lib.load().ldpc_simulate_rounds(self.h, _lib.CHANNEL[channel], float(param), int(codeword), int(seed), int(stream_id),
+                                                    int(frame0), int(B), int(rounds), int(round_stride), int(max_iter), flags, hist_bins,
+                                                    counters.data_ptr(), st))
+
+    def rounds_per_launch(self):
+        """How many Monte-Carlo rounds are worth sending in one ``simulate_rounds`` call: 8 for the LDS-resident erasure decoder (its frame
+        positions are refilled across round boundaries; a 65 536-frame round alone is a 0.23 ms launch that mostly ramps up and drains),
+        1 for everything else (their rounds are milliseconds long)."""
+        return 8 if self.alg == "BEC" and self.backend != "stream" and self.fused_info()["waves_per_frame"] > 0 else 1
+
     def _simulate_random_words(self, channel, param, seed, stream_id, frame0, B, max_iter, counters, flags, hist_bins, st):
         """``--codeword -1`` (src/main.py:38): every frame sends a random word of the code book (small codes only, as upstream).  A
         composition on the device -- channel kernel (picks the word, adds the noise) -> decode -> count against the sent words."""

@@ -68,6 +68,8 @@ SIGNATURES = {
     "ldpc_debug_copy4": (_c.c_int, [_P, _P, _c.c_int64, _P]),
     "ldpc_simulate": (_c.c_int, [_P, _c.c_int, _c.c_double, _c.c_int, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_int64,
                                  _c.c_int32, _c.c_uint32, _c.c_int32, _P, _P]),
+    "ldpc_simulate_rounds": (_c.c_int, [_P, _c.c_int, _c.c_double, _c.c_int, _c.c_uint64, _c.c_uint64, _c.c_uint64, _c.c_int64, _c.c_int32,
+                                        _c.c_uint64, _c.c_int32, _c.c_uint32, _c.c_int32, _P, _P]),
     "ldpc_ml_create": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int32, _c.POINTER(_P)]),
     "ldpc_ml_destroy": (_c.c_int, [_P]),
     "ldpc_ml_decode": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.POINTER(_c.c_double), _P, _c.c_int64, _P, _P, _P, _P, _P, _P, _P]),

@@ -702,10 +702,10 @@ int ldpc_count_errors_bits(const uint32_t* xhat_bits, const uint32_t* erased_bit
     });
 }
 
-int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id,
-                  uint64_t frame0, int64_t B, int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters,
-                  void* stream) {
-    return guarded("ldpc_simulate", [&]() -> int {
+static int simulate_impl(ldpc_decoder_t h, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id,
+                         uint64_t frame0, int64_t B, int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters,
+                         void* stream) {
+    {
         Decoder* d = (Decoder*)h;
         if (!d || !counters || B < 0) {
             set_error("ldpc_simulate: bad arguments");
@@ -765,6 +765,39 @@ int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uin
             LDPC_TRY(count_errors((uint8_t*)d->h_out.p, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters,
                                   st));
         }
+        return LDPC_OK;
+    }
+}
+
+int ldpc_simulate(ldpc_decoder_t h, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id,
+                  uint64_t frame0, int64_t B, int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters,
+                  void* stream) {
+    return guarded("ldpc_simulate", [&]() -> int {
+        return simulate_impl(h, channel, param, codeword, seed, stream_id, frame0, B, max_iter, flags, hist_bins, counters, stream);
+    });
+}
+
+int ldpc_simulate_rounds(ldpc_decoder_t h, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0,
+                         int64_t B, int32_t rounds, uint64_t round_stride, int32_t max_iter, uint32_t flags, int32_t hist_bins,
+                         int64_t* counters, void* stream) {
+    return guarded("ldpc_simulate_rounds", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !counters || B < 0 || rounds < 0 || hist_bins < 0 || (rounds > 1 && round_stride < (uint64_t)B)) {
+            set_error("ldpc_simulate_rounds: bad arguments (rounds must not overlap: round_stride >= B)");
+            return LDPC_E_ARG;
+        }
+        if (B == 0 || rounds == 0) return LDPC_OK;
+        // one launch for all rounds where the kernel refills its frame positions across round boundaries (the erasure Monte-Carlo kernel)
+        if (rounds > 1 && channel == CH_BEC && d->alg == ALG_BEC && d->backend != BK_STREAM && (codeword == 0 || codeword == 1) &&
+            fused_simulate_rounds_supported(d) && fused_simulate_supported(d, channel, param, hist_bins) && LDPC_FLAG_PRIOR_GRID_OF(flags) < 0 &&
+            (B + 31) / 32 * (int64_t)rounds < ((int64_t)1 << 31)) {
+            LDPC_HIP_TRY(hipSetDevice(d->code->device));
+            return fused_simulate(d, channel, param, codeword, seed, stream_id, frame0, B, max_iter, flags, hist_bins, counters, (hipStream_t)stream,
+                                  rounds, round_stride);
+        }
+        for (int32_t r = 0; r < rounds; ++r)  // every other decoder: round by round
+            LDPC_TRY(simulate_impl(h, channel, param, codeword, seed, stream_id, frame0 + (uint64_t)r * round_stride, B, max_iter, flags, hist_bins,
+                                   counters + (size_t)r * (size_t)(4 + hist_bins), stream));
         return LDPC_OK;
     });
 }

@@ -72,7 +72,8 @@ constexpr int BSYS_ZERO = 0;     // {0,0}: summary read by a missing edge of a v
 constexpr int BSYS_KNOWN0 = 2;   // {~0,0}: message read by a missing edge of a short check row: a known 0, neutral for erasure count and parity
 constexpr int BSYS_TICKET = 4;
 constexpr int BSYS_VERDICT = 8;  // four words per wave: frame masks (changed, erased, wrong); NW <= 8
-constexpr int BSYS_HIST = 64;    // Monte-Carlo kernel: histogram of executed sweeps, up to 64 bins
+constexpr int BSYS_HIST = 64;    // Monte-Carlo kernel: histogram of executed sweeps, up to 64 bins; the second accumulator slot's histogram
+                                 // follows in the row behind the system row (words 128..191)
 
 template <int DC_, int DV_, int CRW_, int VRW_, int NW_, int VRX_, int DVX_, bool MC_ = false>
 struct BecShape {
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? (NW == 4 ? 4 : 2) : 2) void k_fu
         *sysw(BSYS_KNOWN0) = ~0u;
         *sysw(BSYS_KNOWN0 + 1) = 0u;
     }
-    if (threadIdx.x < 64) *sysw(BSYS_HIST + (int)threadIdx.x) = 0u;
+    for (int i = (int)threadIdx.x; i < 128; i += 64 * NW) *sysw(BSYS_HIST + i) = 0u;
     const uint32_t lane8 = (uint32_t)lane * 8u;
     const uint32_t own_vaddr = lds0 + (uint32_t)w * VNK * 512u + lane8;
     const uint32_t sum_vaddr = lds0 + SUM_BASE + (uint32_t)w * 512u + lane8;
@@ -496,11 +497,58 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? (NW == 4 ? 4 : 2) : 2) void k_fu
     uint32_t res_left = 0;   // columns of the reservoir (resk) not handed out yet
     bool drained = false;    // no slab ticket left
     uint32_t age = 0;        // lanes 0..31 (of every wave, identically): sweeps executed by the frame at position `lane`
-    u64 c_tot = 0, c_wec = 0, c_isum = 0, c_bec = 0;  // c_isum (wave 0) and c_bec (every wave) per lane, the others wave-uniform in wave 0
+    // Counters (src/main.py:41-45) per ROUND: one launch may carry several rounds of A.B frames (ldpc_simulate_rounds), each with its own
+    // counter row, while the 32 positions are refilled across round boundaries -- a workgroup never drains between rounds.  Frames of at
+    // most TWO rounds are in flight in a workgroup at a time (slots 0 / 1, tagged row_of[s]); a slab of a third round waits (`pending`)
+    // until every frame of one of the two has left and that slot's sums have been added to its row.
+    uint32_t S1 = 0;         // positions whose frame belongs to accumulator slot 1 (the others: slot 0)
+    int row_of[2] = {-1, -1};
+    // 32-bit partial sums, added to the 64-bit rows when a slot is released and at the latest every A.flush_every frames (fused_launch:
+    // 2^31 / max(n, max_iter), so that neither the sweep sum nor the bit-error sum of a lane can wrap)
+    // Packed (this kernel sits at its register limits): c_isum -- lanes 0..31 the sweep sums of slot 0's positions, lanes 32..63 those of slot 1
+    // (`age` is kept in both halves); c_bec -- bit errors of this wave's variables per lane, slot 0 in the low, slot 1 in the high 16 bits;
+    // c_tot / c_wec -- frames / word errors, one 16-bit field per slot, wave-uniform (flush_every <= 4096 frames keeps every field in range).
+    uint32_t c_isum = 0, c_bec = 0;
+    uint32_t c_tot = 0, c_wec = 0;
     uint32_t all[3] = {0u, 0u, 0u};  // last exchange: changed, erased, wrong
+#define BECS_SPR ((uint32_t)((A.B + BEC_SLAB - 1) / BEC_SLAB))  /* slabs per round (re-read from the kernel arguments where needed: no live register) */
+    int pending = -1;        // a slab ticket taken but not drawn yet
+    int res_row = 0;         // round of the frames in the reservoir
+
+    auto flush_slot = [&](auto S_, bool release) {  // wave-uniform: sums of slot s -> its counter row; `release`: the slot is free afterwards
+        constexpr int s = decltype(S_)::value;
+        u64* row = (u64*)A.counters + (size_t)row_of[s] * (size_t)A.counter_stride;
+        u64 b = (u64)((c_bec >> (16 * s)) & 0xffffu);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) b += __shfl_xor(b, o);
+        if (lane == 0 && b) global_add(&row[2], b);
+        c_bec &= 0xffff0000u >> (16 * s);
+        if (w == 0) {
+            u64 t = (lane >> 5) == s ? (u64)c_isum : 0ull;
+#pragma unroll
+            for (int o = 32; o; o >>= 1) t += __shfl_xor(t, o);
+            if (lane == 0) {
+                const uint32_t ft = (c_tot >> (16 * s)) & 0xffffu, fw = (c_wec >> (16 * s)) & 0xffffu;
+                if (t) global_add(&row[3], t);
+                if (ft) global_add(&row[0], (u64)ft);
+                if (fw) global_add(&row[1], (u64)fw);
+            }
+            if (A.hist_bins > 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_add_u32 of the slot have landed (only wave 0 touches the histogram)
+                auto hp = sysw(BSYS_HIST + 64 * s + lane);
+                const unsigned h = *hp;
+                *hp = 0u;
+                if (lane < A.hist_bins && h) global_add(&row[4 + lane], (u64)h);
+            }
+        }
+        c_isum = (lane >> 5) == s ? 0u : c_isum;
+        c_tot &= 0xffff0000u >> (16 * s);
+        c_wec &= 0xffff0000u >> (16 * s);
+        if (release) row_of[s] = -1;
+    };
 
     SlabTickets tickets;
-    tickets.init(A.B);
+    tickets.init((long long)BECS_SPR * BEC_SLAB * (long long)(A.rounds > 0 ? A.rounds : 1));
     const int nblk = (n + 3) >> 2, npair = (nblk + 1) >> 1;
     const uint32_t thr32 = A.bsc_thr > 0xffffffffull ? 0xffffffffu : (uint32_t)A.bsc_thr;
     const bool all_erased = A.bsc_thr > 0xffffffffull;
@@ -511,41 +559,71 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? (NW == 4 ? 4 : 2) : 2) void k_fu
         const uint32_t capm = max_iter > 0 ? (uint32_t)__ballot((int)age >= max_iter) : 0u;
         const uint32_t X = L & (early ? (~all[0] | ~all[1] | capm) : capm);
         if (X != 0u) {
+            // the leaving frames by accumulator slot: those of round row_of[0], the rest belong to row_of[1]
+            const uint32_t in0 = ~S1;
+            static_for<0, 2>([&](auto S_) {
+                constexpr int sl = decltype(S_)::value;
+                const uint32_t XS = sl == 0 ? (X & in0) : (X & ~in0);
+                if (XS != 0u) {  // wave-uniform
 #pragma unroll
-            for (int q = 0; q < VRW; ++q) c_bec += (u64)__popc(B3(xv[q], cwm, xe[q], (X0 ^ X1) | X2) & X);  // an unresolved erasure counts as a bit error (src/main.py:41)
-            if (w == 0) {
-                c_tot += (u64)__popc(X);
-                c_wec += (u64)__popc(all[2] & X);
-                if (lane < 32 && ((X >> lane) & 1u)) {
-                    c_isum += (u64)age;
-                    if (A.hist_bins > 0) {
-                        typedef __attribute__((address_space(3))) unsigned lds_u32;
-                        lds_u32* bin = (lds_u32*)(uintptr_t)(lds0 + SYS_BASE) + BSYS_HIST + ((int)age < A.hist_bins ? (int)age : A.hist_bins - 1);
-                        __hip_atomic_fetch_add(bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u32
+                    for (int q = 0; q < VRW; ++q) c_bec += (uint32_t)__popc(B3(xv[q], cwm, xe[q], (X0 ^ X1) | X2) & XS) << (16 * sl);  // an unresolved erasure counts as a bit error (src/main.py:41)
+                    c_isum += ((lane >> 5) == sl && ((XS >> (lane & 31)) & 1u)) ? age : 0u;
+                    c_tot += (uint32_t)__popc(XS) << (16 * sl);
+                    c_wec += (uint32_t)__popc(all[2] & XS) << (16 * sl);
+                    if (w == 0) {
+                        if (lane < 32 && ((XS >> lane) & 1u)) {
+                            if (A.hist_bins > 0) {
+                                typedef __attribute__((address_space(3))) unsigned lds_u32;
+                                lds_u32* bin = (lds_u32*)(uintptr_t)(lds0 + SYS_BASE) + BSYS_HIST + 64 * sl + ((int)age < A.hist_bins ? (int)age : A.hist_bins - 1);
+                                __hip_atomic_fetch_add(bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u32
+                            }
+                        }
                     }
+                    if (((c_tot >> (16 * sl)) & 0xffffu) >= (uint32_t)A.flush_every) flush_slot(S_, false);
                 }
-            }
+            });
             L &= ~X;
         }
         // ---------------- refill the free positions from the reservoir; an empty reservoir is restocked with the next slab of 32 frames
         uint32_t F = ~L;
         while (F != 0u) {
             if (res_left == 0u) {
-                if (drained) break;
-                long long slab_s = 0;
-                if constexpr (NW == 1) {
-                    slab_s = tickets.next(A.next_frame, lane);
-                } else {
-                    if (w == 0) {
-                        const long long s0 = tickets.next(A.next_frame, lane);
-                        if (lane == 0) *sysw(BSYS_TICKET) = (uint32_t)(int32_t)s0;
+                if (pending < 0) {
+                    if (drained) break;
+                    long long slab_s = 0;
+                    if constexpr (NW == 1) {
+                        slab_s = tickets.next(A.next_frame, lane);
+                    } else {
+                        if (w == 0) {
+                            const long long s0 = tickets.next(A.next_frame, lane);
+                            if (lane == 0) *sysw(BSYS_TICKET) = (uint32_t)(int32_t)s0;
+                        }
+                        wg_barrier();
+                        slab_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*sysw(BSYS_TICKET));
                     }
-                    wg_barrier();
-                    slab_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*sysw(BSYS_TICKET));
+                    if (slab_s < 0) { drained = true; break; }
+                    pending = (int)slab_s;
                 }
-                if (slab_s < 0) { drained = true; break; }
-                const u64 f0 = (u64)slab_s * BEC_SLAB;
-                const long long left = A.B - (long long)f0;
+                // round of the slab and its accumulator slot
+                const uint32_t spr = BECS_SPR;
+                const uint32_t rnd = (uint32_t)pending / spr, tslab = (uint32_t)pending - rnd * spr;
+                if ((int)rnd != row_of[0] && (int)rnd != row_of[1]) {
+                    const uint32_t busy = L | R;
+                    const uint32_t in0 = ~S1;
+                    if (row_of[0] < 0 || (busy & in0) == 0u) {
+                        if (row_of[0] >= 0) flush_slot(std::integral_constant<int, 0>{}, true);
+                        row_of[0] = (int)rnd;
+                    } else if (row_of[1] < 0 || (busy & ~in0) == 0u) {
+                        if (row_of[1] >= 0) flush_slot(std::integral_constant<int, 1>{}, true);
+                        row_of[1] = (int)rnd;
+                    } else {
+                        break;  // frames of two other rounds are still in flight: the slab waits for one of them to empty
+                    }
+                }
+                pending = -1;
+                res_row = (int)rnd;
+                const u64 f0 = (u64)rnd * A.round_stride + (u64)tslab * BEC_SLAB;   // first frame of the slab, relative to A.frame0
+                const long long left = A.B - (long long)tslab * BEC_SLAB;            // frames of the round from this slab on
                 // Channel, the SAME stream as ldpc_channel (src/bec.py:17: erased where the uniform draw is below p): Philox block b of frame f
                 // holds the words of variables 4b..4b+3.  Lanes 0-31 take block 2p for the 32 frames, lanes 32-63 block 2p+1; the comparison's
                 // lane mask IS the plane word of a variable (low half: block 2p, high half: 2p+1).
@@ -588,8 +666,12 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? (NW == 4 ? 4 : 2) : 2) void k_fu
                 pv[q] = (pv[q] & ~dm) | (kb & cwm);
             }
             age = (lane & 31) == d ? 0u : age;
+            S1 = res_row == row_of[1] ? (S1 | dm) : (S1 & ~dm);
         }
-        if ((L | R) == 0u) break;  // nothing in flight and nothing left to start
+        if ((L | R) == 0u) {
+            if (pending < 0) break;  // nothing in flight and nothing left to start
+            continue;                // (a waiting slab: both slots are free now, the refill above takes it on the next trip)
+        }
         // ---------------- one sweep of all 32 positions
         becs_check_phase<SH>(smem, cn_idx, sum_vaddr, w, ~R);
         if constexpr (NW > 1) wg_barrier(); else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
@@ -603,28 +685,10 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? (NW == 4 ? 4 : 2) : 2) void k_fu
         L = U;
         R = 0u;
     }
-    // ---------------- counters of the workgroup -> global (src/main.py:41-45)
-    {
-        u64 b = c_bec;
-#pragma unroll
-        for (int o = 32; o; o >>= 1) b += __shfl_xor(b, o);
-        if (lane == 0 && b) global_add(&A.counters[2], b);
-    }
+    // ---------------- counters of the workgroup -> their rows (src/main.py:41-45)
     if constexpr (NW > 1) wg_barrier();
-    if (w == 0) {
-        u64 s = lane < 32 ? c_isum : 0ull;
-#pragma unroll
-        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) {
-            if (c_tot) global_add(&A.counters[0], c_tot);
-            if (c_wec) global_add(&A.counters[1], c_wec);
-            if (s) global_add(&A.counters[3], s);
-        }
-        if (lane < A.hist_bins) {
-            const unsigned h = *sysw(BSYS_HIST + lane);
-            if (h) global_add(&A.counters[4 + lane], (u64)h);
-        }
-    }
+    if (row_of[0] >= 0) flush_slot(std::integral_constant<int, 0>{}, true);
+    if (row_of[1] >= 0) flush_slot(std::integral_constant<int, 1>{}, true);
 }
 
 template <int DC, int DV, int CRW, int VRW, int NW, int VRX = 0, int DVX = DV>

@@ -143,7 +143,8 @@ void fused_plan_destroy(Decoder* d);
 bool fused_supported(const Decoder* d);
 bool fused_simulate_supported(const Decoder* d, int channel, double param, int hist_bins);
 int fused_simulate(Decoder* d, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
-                   int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st);
+                   int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st, int rounds = 1, uint64_t round_stride = 0);
+bool fused_simulate_rounds_supported(const Decoder* d);
 int fused_info(const Decoder* d, double* out8);
 int fused_kernel_name(const Decoder* d, bool sim, char* buf, size_t len);
 int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags,

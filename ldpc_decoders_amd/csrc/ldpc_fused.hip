@@ -334,7 +334,7 @@ static int becs_build_plan(Decoder* d, FusedPlan* p, const ShapeEntry& shape, co
     const int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
     const uint32_t sum_base = (uint32_t)NW * VNK * 64, sys_base = sum_base + (uint32_t)CR * 64;
     const uint32_t zero_e = sys_base, known0_e = sys_base + 1;
-    p->lds_bytes = (size_t)(sys_base + 64) * 8;
+    p->lds_bytes = (size_t)(sys_base + 128) * 8;  // system row + the row of the second accumulator slot's histogram (Monte-Carlo kernel)
     if (p->lds_bytes > (size_t)160 * 1024 || sys_base + 64 > 65536u || CR > CRW * NW) return LDPC_OK;  // plan stays !ok
     std::vector<uint32_t> cn_tab((size_t)NW * CNW * 64, 0), vn_tab((size_t)NW * VNW * 64, 0);
     std::vector<int32_t> var_of_slot((size_t)NPAD, -1);
@@ -632,7 +632,9 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
     unsigned long long* next_set = dsp.d + (size_t)dsp.sel * 64;
     if (!(dsp.clean && dsp.stream == st)) LDPC_HIP_TRY(hipMemsetAsync(next_set, 0, 8 * 64, st));
     long long groups = (long long)p->num_cu * p->groups_per_cu;
-    const long long units = shape.alg == ALG_BEC ? (B + 31) / 32 : B;  // the bit-sliced erasure kernels hand out slabs of 32 frames
+    if (a.rounds < 1) a.rounds = 1;
+    if (a.rounds == 1) a.round_stride = 0;
+    const long long units = shape.alg == ALG_BEC ? (B + 31) / 32 * a.rounds : B;  // the bit-sliced erasure kernels hand out slabs of 32 frames
     if (groups > units) groups = units;
     a.B = B;
     a.n = c->n;
@@ -738,9 +740,17 @@ bool fused_simulate_supported(const Decoder* d, int channel, double param, int h
     return channel == CH_BIAWGN || channel == CH_BSC;
 }
 
+bool fused_simulate_rounds_supported(const Decoder* d) {  // one launch for several rounds: the erasure Monte-Carlo kernel (continuous refill)
+    return fused_supported(d) && d->alg == ALG_BEC;
+}
+
 int fused_simulate(Decoder* d, int channel, double param, int codeword, uint64_t seed, uint64_t stream_id, uint64_t frame0, int64_t B,
-                   int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st) {
+                   int32_t max_iter, uint32_t flags, int32_t hist_bins, int64_t* counters, hipStream_t st, int rounds, uint64_t round_stride) {
     if (B <= 0) return LDPC_OK;
+    if (rounds > 1 && (!fused_simulate_rounds_supported(d) || (B + 31) / 32 * (int64_t)rounds >= ((int64_t)1 << 31))) {
+        set_error("fused_simulate: several rounds per launch are the erasure kernel's (at most 2^31 slabs of 32 frames)");
+        return LDPC_E_UNSUPPORTED;
+    }
     if (all_shapes()[d->fused->shape].esz == 8 && channel == CH_BSC && !(param > 0.0 && param < 0.5)) {
         // fp64, BSC beyond p = 1/2 (negative LLRs): priors and the received word of a chunk are generated into HBM by the channel kernel,
         // the decode kernel then counts the errors itself (no decisions written, no counting kernel)
@@ -784,6 +794,9 @@ int fused_simulate(Decoder* d, int channel, double param, int codeword, uint64_t
         a.bsc_llr_d = channel == CH_BSC ? log(1.0 - param) - log(param) : 0.0;
     }
     a.counters = (unsigned long long*)counters;
+    a.rounds = rounds < 1 ? 1 : rounds;
+    a.round_stride = round_stride;
+    a.counter_stride = 4 + hist_bins;
     return fused_launch(d, a, true, B, max_iter, flags, st);
 }
 

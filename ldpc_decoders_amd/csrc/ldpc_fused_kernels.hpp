@@ -190,6 +190,10 @@ struct FusedArgs {
     uint32_t certain_entry;         // gather-table entry of the "certain" variable slot that pads short check rows (0xffffffff: none)
     unsigned long long* counters;   // [4 + hist_bins] tot, wec, bec, iter_sum, histogram of sweeps
     int flush_every;                // SIM: frames a workgroup counts in 32-bit lanes before adding them to `counters`
+    // several rounds per launch (erasure Monte-Carlo kernel, ldpc_simulate_rounds): `rounds` rounds of B frames each; round r covers
+    // frames frame0 + r * round_stride + [0, B) and accumulates into counters + r * counter_stride
+    int rounds, counter_stride;
+    unsigned long long round_stride;
     // exact-in-fp32 mode: priors are rounded to multiples of 1 / grid_scale (SIM: in the kernel; decode: by the channel kernel); a frame
     // in which some |v2c|, |marginal| reaches grid_limit -- beyond it an fp32 sum of grid multiples may round -- is counted in grid_viol
     float grid_scale, grid_inv, grid_limit;

@@ -90,6 +90,7 @@ class DeviceSimulator:
         # the 0.25 ms rounds of the erasure decoder -15 %: an opt-in, not the default.
         self._lanes = [(handle, None)]
         self._round = 0
+        self._multi = []  # slots of launch_rounds: [rounds, k] counter blocks
 
     def _lane(self):
         import os
@@ -125,6 +126,53 @@ class DeviceSimulator:
                 slot["done"].record()
         slot["busy"] = True
         return slot
+
+    def rounds_per_launch(self):
+        """Rounds worth sending in ONE launch (``launch_rounds``): > 1 only where the kernel keeps its frame positions busy across round
+        boundaries (the LDS-resident erasure decoder).  Every round keeps its own counter row, so counters stay a function of the round
+        size alone."""
+        import os
+
+        h = self.h
+        if self.codeword == -1 or self.prior_grid is not None or self.device != "cuda" or not hasattr(h, "rounds_per_launch"):
+            return 1
+        if os.environ.get("LDPC_SIM_STREAMS", "1") == "2":  # the two-stream experiment alternates single rounds over two decoders
+            return 1
+        return int(h.rounds_per_launch())
+
+    def launch_rounds(self, param, stream_id, frame0, frames_total, rounds, flags=0):
+        """Enqueue ``rounds`` consecutive rounds of ``frames_total`` global frames each -- round r covers [frame0 + r * frames_total, + frames_total),
+        split over ranks like ``launch_round`` -- as one call with one counter row per round and ONE all-reduce of the whole block; returns a
+        ticket for ``finish_rounds``."""
+        torch = self.torch
+        k = 4 + self.hist_bins
+        blk = None
+        for b in self._multi:
+            if not b["busy"] and b["dev"].shape[0] == rounds:
+                blk = b
+        if blk is None:
+            blk = dict(dev=torch.zeros((rounds, k), dtype=torch.int64, device=self.device),
+                       host=torch.zeros((rounds, k), dtype=torch.int64).pin_memory() if self.device == "cuda" else torch.zeros((rounds, k), dtype=torch.int64),
+                       done=torch.cuda.Event() if self.device == "cuda" else None, busy=False)
+            self._multi.append(blk)
+        start, cnt = self.comm.shard(frame0, frames_total)
+        blk["dev"].zero_()
+        if cnt > 0:
+            self.h.simulate_rounds(self.channel, param, self.codeword, self.seed, stream_id, start, cnt, rounds, frames_total, self.max_iter,
+                                   blk["dev"], flags=flags, hist_bins=self.hist_bins)
+        self.comm.all_reduce_sum(blk["dev"], async_on_stream=True)
+        blk["host"].copy_(blk["dev"], non_blocking=True)
+        if blk["done"] is not None:
+            blk["done"].record()
+        blk["busy"] = True
+        return blk
+
+    def finish_rounds(self, blk):
+        """Wait for one ``launch_rounds`` ticket; returns its whole-job counter rows (numpy int64 [rounds, 4 + hist_bins])."""
+        if blk["done"] is not None:
+            blk["done"].synchronize()
+        blk["busy"] = False
+        return blk["host"].numpy().copy()
 
     def finish_round(self, slot):
         """Wait for one launched round; returns its whole-job counters (numpy int64)."""
@@ -171,6 +219,16 @@ class DeviceSimulator:
         count(self.run_round(param, stream_id, frame0, per_round))
         frame0 += per_round
         depth = self.pipeline_depth()
+        rpl = self.rounds_per_launch()
+        while rpl > 1 and (more() or inflight):
+            # several rounds per launch: the rows are counted IN ORDER until the stopping rule fires; rows behind it (and a block already in
+            # flight) are decoded and discarded, exactly like the speculative round of the pipelined loop below
+            while more() and len(inflight) < depth:
+                inflight.append(self.launch_rounds(param, stream_id, frame0, per_round, rpl))
+                frame0 += per_round * rpl
+            for row in self.finish_rounds(inflight.pop(0)):
+                if more():
+                    count(row)
         while more() or inflight:
             while more() and len(inflight) < depth:
                 inflight.append(self.launch_round(param, stream_id, frame0, per_round))

@@ -215,3 +215,62 @@ def test_whole_batch_erasure_decoder_against_the_oracle():
             ref = C.bec_decode(g, y.cpu().numpy(), 50)
         assert (xh == ref[0]).all() and (it == ref[1]).all(), backend
     assert 0.05 < (ref[0] == 2).any(axis=1).mean() < 0.95  # stopping sets and complete decodes both present
+
+
+@pytest.mark.parametrize("name,backend,B,stride,cw", [
+    ("1200_3_6_rand_ldpc_1", "auto", 4096, 4096, 0),     # LDS-resident erasure decoder: ONE launch, positions refilled across round boundaries
+    ("1200_3_6_rand_ldpc_1", "auto", 1000, 8000, 1),     # ragged rounds (1000 = 31 slabs + 8 frames), rounds of one rank of a sharded job
+    ("1200_3_6_rand_ldpc_1", "auto", 37, 37, 0),         # rounds smaller than the 32 x (workgroups) positions of the chip: rows interleave everywhere
+    ("7_4_hamming", "auto", 333, 333, 0),
+    ("1200_3_6_rand_ldpc_1", "stream", 2048, 2048, 0),   # streaming erasure kernels: round by round behind the same entry point
+])
+def test_simulate_rounds_rows_equal_round_by_round_calls(name, backend, B, stride, cw):
+    """ldpc_simulate_rounds: every counter row must be exactly what ldpc_simulate returns for that round alone (same Philox frames), however
+    many rounds share the launch -- the host applies the stopping rule of src/main.py:37 to the rows in order."""
+    import torch
+    from ldpc_decoders_amd._device import DecoderHandle
+    from ldpc_decoders_amd.codes import Code
+
+    g = golden_edges(name)
+    code = Code.from_edges(g.m, g.n, g.chk, g.var)
+    h = DecoderHandle(code, "BEC", "f32", backend)
+    R, bins = 11, 51
+    rows = torch.zeros((R, 4 + bins), dtype=torch.int64, device="cuda")
+    h.simulate_rounds("bec", 0.41, cw, 77, 3, 500, B, R, stride, 50, rows, hist_bins=bins)
+    one = torch.zeros((R, 4 + bins), dtype=torch.int64, device="cuda")
+    for r in range(R):
+        h.simulate("bec", 0.41, cw, 77, 3, 500 + r * stride, B, 50, one[r], hist_bins=bins)
+    assert (rows == one).all(), (rows[:, :4].tolist(), one[:, :4].tolist())
+    assert (rows[:, 0] == B).all() and int(rows[:, 1].sum()) > 0
+    # accumulation (not overwrite), and a single round through the same entry point
+    h.simulate_rounds("bec", 0.41, cw, 77, 3, 500, B, 1, stride, 50, rows[:1], hist_bins=bins)
+    assert (rows[0] == 2 * one[0]).all()
+
+
+def test_simulate_rounds_of_an_llr_decoder_and_forced_flushes():
+    # LLR decoders take the round-by-round path; the erasure kernel's 16-bit partial sums are flushed every 4096 frames of a workgroup
+    import torch
+    from ldpc_decoders_amd._device import DecoderHandle
+    from ldpc_decoders_amd.codes import Code
+
+    g = golden_edges("1200_3_6_rand_ldpc_1")
+    code = Code.from_edges(g.m, g.n, g.chk, g.var)
+    h = DecoderHandle(code, "MSA", "f32", "auto")
+    rows = torch.zeros((3, 4 + 11), dtype=torch.int64, device="cuda")
+    h.simulate_rounds("biawgn", 2.0, 0, 5, 1, 0, 1024, 3, 1024, 10, rows, hist_bins=11)
+    one = torch.zeros_like(rows)
+    for r in range(3):
+        h.simulate("biawgn", 2.0, 0, 5, 1, r * 1024, 1024, 10, one[r], hist_bins=11)
+    assert (rows == one).all()
+    # a long launch of a small code: each of the 1024 workgroups handles > 4096 frames per slot -> forced flushes of the packed sums
+    g2 = golden_edges("7_4_hamming")
+    hb = DecoderHandle(Code.from_edges(g2.m, g2.n, g2.chk, g2.var), "BEC", "f32", "auto")
+    B = 1 << 23
+    big = torch.zeros((2, 4 + 20), dtype=torch.int64, device="cuda")
+    hb.simulate_rounds("bec", 0.3, 0, 9, 0, 0, B, 2, B, 20, big, hist_bins=20)
+    ref = torch.zeros((2, 4 + 20), dtype=torch.int64, device="cuda")
+    hs = DecoderHandle(Code.from_edges(g2.m, g2.n, g2.chk, g2.var), "BEC", "f32", "stream")  # bit-plane counters of the streaming kernels: another code path
+    for r in range(2):
+        hs.simulate("bec", 0.3, 0, 9, 0, r * B, B, 20, ref[r], hist_bins=20)
+    assert hb.last_stats()[0] == "fused" and hs.last_stats()[0] == "stream"
+    assert (big == ref).all() and int(big[0, 0]) == B

@@ -17,4 +17,10 @@ for snr in (1.0, 3.0):
     t0 = time.perf_counter()
     for _ in range(3): x, it = dec.decode_batch(None, pri)
     dt = (time.perf_counter() - t0) / 3
+    hb = dec.handle
+    t0 = time.perf_counter()
+    for _ in range(3): bits, _e, it2 = hb.decode_host_bits(pri, None, 50)
+    dtb = (time.perf_counter() - t0) / 3
+    assert (it2 == it).all()
+    print("snr %.1f: ldpc_decode_host_bits (packed decisions stay packed) %.2f ms = %.2f M frames/s" % (snr, dtb * 1e3, B / dtb / 1e6))
     print("snr %.1f: host-buffer decode %.2f ms per %d frames = %.2f M frames/s (%.1f GB/s over PCIe, pageable numpy buffers), mean sweeps %.1f" % (snr, dt * 1e3, B, B / dt / 1e6, B * g.n * 5 / dt / 1e9, it.mean()))
