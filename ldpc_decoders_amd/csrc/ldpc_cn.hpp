@@ -218,6 +218,38 @@ __device__ __forceinline__ float spa_llr_of_eo(float ep, float op, float es, flo
     return 0.69314718055994530942f * (__builtin_amdgcn_logf(e) - __builtin_amdgcn_logf(o));  // v_log_f32 is log2
 }
 
+// ---- the same rule in the BASE-2 LLR domain (LDS-resident fp32 kernels) ------------------------------------------------------
+// Belief propagation is invariant under one positive scale on every LLR (sums are linear, decisions are signs, the check rule maps
+// scaled inputs to the equally scaled output once exp / ln are replaced by the matching base): with every prior multiplied by log2(e)
+// ONCE per frame, u_i = 2^-|v2c'_i| is the bare v_exp_f32 (negation and |.| are source modifiers: no multiply, no fabs) and the message
+// |c2v'_j| = log2(E_j) - log2(O_j) the bare pair of v_log_f32 (no ln 2 multiply).  Soft outputs are scaled back by ln 2 where a kernel
+// returns them.
+// Degree 6 builds the six leave-one-out pairs from a TREE instead of prefix / suffix chains: three pairs P01, P23, P45 (one packed fma
+// each), the three joins of two pairs (packed multiply + fma), and one push per edge -- (E_0, O_0) = (P23 x P45) pushed with u_1, ... --
+// 15 packed instructions of depth 4 per row where prefix + suffix + join take 22 of depth 7.  Every term is positive, as before.
+__device__ __forceinline__ float spa2_u_of_llr(float v) { return __builtin_amdgcn_exp2f(-__builtin_fabsf(v)); }  // 2^-|v|: one v_exp_f32
+__device__ __forceinline__ spa_f2 spa2_push(spa_f2 eo, float u) {  // (E + uO, O + uE)
+    return __builtin_elementwise_fma(spa_f2{u, u}, spa_f2{eo.y, eo.x}, eo);
+}
+__device__ __forceinline__ spa_f2 spa2_join(spa_f2 a, spa_f2 b) {  // (EaEb + OaOb, EaOb + OaEb)
+    return __builtin_elementwise_fma(spa_f2{a.y, a.y}, spa_f2{b.y, b.x}, spa_f2{a.x, a.x} * b);
+}
+__device__ __forceinline__ float spa2_llr_of_eo(spa_f2 eo) {  // log2(E / O), O kept off zero (a saturated message, not +inf)
+    return __builtin_amdgcn_logf(eo.x) - __builtin_amdgcn_logf(fmaxf(eo.y, 1.17549435e-38f));
+}
+// u[0..5] -> the six leave-one-out magnitudes log2(E_j / O_j)
+__device__ __forceinline__ void spa2_loo6(const float (&u)[6], float (&mag)[6]) {
+    const spa_f2 p01 = spa2_push(spa_f2{1.0f, u[0]}, u[1]), p23 = spa2_push(spa_f2{1.0f, u[2]}, u[3]), p45 = spa2_push(spa_f2{1.0f, u[4]}, u[5]);
+    const spa_f2 q = spa2_join(p23, p45), r = spa2_join(p01, p45), s = spa2_join(p01, p23);
+    mag[0] = spa2_llr_of_eo(spa2_push(q, u[1]));
+    mag[1] = spa2_llr_of_eo(spa2_push(q, u[0]));
+    mag[2] = spa2_llr_of_eo(spa2_push(r, u[3]));
+    mag[3] = spa2_llr_of_eo(spa2_push(r, u[2]));
+    mag[4] = spa2_llr_of_eo(spa2_push(s, u[5]));
+    mag[5] = spa2_llr_of_eo(spa2_push(s, u[4]));
+}
+constexpr float SPA2_LOG2E = 1.44269504088896340736f, SPA2_LN2 = 0.69314718055994530942f;
+
 template <int DCMAX>
 __device__ __forceinline__ void cn_spa(float (&v)[DCMAX], int deg) {
     float u[DCMAX], pe[DCMAX], po[DCMAX];

@@ -458,12 +458,14 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                     for (int t = 0; t < 4; ++t) {
                         pri4[t] = -(A.sim_k * (A.sim_mean + A.sim_sigma * z[t]));
                         if constexpr (GRID) pri4[t] = __builtin_rintf(pri4[t] * A.grid_scale) * A.grid_inv;  // both scalings are exact (powers of two)
+                        if constexpr (ALG == ALG_SPA) pri4[t] *= SPA2_LOG2E;  // sum-product runs in the base-2 LLR domain (ldpc_cn.hpp)
                     }
                 } else {  // CH_BSC: same integer threshold and the same LLR expression as k_discrete
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int y = A.codeword ^ ((u64)ph.w[t] < A.bsc_thr ? 1 : 0);
                         pri4[t] = (GRID ? __builtin_rintf(A.bsc_llr * A.grid_scale) * A.grid_inv : A.bsc_llr) * (float)(1 - 2 * y);
+                        if constexpr (ALG == ALG_SPA) pri4[t] *= SPA2_LOG2E;
                     }
                 }
 #pragma unroll
@@ -482,6 +484,7 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
             for (int q = 0; q < VRW; ++q) {
                 const int v = vmap_of(q);
                 prior[q] = v >= 0 ? pf[v] : 0.0f;
+                if constexpr (ALG == ALG_SPA) prior[q] *= SPA2_LOG2E;  // base-2 LLR domain (ldpc_cn.hpp); the soft output is scaled back
             }
         }
         if constexpr (VRX > 0) {
@@ -602,10 +605,15 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                         for (int j = DC - 3; j >= 0; --j) suf[j] = fminf(suf[j + 1], a[j + 1]);
                         pre[0] = suf[0];            // fminf(pre[j], suf[j]) below: the two ends are one-sided
                         suf[DC - 1] = pre[DC - 1];
+                    } else if constexpr (DC == 6) {
+                        // sum-product, base-2 LLR domain: the six leave-one-out magnitudes from the pair tree (ldpc_cn.hpp spa2_loo6) -> pre[]
+#pragma unroll
+                        for (int j = 0; j < DC; ++j) a[j] = spa2_u_of_llr(v[j]);
+                        spa2_loo6(a, pre);
                     } else {
                         // sum-product: (E, O) pairs of prod (1 + u_i), prefix in (pre, preo), suffix in (suf, sufo) -- ldpc_cn.hpp
 #pragma unroll
-                        for (int j = 0; j < DC; ++j) a[j] = spa_u_of_llr(a[j]);
+                        for (int j = 0; j < DC; ++j) a[j] = spa2_u_of_llr(v[j]);
                         pre[0] = 1.0f; preo[0] = 0.0f;
 #pragma unroll
                         for (int j = 1; j < DC; ++j) {
@@ -622,14 +630,15 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                     static_for<0, DC>([&](auto J_) {
                         constexpr int j = decltype(J_)::value;
                         float mag;
-                        if constexpr (ALG == ALG_MSA) mag = fminf(pre[j], suf[j]); else mag = spa_llr_of_eo(pre[j], preo[j], suf[j], sufo[j]);
+                        if constexpr (ALG == ALG_MSA) mag = fminf(pre[j], suf[j]);
+                        else if constexpr (DC == 6) mag = pre[j];
+                        else mag = spa2_llr_of_eo(spa2_join(spa_f2{pre[j], preo[j]}, spa_f2{suf[j], sufo[j]}));
                         // GRID: the guard watches the outgoing magnitudes and the marginals.  Both below L = 2^(21-k) keeps every sum of the
                         // sweep exact: v2c = marg - c2v_old stays below 2L, a partial sum of up to 8 messages below 8L = 2^(24-k).  (The
                         // incoming |v2c| themselves are not watched: a short row's padding position is +inf by construction.)
                         if constexpr (GRID) gmax = fmaxf(gmax, mag);
                         float c;  // mag | ((vx ^ v[j]) & sign bit)
-                        if constexpr (ALG == ALG_MSA) asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(c) : "v"(vx ^ __float_as_uint(v[j])), "s"(sign_mask), "v"(mag));
-                        else c = __uint_as_float(__float_as_uint(mag) | ((vx ^ __float_as_uint(v[j])) & 0x80000000u));
+                        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(c) : "v"(vx ^ __float_as_uint(v[j])), "s"(sign_mask), "v"(mag));
                         c2v_old[r][j] = c;
                         if constexpr (!BIG) lds_st_tid<(r * DC + j) * 256>(c);
                     });
@@ -760,7 +769,7 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
 #pragma unroll
                 for (int q = 0; q < VRW; ++q) {
                     const int v = vmap_of(q);
-                    if (v >= 0) sf[v] = it > 0 ? lds_marg[q * 64 + lane] : 0.0f;
+                    if (v >= 0) sf[v] = it > 0 ? lds_marg[q * 64 + lane] * (ALG == ALG_SPA ? SPA2_LN2 : 1.0f) : 0.0f;
                 }
             }
         }

@@ -155,7 +155,12 @@ def test_config3_spa_bsc_full_batch(tmp_path):
     xo, io = res["x"], res["it"]
     differ = np.flatnonzero(~(xh[idx] == xo).all(axis=1))
     print("config 3 sum-product / BSC: %d of %d re-decoded frames differ from the fp64 phi oracle: %s" % (len(differ), len(idx), idx[differ].tolist()))
-    assert set(idx[differ].tolist()) <= CONFIG3_SPA_FRAMES_THAT_MAY_DIFFER
+    # fp32 arithmetic against the fp64 statement of the same rule: a frame may end in a different word only where the decoder does NOT
+    # converge -- there the iteration is chaotic and the last word depends on the last bit of every message (which frames of that kind
+    # differ changes with any re-association of the arithmetic: round 4's prefix / suffix form and round 5's pair tree in the base-2
+    # domain each differ on 26 of the 65 536, 23 of them the same).  Every converging frame must be identical; the others are bounded.
+    assert (io[differ] == 50).all() and (it[idx][differ] == 50).all(), "a CONVERGING frame differs from the fp64 oracle"
+    assert len(differ) <= 40, "more than 0.06 % of the batch differ"
     assert (np.abs(it[idx] - io) <= 1)[io < 50].mean() >= 0.999
     # the published curve, in the reference's arithmetic
     ref = _published_point("bsc", "1200_3_6_rand_ldpc_1", "SPA", 10, 0, "0.06")
@@ -169,12 +174,6 @@ def test_config3_spa_bsc_full_batch(tmp_path):
     assert abs(wer - ref["wer"]) <= 4 * sigma
     # bit errors per failed word: 100 failed words upstream, spread of the count per word about its mean -> 4 sigma ~ 40 %
     assert 0.6 <= (ber / wer) / (ref["ber"] / ref["wer"]) <= 1.6
-
-
-# fp32 message arithmetic against the fp64 oracle: measured on ALL 65 536 frames of the batch (round 4; 25 s of host time on the bench
-# host), 26 non-converging frames (0.04 %) end in different words; the list names them, any other frame must be identical
-CONFIG3_SPA_FRAMES_THAT_MAY_DIFFER = {27, 3405, 5630, 6517, 6765, 8213, 9090, 17125, 17180, 18000, 21207, 24486, 24982, 29821, 30669, 32453,
-                                      36016, 39127, 48564, 49307, 50062, 54958, 55836, 57414, 58233, 61295}
 
 
 def test_config3_erasure_full_batch():
