@@ -747,14 +747,18 @@ static int simulate_impl(ldpc_decoder_t h, int channel, double param, int codewo
         }
         if (channel != CH_BEC && !tiled_noise) LDPC_TRY(d->h_in.reserve((size_t)cap * n * esz));
         if (channel != CH_BIAWGN) LDPC_TRY(d->h_y0.reserve((size_t)cap * n));
-        LDPC_TRY(d->h_out.reserve((size_t)cap * n));
+        if (tiled_noise) LDPC_TRY(d->h_bits.reserve((size_t)cap * ((n + 31) / 32) * 4));  // decisions leave the planes as packed words: no [B,n] bytes
+        else LDPC_TRY(d->h_out.reserve((size_t)cap * n));
         LDPC_TRY(d->h_iters.reserve((size_t)cap * sizeof(int32_t)));
         for (int64_t b0 = 0; b0 < B; b0 += step) {
             const int64_t nb = (B - b0) < step ? (B - b0) : step;
             if (tiled_noise) {
-                LDPC_TRY(stream_simulate_biawgn(d, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, max_iter, flags, (uint8_t*)d->h_out.p,
-                                                (int32_t*)d->h_iters.p, st));
-                LDPC_TRY(count_errors((uint8_t*)d->h_out.p, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters, st));
+                d->out_bits = (uint32_t*)d->h_bits.p;
+                const int rc = stream_simulate_biawgn(d, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, max_iter, flags, nullptr,
+                                                      (int32_t*)d->h_iters.p, st);
+                d->out_bits = nullptr;
+                if (rc) return rc;
+                LDPC_TRY(count_errors_bits((const uint32_t*)d->h_bits.p, nullptr, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters, st));
                 continue;
             }
             void* pri = channel == CH_BEC ? nullptr : d->h_in.p;

@@ -189,13 +189,17 @@ template <typename T, int ALG, int DCMAX, int FIXED_DC, int UNR>
 __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
                                             T* __restrict__ c2v, const T* __restrict__ src,
                                             const u64* __restrict__ live, int m, int n, int64_t E, int tiles, int chunks,
-                                            int cpw, int first, int xcd_aware) {
+                                            int cpw, int first, int xcd_aware, int freeze) {
     const int lane = threadIdx.x;
     int tile, chunk;
     if (!task_of(tiles, chunks, xcd_aware, &tile, &chunk)) return;
     const u64 lv = live[tile];
     if (lv == 0) return;
-    const bool on = (lv >> lane) & 1ull;
+    // A tile with a live frame is processed by ALL its lanes: the messages of a frame that has left are never looked at again, and a
+    // store that skips some lanes is a partial line -- sub-sector writes, measured 47 % slower passes at 90 % live lanes (n = 64 800:
+    // 16.6 against 11.3 ms per check pass, profiles/r05_config5_timeline.txt).  Only a decode that returns the soft output freezes the
+    // lanes of departed frames (`freeze`): their marginals must stay those of their own last sweep.
+    const bool on = freeze ? (bool)((lv >> lane) & 1ull) : true;
     const bool dense = E * 4 >= (int64_t)m * DCMAX * 3;  // average row length at least three quarters of DCMAX (wave-uniform)
     T* ct = c2v + (int64_t)tile * E * 64 + lane;
     const T* st = src + (int64_t)tile * n * 64 + lane;
@@ -269,13 +273,13 @@ template <typename T, int ALG, int DVMAX, int UNR, int FIXED_DV>
 __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ col_edge,
                                             const T* __restrict__ c2v, const T* __restrict__ prior_t, T* __restrict__ marg_t,
                                             const u64* __restrict__ live, u64* __restrict__ xbits,
-                                            int n, int64_t E, int tiles, int chunks, int vpw, int xcd_aware) {
+                                            int n, int64_t E, int tiles, int chunks, int vpw, int xcd_aware, int freeze) {
     const int lane = threadIdx.x;
     int tile, chunk;
     if (!task_of(tiles, chunks, xcd_aware, &tile, &chunk)) return;
     const u64 lv = live[tile];
     if (lv == 0) return;
-    const bool on = (lv >> lane) & 1ull;
+    const bool on = freeze ? (bool)((lv >> lane) & 1ull) : true;  // (see k_cn; the decision words below keep the bits of departed frames either way)
     const T* ct = c2v + (int64_t)tile * E * 64 + lane;
     const T* pt = prior_t + (int64_t)tile * n * 64 + lane;
     T* mt = marg_t + (int64_t)tile * n * 64 + lane;
@@ -534,20 +538,21 @@ constexpr int unroll_for(int row_bytes) {
 
 struct Geometry {
     int tiles, cn_chunks, cpw, vn_chunks, vpw, xcd_aware;
+    int freeze = 0;  // lanes of departed frames do not compute or store (soft-output decodes)
 };
 
 template <typename T, int ALG, int DCMAX, int FIXED_DC>
 void launch_cn(const Code* c, T* c2v, const T* src, const u64* live, const Geometry& g, int first, hipStream_t st) {
     constexpr int UNR = unroll_for(2 * DCMAX * (int)sizeof(T));  // old message + marginal line per edge
     hipLaunchKernelGGL((k_cn<T, ALG, DCMAX, FIXED_DC, UNR>), dim3(task_blocks(g.tiles, g.cn_chunks, g.xcd_aware)), dim3(64, 4), 0, st, c->d_row_ptr,
-                       c->d_edge_var, c2v, src, live, c->m, c->n, c->E, g.tiles, g.cn_chunks, g.cpw, first, g.xcd_aware);
+                       c->d_edge_var, c2v, src, live, c->m, c->n, c->E, g.tiles, g.cn_chunks, g.cpw, first, g.xcd_aware, g.freeze);
 }
 
 template <typename T, int ALG, int DVMAX, int FIXED_DV = 0>
 void launch_vn(const Code* c, const T* c2v, const T* prior, T* marg, const u64* live, u64* xbits, const Geometry& g, hipStream_t st) {
     constexpr int UNR = unroll_for((DVMAX + 1) * (int)sizeof(T));
     hipLaunchKernelGGL((k_vn<T, ALG, DVMAX, UNR, FIXED_DV>), dim3(task_blocks(g.tiles, g.vn_chunks, g.xcd_aware)), dim3(64, 4), 0, st, c->d_col_ptr, c->d_col_edge,
-                       c2v, prior, marg, live, xbits, c->n, c->E, g.tiles, g.vn_chunks, g.vpw, g.xcd_aware);
+                       c2v, prior, marg, live, xbits, c->n, c->E, g.tiles, g.vn_chunks, g.vpw, g.xcd_aware, g.freeze);
 }
 
 template <typename T, int ALG>
@@ -656,6 +661,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
 
     Geometry g;
     g.tiles = tiles;
+    g.freeze = soft_out != nullptr ? 1 : 0;
     // Nodes per wave.  The marginal lines a check pass gathers are re-used dv times; the fewer tiles are in flight at once, the
     // more of those re-reads hit on chip -- so a tile is cut into MANY short wave tasks (tile-major task order).  Measured on one
     // MI355X (sweep of 32 768 frames of the (3,6) n = 64 800 shape, profiles/r03_stream_chunking.txt): 64 checks per wave 20.9 ms,
@@ -743,7 +749,11 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                 ++polls;
                 // Read the OLDEST poll once a newer one is enqueued behind it (its event has long fired: a block of sweeps lies in
                 // between); with a single-tile batch, or an unbounded run, there is nothing to overlap and the newest is read at once.
-                const bool eager = max_iter <= 0 || cur_tiles < 2;
+                // LONG sweeps (more than ~1.5 ms of streaming work: n = 64 800 x 512 tiles is 19 ms) also read the newest at once: the
+                // host round trip is a percent of one sweep, and the repack decision then rests on the live counts of THIS check point
+                // instead of those of a sweep ago -- while frames leave by the thousand per sweep (profiles/r05_config5_timeline.txt).
+                const double sweep_us_now = (double)cur_tiles * 64.0 * sizeof(T) * (4.0 * E + n) / 5.0e6;
+                const bool eager = max_iter <= 0 || cur_tiles < 2 || sweep_us_now > 1500.0;
                 while (!pending.empty() && (pending.size() >= 2 || eager)) {
                     const PendingPoll pp = pending.front();
                     pending.erase(pending.begin());
@@ -1187,7 +1197,9 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
     const int cpw = env_int("LDPC_STREAM_CPW", 4), vpw = env_int("LDPC_STREAM_VPW", 16);
     const int cn_chunks = (m + cpw - 1) / cpw, vn_chunks = (n + vpw - 1) / vpw;
     const int cap = max_iter > 0 ? max_iter : 100000;
-    const int poll_every = 4;
+    // the live counters are read (synchronously) every fourth sweep; every sweep where a sweep is more than ~1.5 ms of streaming work
+    // (the round trip is then a percent of it, and frames leave by the thousand per sweep: the repack should not wait three sweeps)
+    const int poll_every = (double)tiles * 64.0 * (8.0 * E + 4.0 * n) / 5.0e6 > 1500.0 ? 1 : 4;
     const bool reg36 = c->min_dc == c->max_dc && c->max_dc == 6;
     const bool dv3 = c->min_dv == c->max_dv && c->max_dv == 3;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
