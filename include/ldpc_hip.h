@@ -83,6 +83,22 @@ int ldpc_decoder_last_repacks(ldpc_decoder_t dec, int* repacks);
  * Synchronises the device. */
 int ldpc_decoder_grid_violations(ldpc_decoder_t dec, int64_t* count, int64_t* frames, int64_t cap, int reset);
 
+/* The same redo list WITHOUT a host round trip (exact-in-fp32 Monte-Carlo rounds kept in flight, ldpc_decoders_amd/montecarlo.py): the
+ * list as it lives in device memory -- list_dev[0] = frames set aside since the last reset, list_dev[1 .. cap] their global indices --
+ * consumed on a stream by ldpc_channel_list (the priors of exactly those frames) -> ldpc_decode (fp64 decoder, `rows` frames: rows beyond
+ * the list decode whatever the buffer holds and are not counted) -> ldpc_count_errors_list (counts the first min(list_dev[0], rows) rows,
+ * each into the counter row of ITS round: counters_dev + ((frame - frame_base) / round_stride) * counter_stride, so that `nrounds` guarded
+ * launches may share one redo pass and still keep one exact counter row per round; redone2_dev[0] += the rows counted, redone2_dev[1] += 1
+ * if the list held more than `rows`: the caller must treat those rounds as failed) -> ldpc_decoder_grid_list_reset.  The guarded kernel
+ * of the NEXT launch of the same decoder must be ordered behind the reset.  No upstream counterpart (see LDPC_FLAG_PRIOR_GRID). */
+int ldpc_decoder_grid_list(ldpc_decoder_t dec, uint64_t** list_dev, int64_t* cap, void* stream);
+int ldpc_decoder_grid_list_reset(ldpc_decoder_t dec, void* stream);
+int ldpc_channel_list(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, const uint64_t* list_dev,
+                      int64_t rows, int32_t n, void* priors_dev, void* stream);
+int ldpc_count_errors_list(const uint8_t* xhat_dev, int codeword, const int32_t* iters_dev, const uint64_t* list_dev, int64_t rows, int32_t n,
+                           int32_t hist_bins, int64_t* counters_dev, int64_t counter_stride, uint64_t frame_base, uint64_t round_stride,
+                           int64_t nrounds, int64_t* redone2_dev, void* stream);
+
 /* Fused-backend plan of this decoder: out8 = {wavefronts per frame (0 = fused backend unavailable), conflict-free LDS gather cycles per sweep, extra bank-conflict
  * cycles with the trivial placement, extra cycles with the planned placement, resident waves per CU, LDS bytes per
  * frame, check rounds, variable rounds}. */

@@ -340,6 +340,42 @@ class DecoderHandle:
                                                      counters.data_ptr(), st))
         return int(cnt)
 
+    # ---- exact-in-fp32 rounds without a host round trip (montecarlo.DeviceSimulator sends them in blocks)
+    REDO_ROWS = 256  # frames of one BLOCK of rounds the fp64 sibling re-decodes at most (a 65 536-frame round at 1-2 dB sets aside 1-15)
+
+    def grid_list_dev(self):
+        """Device address of this decoder's redo list ([0] = count, [1..] = global frame indices) -- ``ldpc_decoder_grid_list``."""
+        import torch
+
+        p, cap = ctypes.c_void_p(), ctypes.c_int64(0)
+        _lib.check(_lib.load().ldpc_decoder_grid_list(self.h, ctypes.byref(p), ctypes.byref(cap), torch.cuda.current_stream().cuda_stream))
+        return p.value
+
+    def redo_on_stream(self, param, codeword, seed, stream_id, max_iter, k, counters, redone2, frame_base, round_stride, hist_bins=0):
+        """Enqueue, on the CURRENT torch stream, the fp64 re-decode of every frame the guarded kernels set aside since the list was last reset
+        (``simulate(..., flags=grid)``, one or several rounds): their priors are drawn again from the device-resident list
+        (``ldpc_channel_list``), decoded by the fp64 sibling, counted into the row of their round -- ``counters`` is [rounds, >= 4 + hist_bins],
+        round = (frame - frame_base) / round_stride -- and the list is reset.  ``redone2`` (int64[2], device) += [frames counted, 1 if the list
+        was longer than REDO_ROWS].  No host synchronisation when the sibling runs on the LDS-resident kernels."""
+        import torch
+
+        lib, n, rows = _lib.load(), self.code.n, self.REDO_ROWS
+        st = torch.cuda.current_stream().cuda_stream
+        lst = self.grid_list_dev()
+        if getattr(self, "_redo_pri", None) is None:
+            self._redo_pri = torch.zeros((rows, n), dtype=torch.float32, device="cuda")
+            self._redo_x = torch.zeros((rows, n), dtype=torch.uint8, device="cuda")
+            self._redo_it = torch.zeros((rows,), dtype=torch.int32, device="cuda")
+        h64 = self._fp64_sibling()
+        _lib.check(lib.ldpc_channel_list(_lib.CHANNEL["biawgn"] | _lib.ch_prior_grid(k), _lib.DTYPE["f32"], float(param), int(codeword), int(seed),
+                                         int(stream_id), lst, rows, n, self._redo_pri.data_ptr(), st))
+        h64.decode_device(self._redo_pri.double(), None, max_iter, xhat=self._redo_x, iters=self._redo_it)
+        nrounds, stride = (counters.shape[0], counters.stride(0)) if counters.dim() == 2 else (1, counters.shape[0])
+        _lib.check(lib.ldpc_count_errors_list(self._redo_x.data_ptr(), int(codeword), self._redo_it.data_ptr(), lst, rows, n, hist_bins,
+                                              counters.data_ptr(), int(stride), int(frame_base), int(round_stride), int(nrounds),
+                                              redone2.data_ptr(), st))
+        _lib.check(lib.ldpc_decoder_grid_list_reset(self.h, st))
+
     def last_repacks(self):
         """Streaming backend: how often the last decode re-formed its tiles from the live frames."""
         r = ctypes.c_int(0)

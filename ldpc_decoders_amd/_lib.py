@@ -47,6 +47,10 @@ SIGNATURES = {
     "ldpc_decoder_last_stats": (_c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
     "ldpc_decoder_last_repacks": (_c.c_int, [_P, _c.POINTER(_c.c_int)]),
     "ldpc_decoder_grid_violations": (_c.c_int, [_P, _c.POINTER(_c.c_int64), _P, _c.c_int64, _c.c_int]),
+    "ldpc_decoder_grid_list": (_c.c_int, [_P, _c.POINTER(_P), _c.POINTER(_c.c_int64), _P]),
+    "ldpc_decoder_grid_list_reset": (_c.c_int, [_P, _P]),
+    "ldpc_channel_list": (_c.c_int, [_c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_uint64, _c.c_uint64, _P, _c.c_int64, _c.c_int32, _P, _P]),
+    "ldpc_count_errors_list": (_c.c_int, [_P, _c.c_int, _P, _P, _c.c_int64, _c.c_int32, _c.c_int32, _P, _c.c_int64, _c.c_uint64, _c.c_uint64, _c.c_int64, _P, _P]),
     "ldpc_decoder_fused_info": (_c.c_int, [_P, _c.POINTER(_c.c_double)]),
     "ldpc_plan_layout": (_c.c_int, [_c.c_int32, _c.c_int32, _c.c_int64, _P, _P, _c.c_int, _c.c_int, _c.c_int64, _c.c_char_p,
                                     _c.POINTER(_c.c_double)]),

@@ -355,6 +355,56 @@ int ldpc_decoder_grid_violations(ldpc_decoder_t h, int64_t* count, int64_t* fram
     });
 }
 
+int ldpc_decoder_grid_list(ldpc_decoder_t h, uint64_t** list_dev, int64_t* cap, void* stream) {
+    return guarded("ldpc_decoder_grid_list", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !list_dev) return LDPC_E_ARG;
+        LDPC_HIP_TRY(hipSetDevice(d->code->device));
+        if (!d->gridviol.p) {  // as the first guarded launch would: count + list, zeroed
+            LDPC_TRY(d->gridviol.reserve((size_t)(1 + 4095) * 8));
+            LDPC_HIP_TRY(hipMemsetAsync(d->gridviol.p, 0, (size_t)(1 + 4095) * 8, (hipStream_t)stream));
+        }
+        *list_dev = (uint64_t*)d->gridviol.p;
+        if (cap) *cap = 4095;
+        return LDPC_OK;
+    });
+}
+
+int ldpc_decoder_grid_list_reset(ldpc_decoder_t h, void* stream) {
+    return guarded("ldpc_decoder_grid_list_reset", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d) return LDPC_E_ARG;
+        if (!d->gridviol.p) return LDPC_OK;
+        LDPC_HIP_TRY(hipSetDevice(d->code->device));
+        LDPC_HIP_TRY(hipMemsetAsync(d->gridviol.p, 0, 8, (hipStream_t)stream));
+        return LDPC_OK;
+    });
+}
+
+int ldpc_channel_list(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, const uint64_t* list_dev, int64_t cap,
+                      int32_t n, void* priors, void* stream) {
+    return guarded("ldpc_channel_list", [&]() -> int {
+        if (cap < 0 || n <= 0 || dtype < 0 || dtype > 1 || !priors || !list_dev) {
+            set_error("ldpc_channel_list: bad arguments");
+            return LDPC_E_ARG;
+        }
+        return channel_generate_list(channel, dtype, param, codeword, seed, stream_id, list_dev, cap, n, priors, (hipStream_t)stream);
+    });
+}
+
+int ldpc_count_errors_list(const uint8_t* xhat, int codeword, const int32_t* iters, const uint64_t* list_dev, int64_t rows, int32_t n,
+                           int32_t hist_bins, int64_t* counters, int64_t counter_stride, uint64_t frame_base, uint64_t round_stride, int64_t nrounds,
+                           int64_t* redone2, void* stream) {
+    return guarded("ldpc_count_errors_list", [&]() -> int {
+        if (!xhat || !iters || !counters || !list_dev || !redone2 || rows < 0 || n <= 0 || hist_bins < 0 || nrounds < 1 || counter_stride < 4 + hist_bins) {
+            set_error("ldpc_count_errors_list: bad arguments");
+            return LDPC_E_ARG;
+        }
+        return count_errors_list(xhat, codeword, iters, list_dev, rows, n, hist_bins, counters, counter_stride, frame_base, round_stride, nrounds, redone2,
+                                 (hipStream_t)stream);
+    });
+}
+
 int ldpc_decoder_last_stats(ldpc_decoder_t h, int* backend, int* sweeps) {
     return guarded("ldpc_decoder_last_stats", [&]() -> int {
         Decoder* d = (Decoder*)h;

@@ -29,11 +29,15 @@ __device__ __forceinline__ int64_t word_of_frame(const WordBook& wb, uint64_t se
 template <typename T, bool WORDS>
 __global__ __launch_bounds__(256) void k_biawgn(double sigma, double inv_var2, int codeword, uint64_t seed, uint32_t stream,
                                                 uint64_t frame0, int64_t B, int n, int blocks_per_frame, T* __restrict__ priors, WordBook wb,
-                                                double grid_scale) {
+                                                double grid_scale, const unsigned long long* __restrict__ list) {
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t f = gid / blocks_per_frame;
     const int j = (int)(gid - f * blocks_per_frame);
     if (f >= B) return;
+    // `list` (ldpc_channel_list): row f is global frame list[1 + f], for the first min(list[0], B) rows -- a frame list that lives in
+    // device memory (the redo list of the exactness guard): no host round trip between the kernel that wrote it and this one
+    if (list && (unsigned long long)f >= list[0]) return;
+    if (list) frame0 = list[1 + f] - (uint64_t)f;
     const Philox4 p = philox_word_block(seed, stream, frame0 + (uint64_t)f, (uint32_t)j);
     T z[4];
     box_muller<T>(p.w[0], p.w[1], z[0], z[1]);
@@ -220,6 +224,40 @@ __global__ __launch_bounds__(256) void k_count_bits(const uint32_t* __restrict__
         if (s_hist[i]) atomicAdd(&counters[4 + i], (unsigned long long)s_hist[i]);
 }
 
+// The counters of k_count for the rows of a device-resident frame list (the fp64 re-decodes of the exactness guard): row i < min(list[0], rows)
+// is global frame list[1 + i] and is counted into the counter row of ITS round -- (frame - frame_base) / round_stride -- so that a block of
+// Monte-Carlo rounds that shared one redo pass keeps one exact counter row per round.  One wave per frame, direct atomics (a handful of frames).
+__global__ __launch_bounds__(256) void k_count_list(const uint8_t* __restrict__ xhat, int codeword, const int32_t* __restrict__ iters,
+                                                    const unsigned long long* __restrict__ list, int64_t rows, int n, int hist_bins,
+                                                    unsigned long long* __restrict__ counters, int64_t counter_stride, unsigned long long frame_base,
+                                                    unsigned long long round_stride, int64_t nrounds, unsigned long long* __restrict__ redone) {
+    const unsigned long long have = list[0];
+    const int64_t B = have < (unsigned long long)rows ? (int64_t)have : rows;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&redone[0], (unsigned long long)B);
+        if (have > (unsigned long long)rows) atomicAdd(&redone[1], 1ull);
+    }
+    const int lane = threadIdx.x & 63;
+    for (int64_t f = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); f < B; f += (int64_t)gridDim.x * 4) {
+        int err = 0;
+        const uint8_t* row = xhat + f * n;
+        for (int v = lane; v < n; v += 64) err += row[v] != (uint8_t)codeword;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) err += __shfl_xor(err, off, 64);
+        if (lane == 0) {
+            int64_t r = round_stride ? (int64_t)((list[1 + f] - frame_base) / round_stride) : 0;
+            r = r < 0 ? 0 : (r >= nrounds ? nrounds - 1 : r);
+            unsigned long long* c = counters + r * counter_stride;
+            const int it = iters[f];
+            atomicAdd(&c[0], 1ull);
+            if (err > 0) atomicAdd(&c[1], 1ull);
+            if (err > 0) atomicAdd(&c[2], (unsigned long long)err);
+            atomicAdd(&c[3], (unsigned long long)it);
+            if (hist_bins > 0) atomicAdd(&c[4 + (it < hist_bins ? it : hist_bins - 1)], 1ull);
+        }
+    }
+}
+
 // 4-byte-per-lane coalesced copy with a known byte count: calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE for the access
 // width the streaming kernels use (MI355X_MICROARCH.md: the counters are only calibrated for 16-byte-per-lane streams)
 __global__ __launch_bounds__(256) void k_copy4(const float* __restrict__ src, float* __restrict__ dst, int64_t nwords) {
@@ -239,9 +277,20 @@ int channel_generate(int channel, int dtype, double param, int codeword, uint64_
     return channel_generate_words(channel, dtype, param, codeword, nullptr, 0, seed, stream_id, frame0, B, n, priors, y, nullptr, st);
 }
 
+// rows = the frames of a device-resident list ([0] = how many, [1..] = global frame indices), at most `cap` of them (BI-AWGN)
+int channel_generate_list(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, const uint64_t* list_dev, int64_t cap,
+                          int32_t n, void* priors, hipStream_t st) {
+    if ((channel & 0xff) != CH_BIAWGN || !list_dev) {
+        set_error("ldpc_channel_list: BI-AWGN with a device frame list");
+        return LDPC_E_ARG;
+    }
+    return channel_generate_words(channel, dtype, param, codeword, nullptr, 0, seed, stream_id, 0, cap, n, priors, nullptr, nullptr, st,
+                                  (const unsigned long long*)list_dev);
+}
+
 int channel_generate_words(int channel, int dtype, double param, int codeword, const uint8_t* codebook, int64_t K, uint64_t seed,
                            uint64_t stream_id, uint64_t frame0, int64_t B, int32_t n, void* priors, uint8_t* y, uint8_t* sent,
-                           hipStream_t st) {
+                           hipStream_t st, const unsigned long long* list) {
     if (B <= 0) return LDPC_OK;
     const bool words = codebook != nullptr;
     if (words && (K <= 0 || K > ((int64_t)1 << 31) || !sent)) {
@@ -276,11 +325,11 @@ int channel_generate_words(int channel, int dtype, double param, int codeword, c
         const double var = pow(10.0, -param / 10.0);  // src/biawgn.py:10
         const double sigma = sqrt(var), k = raw ? -1.0 : 2.0 / var;  // the kernel writes -(k*y): k = -1 hands over y itself
         if (dtype == DT_F64) {
-            if (words) hipLaunchKernelGGL((k_biawgn<double, true>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, wb, gs);
-            else hipLaunchKernelGGL((k_biawgn<double, false>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, wb, gs);
+            if (words) hipLaunchKernelGGL((k_biawgn<double, true>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, wb, gs, list);
+            else hipLaunchKernelGGL((k_biawgn<double, false>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (double*)priors, wb, gs, list);
         } else {
-            if (words) hipLaunchKernelGGL((k_biawgn<float, true>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, wb, gs);
-            else hipLaunchKernelGGL((k_biawgn<float, false>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, wb, gs);
+            if (words) hipLaunchKernelGGL((k_biawgn<float, true>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, wb, gs, list);
+            else hipLaunchKernelGGL((k_biawgn<float, false>), grid, block, 0, st, sigma, k, codeword, seed, (uint32_t)stream_id, frame0, B, n, bpf, (float*)priors, wb, gs, list);
         }
     } else if (channel == CH_BSC || channel == CH_BEC) {
         if (!y) {
@@ -336,6 +385,17 @@ int count_errors_bits(const uint32_t* bits, const uint32_t* erased, const uint32
     const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
     hipLaunchKernelGGL(k_count_bits, dim3(grid), dim3(256), (size_t)hist_bins * sizeof(unsigned int), st, bits, erased, sent_bits, codeword, iters, B,
                        n, (n + 31) / 32, hist_bins, (unsigned long long*)counters);
+    LDPC_HIP_TRY(hipGetLastError());
+    return LDPC_OK;
+}
+
+int count_errors_list(const uint8_t* xhat, int codeword, const int32_t* iters, const uint64_t* list_dev, int64_t rows, int32_t n, int32_t hist_bins,
+                      int64_t* counters, int64_t counter_stride, uint64_t frame_base, uint64_t round_stride, int64_t nrounds, int64_t* redone2,
+                      hipStream_t st) {
+    if (rows <= 0) return LDPC_OK;
+    hipLaunchKernelGGL(k_count_list, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xhat, codeword, iters, (const unsigned long long*)list_dev, rows, n,
+                       hist_bins, (unsigned long long*)counters, counter_stride, (unsigned long long)frame_base, (unsigned long long)round_stride, nrounds,
+                       (unsigned long long*)redone2);
     LDPC_HIP_TRY(hipGetLastError());
     return LDPC_OK;
 }

@@ -154,9 +154,15 @@ int fused_decode(Decoder* d, const void* priors, const uint8_t* y0, int64_t B, i
 int channel_generate(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id,
                      uint64_t frame0, int64_t B, int32_t n, void* priors, uint8_t* y, hipStream_t st);
 int channel_generate_words(int channel, int dtype, double param, int codeword, const uint8_t* codebook, int64_t K, uint64_t seed,
-                           uint64_t stream_id, uint64_t frame0, int64_t B, int32_t n, void* priors, uint8_t* y, uint8_t* sent, hipStream_t st);
+                           uint64_t stream_id, uint64_t frame0, int64_t B, int32_t n, void* priors, uint8_t* y, uint8_t* sent, hipStream_t st,
+                           const unsigned long long* list = nullptr);
+int channel_generate_list(int channel, int dtype, double param, int codeword, uint64_t seed, uint64_t stream_id, const uint64_t* list_dev, int64_t cap,
+                          int32_t n, void* priors, hipStream_t st);
 int count_errors_words(const uint8_t* xhat, const uint8_t* sent, int sent_per_frame, int codeword, const int32_t* iters, int64_t B, int32_t n,
                        int32_t hist_bins, int64_t* counters, hipStream_t st);
+int count_errors_list(const uint8_t* xhat, int codeword, const int32_t* iters, const uint64_t* list_dev, int64_t rows, int32_t n, int32_t hist_bins,
+                      int64_t* counters, int64_t counter_stride, uint64_t frame_base, uint64_t round_stride, int64_t nrounds, int64_t* redone2,
+                      hipStream_t st);
 int count_errors(const uint8_t* xhat, const uint8_t* sent, int codeword, const int32_t* iters, int64_t B, int32_t n,
                  int32_t max_iter_hist, int64_t* counters, hipStream_t st);
 

@@ -231,6 +231,14 @@ constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
 #define LDPC_GRID_OPAQUE_CN 15
 #define LDPC_GRID_OPAQUE_VN 15
 #endif
+// (measured, round 5, tools/ab_grid.sh: the regular two-wave shape of n = 1200 is 5 % faster with 8 + 8 packed words, the irregular and the
+// 16-wave shapes are fastest with all of them packed)
+#ifndef LDPC_GRID2_OPAQUE_CN
+#define LDPC_GRID2_OPAQUE_CN 8
+#define LDPC_GRID2_OPAQUE_VN 8
+#endif
+constexpr int grid_opaque_cn(int nw, int vrx) { return (nw == 2 && vrx == 0) ? LDPC_GRID2_OPAQUE_CN : LDPC_GRID_OPAQUE_CN; }
+constexpr int grid_opaque_vn(int nw, int vrx) { return (nw == 2 && vrx == 0) ? LDPC_GRID2_OPAQUE_VN : LDPC_GRID_OPAQUE_VN; }
 constexpr int SIM_ACC_LANE0 = 60;  // hist_bins <= 60 (fused_simulate_supported)
 __device__ __forceinline__ void sim_count(unsigned& accv, int lane, int err, int it, int hist_bins) {
     const int bin = it < hist_bins ? it : hist_bins - 1;  // no histogram: -1, no lane
@@ -298,9 +306,9 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
     auto opaque_tables = [&]() {  // see sim_opaque_cn
         if constexpr (SIM) {
 #pragma unroll
-            for (int i = 0; i < (GRID ? LDPC_GRID_OPAQUE_CN : sim_opaque_cn(ALG, NW, VRX)) && i < CNW; ++i) asm volatile("" : "+v"(cn_idx[i]));
+            for (int i = 0; i < (GRID ? grid_opaque_cn(NW, VRX) : sim_opaque_cn(ALG, NW, VRX)) && i < CNW; ++i) asm volatile("" : "+v"(cn_idx[i]));
 #pragma unroll
-            for (int i = 0; i < (GRID ? LDPC_GRID_OPAQUE_VN : sim_opaque_vn(ALG, NW, VRX)) && i < VNW; ++i) asm volatile("" : "+v"(vn_idx[i]));
+            for (int i = 0; i < (GRID ? grid_opaque_vn(NW, VRX) : sim_opaque_vn(ALG, NW, VRX)) && i < VNW; ++i) asm volatile("" : "+v"(vn_idx[i]));
         }
     };
     auto vmap_of = [&](int q) -> int {
@@ -562,6 +570,12 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                     for (int j = 0; j < DC; ++j) v[j] = mg[r & 1][j] - c2v_old[r][j];
 #pragma unroll
                     for (int j = 0; j < DC; ++j) a[j] = __builtin_fabsf(v[j]);
+                    // GRID, rows without padding positions (regular shapes): every outgoing magnitude of a row is its first or second minimum,
+                    // and the second minimum of the row is at most the larger of ANY two of its entries -- one v_max3_f32 per row bounds all six
+                    // (conservative: it may set a frame aside that the per-edge watch would have kept; LLRs of thousands only occur in the
+                    // diverging frames the guard exists for)
+                    constexpr bool GRID_ROW_BOUND = GRID && VRX == 0 && DC >= 2;
+                    if constexpr (GRID_ROW_BOUND) gmax = fmaxf(fmaxf(gmax, a[0]), a[1]);
 
                     // XOR of the raw words, three inputs per instruction (v_bitop3_b32, truth table 0x96)
 #pragma unroll
@@ -636,7 +650,7 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                         // GRID: the guard watches the outgoing magnitudes and the marginals.  Both below L = 2^(21-k) keeps every sum of the
                         // sweep exact: v2c = marg - c2v_old stays below 2L, a partial sum of up to 8 messages below 8L = 2^(24-k).  (The
                         // incoming |v2c| themselves are not watched: a short row's padding position is +inf by construction.)
-                        if constexpr (GRID) gmax = fmaxf(gmax, mag);
+                        if constexpr (GRID && !GRID_ROW_BOUND) gmax = fmaxf(gmax, mag);
                         float c;  // mag | ((vx ^ v[j]) & sign bit)
                         asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(c) : "v"(vx ^ __float_as_uint(v[j])), "s"(sign_mask), "v"(mag));
                         c2v_old[r][j] = c;

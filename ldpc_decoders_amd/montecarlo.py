@@ -61,7 +61,7 @@ class DeviceSimulator:
     overlaps the decode of round k+1, and no host synchronisation sits between kernels.  ``run_round`` = launch + finish (the
     synchronous form)."""
 
-    DEPTH = 2  # rounds in flight in run_point / bench.py
+    DEPTH = 2  # rounds (or blocks of rounds, launch_rounds) in flight in run_point / bench.py
 
     def __init__(self, handle, channel, max_iter, codeword=0, seed=0x5EED1200, comm=None, hist_bins=0, device="cuda", prior_grid=None):
         """``device``: where the counters live -- "cuda" always in the product (the handle is a HIP decoder); "cpu" lets the N > 1 driver
@@ -77,11 +77,13 @@ class DeviceSimulator:
         self.prior_grid, self.redone = prior_grid, 0
         if prior_grid is not None and (channel != "biawgn" or int(codeword) not in (0, 1)):
             raise ValueError("--prior-grid: min-sum over BI-AWGN with the all-zero / all-one word")
-        k = 4 + self.hist_bins
+        # exact-in-fp32 rounds carry two more words behind the counters: frames re-decoded in fp64, and a flag "the redo list overflowed"
+        k = 4 + self.hist_bins + (2 if prior_grid is not None else 0)
         on_gpu = device == "cuda"
         self._slots = [dict(dev=torch.zeros(k, dtype=torch.int64, device=device),
                             host=torch.zeros(k, dtype=torch.int64).pin_memory() if on_gpu else torch.zeros(k, dtype=torch.int64),
                             done=torch.cuda.Event() if on_gpu else None, busy=False) for _ in range(self.DEPTH + 1)]
+
         self._next = 0
         # lanes = (decoder, HIP stream) pairs that rounds alternate over.  One lane (default): everything on the caller's stream.  Two
         # (LDPC_SIM_STREAMS=2, pipelined rounds of the in-kernel path): consecutive rounds run on two streams with two decoders (own frame
@@ -111,13 +113,12 @@ class DeviceSimulator:
             raise RuntimeError("more than %d rounds in flight" % len(self._slots))
         self._next = (self._next + 1) % len(self._slots)
         start, cnt = self.comm.shard(frame0, frames_total)
+        if self.prior_grid is not None:
+            return self._launch_exact_round(slot, param, stream_id, start, cnt)
         h, stream = self._lane()
         with (self.torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
             slot["dev"].zero_()
-            if cnt > 0 and self.prior_grid is not None:
-                self.redone += h.simulate_exact_fp32(param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
-                                                     self.prior_grid, hist_bins=self.hist_bins)  # (reads its redo list: synchronous)
-            elif cnt > 0:
+            if cnt > 0:
                 h.simulate(self.channel, param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
                            flags=flags, hist_bins=self.hist_bins)
             self.comm.all_reduce_sum(slot["dev"], async_on_stream=True)
@@ -134,8 +135,10 @@ class DeviceSimulator:
         import os
 
         h = self.h
-        if self.codeword == -1 or self.prior_grid is not None or self.device != "cuda" or not hasattr(h, "rounds_per_launch"):
+        if self.codeword == -1 or self.device != "cuda" or not hasattr(h, "rounds_per_launch"):
             return 1
+        if self.prior_grid is not None:  # exact-in-fp32 mode: one fp64 redo pass per block of eight guarded launches
+            return 8 if h.last_stats()[0] == "fused" else 1
         if os.environ.get("LDPC_SIM_STREAMS", "1") == "2":  # the two-stream experiment alternates single rounds over two decoders
             return 1
         return int(h.rounds_per_launch())
@@ -145,7 +148,7 @@ class DeviceSimulator:
         split over ranks like ``launch_round`` -- as one call with one counter row per round and ONE all-reduce of the whole block; returns a
         ticket for ``finish_rounds``."""
         torch = self.torch
-        k = 4 + self.hist_bins
+        k = 4 + self.hist_bins + (2 if self.prior_grid is not None else 0)
         blk = None
         for b in self._multi:
             if not b["busy"] and b["dev"].shape[0] == rounds:
@@ -157,7 +160,13 @@ class DeviceSimulator:
             self._multi.append(blk)
         start, cnt = self.comm.shard(frame0, frames_total)
         blk["dev"].zero_()
-        if cnt > 0:
+        if cnt > 0 and self.prior_grid is not None:
+            for r in range(rounds):
+                self.h.simulate(self.channel, param, self.codeword, self.seed, stream_id, start + r * frames_total, cnt, self.max_iter, blk["dev"][r],
+                                flags=_lib.flag_prior_grid(self.prior_grid), hist_bins=self.hist_bins)
+            self.h.redo_on_stream(param, self.codeword, self.seed, stream_id, self.max_iter, self.prior_grid, blk["dev"], blk["dev"][0][4 + self.hist_bins:],
+                                  start, frames_total, hist_bins=self.hist_bins)
+        elif cnt > 0:
             self.h.simulate_rounds(self.channel, param, self.codeword, self.seed, stream_id, start, cnt, rounds, frames_total, self.max_iter,
                                    blk["dev"], flags=flags, hist_bins=self.hist_bins)
         self.comm.all_reduce_sum(blk["dev"], async_on_stream=True)
@@ -172,14 +181,50 @@ class DeviceSimulator:
         if blk["done"] is not None:
             blk["done"].synchronize()
         blk["busy"] = False
-        return blk["host"].numpy().copy()
+        out = blk["host"].numpy().copy()
+        if self.prior_grid is not None:
+            k = 4 + self.hist_bins
+            self._check_redo(out[0, k:])
+            out = out[:, :k]
+        return out
+
+    # ---- exact-in-fp32 mode: the rounds stay in flight.  The guarded fp32 kernels run back to back; the frames they set aside stay on a
+    # device-resident list and are re-decoded in fp64 by ONE redo pass per block of rounds, enqueued behind the block's last kernel on the
+    # same stream -- priors drawn again on the device from the listed frame indices, every frame counted into the row of its own round --
+    # followed by the all-reduce and the copy-out.  No host round trip anywhere; the redo pass (0.25 ms: a few frames, fifty sweeps of
+    # latency) is paid once per block instead of once per round.
+    def _launch_exact_round(self, slot, param, stream_id, start, cnt):
+        k = 4 + self.hist_bins
+        slot["dev"].zero_()
+        if cnt > 0:
+            self.h.simulate(self.channel, param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
+                            flags=_lib.flag_prior_grid(self.prior_grid), hist_bins=self.hist_bins)
+            self.h.redo_on_stream(param, self.codeword, self.seed, stream_id, self.max_iter, self.prior_grid, slot["dev"], slot["dev"][k:],
+                                  start, 0, hist_bins=self.hist_bins)
+        self.comm.all_reduce_sum(slot["dev"], async_on_stream=True)
+        slot["host"].copy_(slot["dev"], non_blocking=True)
+        slot["done"].record()
+        slot["busy"] = True
+        return slot
+
+    def _check_redo(self, extra):
+        """extra = [frames re-decoded in fp64, redo-list overflows] of a finished round / block."""
+        if extra[1] != 0:
+            raise _lib.LdpcHipError("prior grid 2^-%d: more than %d frames of one block of rounds beyond the exactness guard -- the grid is too fine "
+                                    "for this operating point" % (self.prior_grid, self.h.REDO_ROWS))
+        self.redone += int(extra[0])
 
     def finish_round(self, slot):
         """Wait for one launched round; returns its whole-job counters (numpy int64)."""
         if slot["done"] is not None:
             slot["done"].synchronize()
         slot["busy"] = False
-        return slot["host"].numpy().copy()
+        out = slot["host"].numpy().copy()
+        if self.prior_grid is not None:
+            k = 4 + self.hist_bins
+            self._check_redo(out[k:])
+            out = out[:k]
+        return out
 
     def run_round(self, param, stream_id, frame0, frames_total, flags=0):
         """Decode global frames [frame0, frame0+frames_total) split over ranks; returns the reduced counters (numpy)."""
@@ -190,7 +235,7 @@ class DeviceSimulator:
         streaming kernels, the ADMM composition and ``--codeword -1`` poll / synchronise inside ``simulate``, so a second round in
         flight buys them nothing and would only be decoded for the bin when the stopping rule fires."""
         h = self.h
-        if self.codeword == -1 or not hasattr(h, "last_stats") or self.prior_grid is not None:
+        if self.codeword == -1 or not hasattr(h, "last_stats"):
             return 1
         return self.DEPTH if h.last_stats()[0] == "fused" else 1
 
