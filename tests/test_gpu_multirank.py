@@ -34,3 +34,35 @@ def test_two_ranks_equal_one_rank():
     assert two["value"] > 0 and two["roofline"]["kernel_class"] == "fused_decode" and two["roofline"]["kernel"].startswith("k_fused_f64<")
     assert two["timed_blocks"] == 5 and two["ms_per_step_min"] <= two["ms_per_step"] <= two["ms_per_step_max"]
     assert one["frames_counted"] == two["frames_counted"] == 2 * 8192 and one["bit_errors"] == two["bit_errors"]
+
+
+def _bench_flags(nproc, port, flags):
+    env = dict(os.environ, LDPC_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--no-cpu-baseline", "--points"] + flags
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(1800)
+def test_strong_split_on_the_streaming_backend_and_multi_round_launches_with_two_ranks():
+    # (1) BASELINE configs 4 / 5 state their batch for the whole node: `--total-batch T` splits ONE fixed total over the ranks (strong
+    # scaling).  Streaming backend (pipeline depth 1: the decode polls the host), T = 1001 is odd: the ranks hold 501 + 500 frames.
+    flags = ["--steps", "2", "--warmup", "1", "--repeats", "1", "--total-batch", "1001", "--snr", "2.0", "--precision", "f32", "--backend", "stream"]
+    one, two = _bench_flags(1, 29731, flags), _bench_flags(2, 29732, flags)
+    assert one["scaling"] == two["scaling"] == "strong" and two["config"]["total_batch"] == 1001 and two["config"]["batch_per_gpu"] == 501
+    assert one["config"]["backend"] == two["config"]["backend"] == "stream"
+    for key in ("frames_counted", "word_errors", "bit_errors", "mean_sweeps", "wer", "ber"):
+        assert one[key] == two[key], key
+    assert one["frames_counted"] == 2 * 1001 and two["roofline"]["bound"] == "hbm"
+    # (2) the erasure decoder sends up to eight steps per launch (ldpc_simulate_rounds); with two ranks every step's frame range is still
+    # split in rank order (round_stride = the whole job's frames per step) and each step keeps its own counter row
+    flags = ["--steps", "11", "--warmup", "2", "--repeats", "1", "--decoder", "SPA", "--channel", "bec", "--param", "0.41", "--total-batch", "4097"]
+    one, two = _bench_flags(1, 29733, flags), _bench_flags(2, 29734, flags)
+    assert one["config"]["steps_per_launch"] == two["config"]["steps_per_launch"] == 8 and two["config"]["decoder"] == "BEC"
+    for key in ("frames_counted", "word_errors", "bit_errors", "mean_sweeps", "wer", "ber"):
+        assert one[key] == two[key], key
+    assert one["frames_counted"] == 11 * 4097 and one["word_errors"] > 0
