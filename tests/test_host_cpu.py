@@ -50,6 +50,16 @@ def test_argument_errors_are_reported_not_thrown():
     assert rc == -1
     with pytest.raises(_lib.LdpcHipError):
         _lib.check(rc)
+    # the round-5 entry points refuse null handles / buffers with LDPC_E_ARG before anything touches a device
+    buf = (ctypes.c_uint64 * 8)()
+    assert lib.ldpc_decode_bits(None, None, None, 4, 10, 0, buf, None, buf, None) == -1 and b"ldpc_decode_bits" in lib.ldpc_last_error()
+    assert lib.ldpc_decode_host_bits(None, None, None, 4, 10, 0, buf, None, buf) == -1
+    assert lib.ldpc_count_errors_bits(None, None, None, 0, None, 4, 7, 0, buf, None) == -1
+    assert lib.ldpc_simulate_rounds(None, 0, 1.0, 0, 1, 0, 0, 64, 2, 64, 10, 0, 0, buf, None) == -1
+    assert lib.ldpc_channel_list(0, 0, 1.0, 0, 1, 0, None, 4, 7, buf, None) == -1
+    assert lib.ldpc_count_errors_list(None, 0, None, None, 4, 7, 0, buf, 4, 0, 0, 1, buf, None) == -1
+    p = ctypes.c_void_p()
+    assert lib.ldpc_decoder_grid_list(None, ctypes.byref(p), None, None) == -1 and lib.ldpc_decoder_grid_list_reset(None, None) == -1
 
 
 @pytest.mark.parametrize("name", ["4_2_test", "6_2_3_ldpc", "7_4_hamming", "12_3_4_ldpc"])
