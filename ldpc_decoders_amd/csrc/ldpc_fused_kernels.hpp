@@ -217,12 +217,13 @@ constexpr int sim_opaque_vn(int, int, int) { return LDPC_SIM_OPAQUE_VN_WORDS; }
 #else
 constexpr int sim_opaque_cn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_MSA ? 0 : 15;           // one frame per CU (16 waves): min-sum by the compiler's own allocation (see MAD in the kernel)
-    if (vrx == 0) return alg == ALG_MSA ? 0 : 15;         // regular shapes: min-sum 0 + 2, sum-product all
+    if (vrx == 0) return alg == ALG_MSA ? 0 : 6;          // regular shapes: min-sum 0 + 2; sum-product 6 + 8 (round 5: the pair-tree rule needs
+                                                          // fewer registers than prefix / suffix did -- 15 + 15 before; tools/ab_spa.sh: +5.7 %)
     return 15;                                            // irregular shapes (wide variable rounds)
 }
 constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_SPA ? 15 : 0;
-    if (vrx == 0) return alg == ALG_SPA ? 15 : 2;
+    if (vrx == 0) return alg == ALG_SPA ? 8 : 2;
     return alg == ALG_MSA ? 8 : 15;
 }
 #endif
