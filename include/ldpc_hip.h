@@ -40,7 +40,9 @@ enum { LDPC_CH_RAW_OBSERVATION = 0x100 };  /* or-ed into LDPC_CH_BIAWGN for ldpc
 enum { LDPC_FLAG_NO_EARLY_EXIT = 1 };                                /* NOT reference behaviour: run exactly max_iter   */
 /* Exact-in-fp32 min-sum (no upstream counterpart; the injection point is BPA.decode(y, priors), src/bpa.py:17): priors rounded to
  * multiples of 2^-k.  Min-sum only adds, subtracts and compares, so on such priors fp32 arithmetic reproduces the fp64 reference BIT FOR
- * BIT for as long as every message stays below 2^(24-k) / 8; the LDS-resident fp32 kernels check exactly that and count the frames
+ * BIT for as long as every prior and every check message stays below L = 2^(24-k) / (dv_max + 2), rounded down to a power of two (2^(21-k)
+ * for variable degrees up to 6): then no partial sum, marginal or v2c of any sweep reaches 2^(24-k).  The LDS-resident fp32 kernels check
+ * exactly that (priors once per frame, outgoing check magnitudes in every sweep) and count the frames
  * that do not (ldpc_decoder_grid_violations -- a run is exact iff the count is 0).  k = 0..23.
  *   ldpc_simulate / ldpc_decode: flags | LDPC_FLAG_PRIOR_GRID(k)   (simulate: quantises the generated priors AND arms the guard; decode: arms the guard;
  *                                both return LDPC_E_UNSUPPORTED for an fp32 / fp16 decoder that runs on the streaming kernels, which have no guard;

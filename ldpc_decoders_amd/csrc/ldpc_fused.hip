@@ -680,7 +680,12 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
             }
             a.grid_scale = (float)ldexp(1.0, grid_k);
             a.grid_inv = (float)ldexp(1.0, -grid_k);
-            a.grid_limit = (float)ldexp(1.0, 24 - grid_k - 3);  // partial sums of up to 8 messages stay below 2^(24-k)
+            // L = 2^(24-k) / (dv_max + 2), rounded down to a power of two: |prior| < L and |c2v| < L keep every sum of the iteration
+            // below 2^(24-k), i.e. exact (the kernel's comment at `gmax`)
+            // (irregular shapes keep the older scheme: magnitudes AND marginals below 2^(21-k))
+            int shift = shape.VRX > 0 ? 3 : 0;
+            while ((1 << shift) < c->max_dv + 2 && shape.VRX == 0) ++shift;
+            a.grid_limit = (float)ldexp(1.0, 24 - grid_k - shift);
             a.grid_viol = (unsigned long long*)d->gridviol.p;
         }
     }

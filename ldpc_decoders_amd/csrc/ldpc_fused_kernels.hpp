@@ -232,11 +232,12 @@ constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
 #define LDPC_GRID_OPAQUE_CN 15
 #define LDPC_GRID_OPAQUE_VN 15
 #endif
-// (measured, round 5, tools/ab_grid.sh: the regular two-wave shape of n = 1200 is 5 % faster with 8 + 8 packed words, the irregular and the
-// 16-wave shapes are fastest with all of them packed)
+// (measured, round 5, tools/ab_grid2.sh / ab_grid.sh: the regular two-wave shape of n = 1200 -- whose guard no longer watches marginals --
+// is fastest with the plain kernel's own 0 + 2 packed words: 3.00-3.04 ms per 65 536 frames against 3.17 (8 + 8) and 3.33 (15 + 15); the
+// irregular and the 16-wave shapes are fastest with all of them packed)
 #ifndef LDPC_GRID2_OPAQUE_CN
-#define LDPC_GRID2_OPAQUE_CN 8
-#define LDPC_GRID2_OPAQUE_VN 8
+#define LDPC_GRID2_OPAQUE_CN 0
+#define LDPC_GRID2_OPAQUE_VN 2
 #endif
 constexpr int grid_opaque_cn(int nw, int vrx) { return (nw == 2 && vrx == 0) ? LDPC_GRID2_OPAQUE_CN : LDPC_GRID_OPAQUE_CN; }
 constexpr int grid_opaque_vn(int nw, int vrx) { return (nw == 2 && vrx == 0) ? LDPC_GRID2_OPAQUE_VN : LDPC_GRID_OPAQUE_VN; }
@@ -510,8 +511,25 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
 
         int it = 0;
         bool left_at_0 = false;
-        float gmax = 0.0f;  // GRID: largest |v2c| / |marginal| of this lane in this frame
-
+        // GRID -- the exactness guard.  Every value of the iteration is a multiple of 2^-k; fp32 adds / subtracts of such values are exact
+        // while the result stays below 2^(24-k).  With P = max |prior| and C = max |c2v| of a frame: a partial sum of the variable update is
+        // at most dv C, the marginal P + dv C, v2c = marg - c2v_old at most P + (dv + 1) C -- so P < L and C < L with
+        // L = 2^(24-k) / (dv_max + 2) (rounded down to a power of two by the host: A.grid_limit) keep EVERY sum of every sweep exact.  The
+        // priors are watched once per frame (here), the outgoing magnitudes in every check phase; marginals need no watching of their
+        // own (rounds 3-4 watched them in every variable phase: 4 instructions per variable row and sweep).  That is the scheme of the
+        // REGULAR shapes (GRID_PRIORS); the irregular ones keep the older one -- outgoing magnitudes and marginals both below 2^(21-k),
+        // watched in every sweep: a partial sum of up to 8 messages stays below 2^(24-k) -- because a pass over the priors costs them
+        // registers they do not have (measured both as a per-slot pass here and inside the noise loop: 5-9 % slower; tools/ab_grid.sh).
+        constexpr bool GRID_PRIORS = GRID && VRX == 0;
+        float gmax = 0.0f;  // largest |prior| / |c2v| (/ |marginal|) this lane has seen in this frame
+        if constexpr (GRID_PRIORS) {
+#pragma unroll
+            for (int q = 0; q < VRW; ++q) {
+                // (not watched: SIM's padded slots -- stale words)
+                const bool watched = !SIM || ((valid >> q) & 1u);
+                gmax = fmaxf(gmax, watched ? __builtin_fabsf(prior[q]) : 0.0f);
+            }
+        }
         if (!SIM && A.y0 != nullptr) {
             // iteration-0 test of the received hard word (src/bpa.py:20,29): park it in the marg area as -+1
             const uint8_t* yf = A.y0 + fr * n;
@@ -648,9 +666,8 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                         if constexpr (ALG == ALG_MSA) mag = fminf(pre[j], suf[j]);
                         else if constexpr (DC == 6) mag = pre[j];
                         else mag = spa2_llr_of_eo(spa2_join(spa_f2{pre[j], preo[j]}, spa_f2{suf[j], sufo[j]}));
-                        // GRID: the guard watches the outgoing magnitudes and the marginals.  Both below L = 2^(21-k) keeps every sum of the
-                        // sweep exact: v2c = marg - c2v_old stays below 2L, a partial sum of up to 8 messages below 8L = 2^(24-k).  (The
-                        // incoming |v2c| themselves are not watched: a short row's padding position is +inf by construction.)
+                        // GRID, rows that may hold padding positions: the outgoing magnitudes themselves are watched (the incoming |v2c|
+                        // cannot be: a short row's padding position is +inf by construction)
                         if constexpr (GRID && !GRID_ROW_BOUND) gmax = fmaxf(gmax, mag);
                         float c;  // mag | ((vx ^ v[j]) & sign bit)
                         asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(c) : "v"(vx ^ __float_as_uint(v[j])), "s"(sign_mask), "v"(mag));
@@ -677,7 +694,7 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                 auto finish_var = [&](auto Q_, float s) {
                     constexpr int q = decltype(Q_)::value;
                     const float m1 = prior[q] + s;
-                    if constexpr (GRID) {
+                    if constexpr (GRID && !GRID_PRIORS) {
                         // (not watched: SIM's padded slots -- stale words -- and the "certain" slot that pads short check rows: +inf by design)
                         const bool watched = (!SIM || ((valid >> q) & 1u)) && !(VRX > 0 && ((dummy >> q) & 1u));
                         gmax = fmaxf(gmax, watched ? __builtin_fabsf(m1) : 0.0f);
