@@ -577,7 +577,13 @@ static void unpack_bits_host(const uint32_t* bits, const uint32_t* era, int64_t 
         return;
     }
     std::vector<std::thread> pool;
-    for (int t = 0; t < nt; ++t) pool.emplace_back(rows, B * t / nt, B * (t + 1) / nt);
+    int started = 0;
+    try {
+        pool.reserve((size_t)nt);
+        for (; started < nt - 1; ++started) pool.emplace_back(rows, B * started / nt, B * (started + 1) / nt);
+    } catch (...) {  // no more threads to be had: the rows nobody took are expanded on this one (a joinable thread must never be destroyed)
+    }
+    rows(B * started / nt, B);
     for (std::thread& t : pool) t.join();
 }
 
