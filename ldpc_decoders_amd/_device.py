@@ -341,7 +341,7 @@ class DecoderHandle:
         return int(cnt)
 
     # ---- exact-in-fp32 rounds without a host round trip (montecarlo.DeviceSimulator sends them in blocks)
-    REDO_ROWS = 256  # frames of one BLOCK of rounds the fp64 sibling re-decodes at most (a 65 536-frame round at 1-2 dB sets aside 1-15)
+    REDO_ROWS = 512  # frames of one BLOCK of rounds the fp64 sibling re-decodes at most (a 65 536-frame round at 1-2 dB sets aside 1-15)
 
     def grid_list_dev(self):
         """Device address of this decoder's redo list ([0] = count, [1..] = global frame indices) -- ``ldpc_decoder_grid_list``."""
