@@ -534,11 +534,21 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
                 pref = ("k_becs_cn" if kind == "stream_check_pass" else "k_becs_vn<") if alg == "BEC" else \
                        ("k_cn16<" if kind == "stream_check_pass" else "k_vn16<") if f16 else \
                        ("k_cn<" if kind == "stream_check_pass" else "k_vn<") + ("double" if s == 8 else "float")
+                traffic_note = None
                 for k, v in committed("roofline_counters.json").items():
                     if k.startswith("hbm:") and (":" + pref) in k and v.get("workload", "").startswith(args.code + " "):
                         traffic = v["hbm_bytes_per_launch"]
+                        # the counters were collected on launches of another batch (a full-size PMC pass of n = 64 800 takes minutes): the
+                        # streaming kernels move bytes in proportion to the frames of a launch, so the figure is scaled to this run's batch
+                        try:
+                            cb = int(v["workload"].split(" batch ")[1].split()[0])
+                            if cb != rank_batch:
+                                traffic = int(traffic * rank_batch / cb)
+                                traffic_note = "PMC bytes per launch of %d frames x %d / %d" % (cb, rank_batch, cb)
+                        except (IndexError, ValueError):
+                            pass
                 roof = dict(bound="hbm", achieved=round(sweep_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(sweep_gbs / HBM_PEAK_GBS, 4),
-                            algorithmic_bytes_per_frame_sweep=bytes_per_frame_iter, passes=legs, traffic=traffic,
+                            algorithmic_bytes_per_frame_sweep=bytes_per_frame_iter, passes=legs, traffic=traffic, traffic_scaled=traffic_note,
                             kernel="k_becs_cn + k_becs_vn (one sweep)" if alg == "BEC" else "k_cn16 + k_vn16 (one sweep)" if f16 else "k_cn + k_vn (one sweep)",
                             note="streaming backend: achieved = executed frame-sweeps x algorithmic bytes (SURVEY 8(d): s(4E+n); fp16 storage 8E+4n; "
                                  "erasure bit planes (4E+m+3n)/4) / HIP-event time of the two passes; "

@@ -1046,10 +1046,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                 if (max_iter > 0 && it >= max_iter) break;
                 if constexpr (NW == 4) {  // 128 VGPRs: the packed tables stay packed (unpacked once per use); hoisted out of the loop, the
                                           // unpacked addresses would be spilled and re-read from scratch in every sweep
+#ifndef LDPC_F64_OPAQUE_CN  // how many table words stay packed: every check-phase word, six of the eight variable-phase words -- the most the
+#define LDPC_F64_OPAQUE_CN 64  // 128 registers take unpacked without a spill (round 5, tools/ab_sim.sh c2_f64: 5.48-5.52 ms per 65 536 frames against
+#define LDPC_F64_OPAQUE_VN 6   // 5.53-5.56 with all of them packed; nothing packed: 5.45-5.48 with 17 spilled registers)
+#endif
 #pragma unroll
-                    for (int i = 0; i < CNW; ++i) asm volatile("" : "+v"(cn_idx[i]));
+                    for (int i = 0; i < CNW && i < LDPC_F64_OPAQUE_CN; ++i) asm volatile("" : "+v"(cn_idx[i]));
 #pragma unroll
-                    for (int i = 0; i < VNW; ++i) asm volatile("" : "+v"(vn_idx[i]));
+                    for (int i = 0; i < VNW && i < LDPC_F64_OPAQUE_VN; ++i) asm volatile("" : "+v"(vn_idx[i]));
                 }
                 // ---- check phase (+ syndrome of the previous decisions: sign of the gathered marginals)
                 uint32_t synd = 0;   // min-sum: bit 31 = some owned check is unsatisfied (XOR of IEEE sign bits)
