@@ -450,3 +450,33 @@ def test_fused_kernels_reach_their_hand_off_words_as_lds():
 
     flat = kernel_resources.flat_report()
     assert not flat, "flat accesses in the fused kernels: %s" % flat[:5]
+
+
+def test_bench_workload_selectors_and_cpu_baseline_dispatch():
+    # bench.py --decoder / --channel / --param: the reference's selectors (src/main.py:11-12, src/models.py:3); the `bec` selector pairs
+    # with the ternary erasure decoder whatever SPA / MSA says; the CPU baseline leg follows the same selectors (C port; scipy leg for
+    # the LLR decoders) -- exercised here on the (7,4) Hamming code with a fraction of a second of CPU work
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.resolve_workload("MSA", "biawgn", None, 1.0) == ("MSA", "biawgn", 1.0)
+    assert bench.resolve_workload("SPA", "bsc", None, 1.0) == ("SPA", "bsc", 0.07)
+    assert bench.resolve_workload("SPA", "bec", None, 1.0) == ("BEC", "bec", 0.40)
+    assert bench.resolve_workload("MSA", "bec", 0.35, 1.0) == ("BEC", "bec", 0.35)
+    assert bench.resolve_workload("BEC", "biawgn", None, 1.0)[:2] == ("BEC", "bec")
+    code = bench.load_code("7_4_hamming")
+    assert bench.bytes_per_frame_sweep(code, "MSA", "f32") == 4 * (4 * code.E + code.n)      # s(4E + n)
+    assert bench.bytes_per_frame_sweep(code, "SPA", "f64") == 8 * (4 * code.E + code.n)
+    assert bench.bytes_per_frame_sweep(code, "MSA", "f16") == 8 * code.E + 4 * code.n
+    assert bench.bytes_per_frame_sweep(code, "BEC", "f32") == (4 * code.E + code.m + 3 * code.n) / 4.0
+    for alg, channel, param in (("SPA", "bsc", 0.07), ("BEC", "bec", 0.40), ("MSA", "biawgn", 2.0)):
+        c = bench.cpu_baseline(code, alg, channel, param, 10, "f32", 0.05)
+        assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["physical_cores"] and channel in c["sample"]
+        if alg == "BEC":
+            assert "skipped" in c["scipy"]
+        else:
+            assert c["scipy"].get("value", 0) > 0, c["scipy"]
+    args = bench.parse_args(["--decoder", "SPA", "--channel", "bec", "--total-batch", "1000", "--gpus", "2"])
+    assert args.decoder == "SPA" and args.channel == "bec" and args.total_batch == 1000 and args.param is None and args.points is None
