@@ -28,6 +28,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cstdlib>
+#include <string>
 
 #include "ldpc_cn.hpp"
 #include "ldpc_common.hpp"
@@ -711,6 +712,12 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     DevBuf* set_xbits[2] = {&d->xbits, &d->xbits2};
     DevBuf* set_live[2] = {&d->live, &d->live2};
     DevBuf* set_fmap[2] = {&d->fmap, &d->fmap2};
+    const bool rent_policy = [] {
+        const char* e = std::getenv("LDPC_STREAM_REPACK_POLICY");
+        return e && std::string(e) == "rent";
+    }();
+    double rent_waste = 0.0;
+    int rent_last_it = 0;
     int cur = 0;                 // which buffer set holds the state
     int32_t* fmap = nullptr;     // frame index of (tile, lane); null = identity (never repacked)
     int cur_tiles = tiles;
@@ -764,7 +771,22 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                         sweeps = pp.sweeps;
                         break;
                     }
-                    if (repack_ok && pp.tiling_current && pp.it > 0 && lt >= 2 && (double)lf <= repack_fill * 64.0 * lt && it + 1 < cap) {
+                    // When to repack.  Default: the live frames fill at most `repack_fill` (0.75) of the live tiles.
+                    // LDPC_STREAM_REPACK_POLICY=rent selects "rent or buy" instead -- repack as soon as the tile-sweeps spent on departed
+                    // lanes since the last repack have reached what a repack would cost now (measured: about 0.95 sweep-equivalents per
+                    // tile of the mean of source and destination tiles) -- within a factor two of the best schedule for any departure
+                    // curve.  Measured round 5 (tools/ab_repack_policy.sh, two boxes): it skips the repack at 59 % fill of the n = 64 800
+                    // batch at 2 dB (4 repacks instead of 5) for -1.2 % ... +-0 step time, n = 10 000 fp64 -0.4 ... -0.7 %, fp32 +-0:
+                    // inside the run-to-run spread, so the threshold rule stays the default.
+                    bool want_repack = (double)lf <= repack_fill * 64.0 * lt;
+                    if (rent_policy) {
+                        const int ntr = (lf + 63) / 64;
+                        rent_waste += (double)(lt - ntr) * (double)(pp.it - rent_last_it);
+                        rent_last_it = pp.it;
+                        want_repack = ntr < lt && rent_waste >= 0.95 * 0.5 * (double)(lt + ntr);
+                    }
+                    if (repack_ok && pp.tiling_current && pp.it > 0 && lt >= 2 && want_repack && it + 1 < cap) {
+                        rent_waste = 0.0;
                         const int nt = (lf + 63) / 64;
                         const int nx = 1 - cur;
                         // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs later)
@@ -1193,6 +1215,12 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
     DevBuf* set_fmap[2] = {&d->fmap, &d->fmap2};
     int32_t* fmap = nullptr;  // frame of (tile, lane); null = identity (never repacked)
     int cur = 0, repacks = 0;
+    const bool rent_policy = [] {
+        const char* e = std::getenv("LDPC_STREAM_REPACK_POLICY");
+        return e && std::string(e) == "rent";
+    }();
+    double rent_waste = 0.0;
+    int rent_last_it = 0;
 
     const int cpw = env_int("LDPC_STREAM_CPW", 4), vpw = env_int("LDPC_STREAM_VPW", 16);
     const int cn_chunks = (m + cpw - 1) / cpw, vn_chunks = (n + vpw - 1) / vpw;
@@ -1226,7 +1254,15 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
                     all_left = true;
                     break;
                 }
-                if (repack_ok && it > 0 && lt >= 2 && (double)lf <= repack_fill * 64.0 * lt && it + 1 < cap) {
+                bool want_repack = (double)lf <= repack_fill * 64.0 * lt;
+                if (rent_policy) {  // rent or buy, as in run<T>()
+                    const int ntr = (lf + 63) / 64;
+                    rent_waste += (double)(lt - ntr) * (double)(it - rent_last_it);
+                    rent_last_it = it;
+                    want_repack = ntr < lt && rent_waste >= 0.95 * 0.5 * (double)(lt + ntr);
+                }
+                if (repack_ok && it > 0 && lt >= 2 && want_repack && it + 1 < cap) {
+                    rent_waste = 0.0;
                     const int nt = (lf + 63) / 64, np = (nt + 1) / 2, nx = 1 - cur;
                     // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs at the end)
                     launch_unpack(d, xbits, xhat, B, n, tiles, fmap, st);
