@@ -88,10 +88,16 @@ comm = dist.init_from_env()
 import torch.distributed as td
 sim = DeviceSimulator(_handle(), "biawgn", 50, 0, 7, comm, hist_bins=51)
 a = sim.run_point(2.2, 0, min_wec=40, batch_per_rank=4096)
+# the block forms (several rounds per launch: [rounds, k] counters through ONE all-reduce): erasure decoder, exact-in-fp32 mode
+simb = DeviceSimulator(_handle("BEC", "f32"), "bec", 50, 0, 7, comm, hist_bins=51)
+b = simb.run_point(0.42, 0, min_wec=3000, batch_per_rank=2048)
+sime = DeviceSimulator(_handle("MSA", "f32"), "biawgn", 50, 0, 7, comm, hist_bins=51, prior_grid=8)
+e = sime.run_point(2.0, 0, min_wec=900, batch_per_rank=2048)
 t = torch.arange(5, dtype=torch.int64, device="cuda") * (1 << 40)
 comm.all_reduce_sum(t)
 json.dump({"backend": comm.backend, "group": comm.group, "initialized": td.is_initialized(), "td_backend": td.get_backend() if td.is_initialized() else None,
-           "point": a, "big": t.cpu().tolist(), "max": comm.max_float(1.5)}, open(sys.argv[1], "w"))
+           "point": a, "bec": b, "exact": e, "rpl": [simb.rounds_per_launch(), sime.rounds_per_launch()], "big": t.cpu().tolist(), "max": comm.max_float(1.5)},
+          open(sys.argv[1], "w"))
 dist.finalize()
 '''
 
@@ -113,6 +119,8 @@ def test_rccl_all_reduce_of_the_counters_on_one_gpu(tmp_path):
     assert outs["rccl"]["backend"] == "nccl" and outs["rccl"]["group"] and outs["rccl"]["td_backend"] == "nccl"
     assert not outs["plain"]["initialized"]
     assert outs["rccl"]["point"] == outs["plain"]["point"] and outs["rccl"]["point"]["wec"] >= 40
+    assert outs["rccl"]["rpl"] == [8, 8] and outs["rccl"]["bec"] == outs["plain"]["bec"] and outs["rccl"]["exact"] == outs["plain"]["exact"]
+    assert outs["rccl"]["bec"]["wec"] >= 3000 and outs["rccl"]["bec"]["tot"] % 2048 == 0 and outs["rccl"]["exact"]["wec"] >= 900
     assert outs["rccl"]["big"] == [i << 40 for i in range(5)] and outs["rccl"]["max"] == 1.5
 
 
