@@ -247,6 +247,30 @@ def test_simulate_rounds_rows_equal_round_by_round_calls(name, backend, B, strid
     assert (rows[0] == 2 * one[0]).all()
 
 
+def test_simulate_rounds_with_more_rounds_in_flight_than_accumulator_slots():
+    # One slab of 32 frames per round and thousands of rounds: every workgroup is handed slabs of many different rounds in quick
+    # succession, frames of three rounds would be in flight at once -- the kernel's two accumulator slots force the third slab to WAIT
+    # (its ticket is held, `pending`) until one of the two rounds has no frame left.  Rows must still be exact, each against its own launch.
+    import torch
+    from ldpc_decoders_amd._device import DecoderHandle
+    from ldpc_decoders_amd.codes import Code
+
+    g = golden_edges("1200_3_6_rand_ldpc_1")
+    h = DecoderHandle(Code.from_edges(g.m, g.n, g.chk, g.var), "BEC", "f32", "auto")
+    R, B, bins = 6000, 32, 51
+    rows = torch.zeros((R, 4 + bins), dtype=torch.int64, device="cuda")
+    h.simulate_rounds("bec", 0.42, 0, 5, 2, 10_000, B, R, B, 50, rows, hist_bins=bins)
+    assert (rows[:, 0] == B).all()
+    one = torch.zeros((R, 4 + bins), dtype=torch.int64, device="cuda")
+    for r in range(0, R, 7):  # every seventh round alone (857 launches)
+        h.simulate("bec", 0.42, 0, 5, 2, 10_000 + r * B, B, 50, one[r], hist_bins=bins)
+    assert (rows[::7] == one[::7]).all()
+    # and the sum over all rows equals one long launch of the same frame range
+    tot = torch.zeros(4 + bins, dtype=torch.int64, device="cuda")
+    h.simulate("bec", 0.42, 0, 5, 2, 10_000, R * B, 50, tot, hist_bins=bins)
+    assert (rows.sum(dim=0) == tot).all() and int(tot[1]) > 0
+
+
 def test_simulate_rounds_of_an_llr_decoder_and_forced_flushes():
     # LLR decoders take the round-by-round path; the erasure kernel's 16-bit partial sums are flushed every 4096 frames of a workgroup
     import torch
