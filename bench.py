@@ -1,37 +1,39 @@
 #!/usr/bin/env python3
-"""Headline benchmark: decoded frames/s of the BP hot path on MI355X, n=1200 (3,6)-regular min-sum, max_iter=50.
+"""Benchmark of the BP hot path on MI355X: decoded frames/s (+ roofline of the dominant kernel, + the CPU port timed in the same run).
+
+Default = the headline of BASELINE.json (configs[1]): code 1200_3_6_rand_ldpc_1 (the reference's own H, shipped in ldpc_decoders_amd/data/codes),
+min-sum over BI-AWGN, max_iter 50, 65 536 frames per GPU, fp64 messages -- the reference's own arithmetic: hard decisions and iteration
+counts bit-identical to it -- at 1.0 dB, where every frame fails and therefore executes exactly 50 sweeps (no early-exit benefit).
+`--decoder MSA|SPA|BEC --channel biawgn|bsc|bec --param P --code C --precision f64|f32|f16 --batch B` select every other BASELINE
+configuration through the reference's own selectors (src/main.py:11-12, src/models.py:3; `bec` pairs with the ternary erasure decoder
+whatever --decoder says); `--total-batch T` fixes the frames per step over ALL GPUs (strong scaling: configs 4 / 5 state their batch for the
+whole node).  tools/round_measure.sh holds the exact command of every committed line (profiles/rNN_bench*.json).
 
 A "step" is one pass of the hot path over one batch of synthetic input, entirely on the GPU:
-    BI-AWGN channel + LLR (Philox noise, all-zero word) -> flooding min-sum decode (syndrome early exit as in the
-    reference) -> bit/word error counters.
-Workload = BASELINE.json configs[1]: code 1200_3_6_rand_ldpc_1 (the reference's own H, shipped in ldpc_decoders_amd/data/codes), batch
-65 536 frames per GPU.  Message arithmetic: fp64 by default -- the reference's own, hard decisions and iteration counts
-bit-identical to it (LDS-resident fp64 min-sum kernel) --; `--precision f32` is the throughput mode, reported beside it under
-"fp32_mode".  Default operating point 1.0 dB: every frame fails there, so every frame executes exactly 50 sweeps -- the honest
-"50-iteration" number (no early-exit benefit).  `--snr` selects others; `--points` adds 2.0/3.0 dB lines under "points".
+    channel + LLR (Philox noise keyed by the global frame index, all-zero word) -> flooding BP with the syndrome early exit of the
+    reference -> bit / word error counters.
 
-Timing.  W warm-up steps, then the timed block -- EXACTLY K steps enqueued through the pipelined driver (montecarlo.DeviceSimulator: two
-rounds in flight, counters all-reduced on the stream, no host sync between kernels), bracketed by barrier + torch.cuda.synchronize() on
-both sides, MAX over ranks -- is repeated `--repeats` times (default 5): `ms_per_step` / `value` are the MEDIAN block, the spread is
-reported beside them (`ms_per_step_min` / `_max`, `blocks_ms_per_step`).  No per-kernel instrumentation runs inside a timed block; the
-per-kernel durations behind `roofline` come from a SEPARATE pass of the same steps with the library's HIP events on the decode stream
-(`ldpc_decoder_profile`).
+Timing.  W warm-up steps, then the timed block -- EXACTLY K steps enqueued through the pipelined driver (montecarlo.DeviceSimulator: rounds in
+flight, counters all-reduced on the stream, no host sync between kernels; where the decoder takes several steps per launch -- the erasure
+decoder: ldpc_simulate_rounds, one counter row per step -- up to eight steps travel together), bracketed by barrier + torch.cuda.synchronize()
+on both sides, MAX over ranks -- is repeated `--repeats` times (default 5): `ms_per_step` / `value` are the MEDIAN block, the spread is
+reported beside them.  No per-kernel instrumentation runs inside a timed block; the per-kernel durations behind `roofline` come from a
+SEPARATE pass of the same launches with the library's HIP events on the decode stream (`ldpc_decoder_profile`).
 
-Roofline.  `roofline.bound` names the resource that binds the dominant kernel:
-  "lds" / "valu"  the LDS-resident (fused) kernels: frac = busy LDS-array (VALU) cycles / available cycles at 2.4 GHz.  Cycles per
-                  frame-sweep are MEASURED counters of the very kernel that is timed (rocprofv3 --pmc on tools/sim_driver.py, committed as
-                  profiles/roofline_counters.json keyed by the kernel's name, which the library reports) x the frame-sweeps/s of this run.
+Roofline.  `roofline.bound` / `binding_unit` name the resource that binds the dominant kernel, `frac` = achieved / peak OF THAT UNIT:
+  "lds" / "valu"  the LDS-resident kernels: busy cycles of the binding unit (LDS array, LDS issue / transfer path, VALU) / cycles available
+                  at 2.4 GHz.  Cycles per frame-sweep are MEASURED counters of the very kernel that is timed (rocprofv3 --pmc on
+                  tools/sim_driver.py, committed as profiles/roofline_counters.json keyed by the kernel's name) x the frame-sweeps/s of this run.
   "hbm"           the streaming kernels: bytes / HIP-event time / 8 TB/s, with the SURVEY.md 8(d) algorithmic bytes s(4E+n) for the sweep and
                   each pass's own compulsory bytes (check pass s(2E+n), variable pass s(E+2n)); PMC traffic beside it.
-The 8(d) HBM-model figure of a fused kernel is kept as `hbm_model` (flagged: the messages never leave the CU, it bounds nothing).
+The 8(d) HBM-model figure of an LDS-resident kernel is kept as `hbm_model` (flagged: the messages never leave the CU, it bounds nothing).
 
-Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run, one rank per GPU
-(RCCL); frames sharded by global frame index, ONE all-reduce of the counters per step; rank 0 prints ONE JSON line.  Every line --
-N > 1 included -- carries `roofline` (rank 0's kernels), `cpu_baseline` (rank 0's host, timed BEFORE the process touches a GPU or joins
-the process group: the scipy leg forks one worker per host core) and `collective` (backend + the number of ranks an all-reduce of
-ones saw).
-`run_bench(args, comm, make_handle, device)` is the whole driver layer with the decoder handle injected -- tests/test_dist_cpu.py runs
-it on 8 gloo ranks with a CPU stand-in for the handle; `main()` always passes the HIP handle.
+Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run, one rank per GPU (RCCL); frames sharded
+by global frame index, ONE all-reduce of the counters per step (per block of steps); rank 0 prints ONE JSON line.  Every line -- N > 1
+included -- carries `roofline` (rank 0's kernels), `cpu_baseline` (rank 0's host, timed BEFORE the process touches a GPU or joins the
+process group: the scipy leg forks one worker per hardware thread) and `collective` (backend + the number of ranks an all-reduce of ones saw).
+`run_bench(args, comm, make_handle, device)` is the whole driver layer with the decoder handle injected -- tests/test_dist_cpu.py runs it on
+8 gloo ranks with a CPU stand-in for the handle; `main()` always passes the HIP handle.
 """
 import argparse
 import json
