@@ -15,7 +15,7 @@ A "step" is one pass of the hot path over one batch of synthetic input, entirely
 
 Timing.  W warm-up steps, then the timed block -- EXACTLY K steps enqueued through the pipelined driver (montecarlo.DeviceSimulator: rounds in
 flight, counters all-reduced on the stream, no host sync between kernels; where the decoder takes several steps per launch -- the erasure
-decoder: ldpc_simulate_rounds, one counter row per step -- up to eight steps travel together), bracketed by barrier + torch.cuda.synchronize()
+decoder: ldpc_simulate_rounds, one counter row per step -- up to 32 steps travel together), bracketed by barrier + torch.cuda.synchronize()
 on both sides, MAX over ranks -- is repeated `--repeats` times (default 5): `ms_per_step` / `value` are the MEDIAN block, the spread is
 reported beside them.  No per-kernel instrumentation runs inside a timed block; the per-kernel durations behind `roofline` come from a
 SEPARATE pass of the same launches with the library's HIP events on the decode stream (`ldpc_decoder_profile`).

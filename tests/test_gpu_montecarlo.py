@@ -119,7 +119,7 @@ def test_rccl_all_reduce_of_the_counters_on_one_gpu(tmp_path):
     assert outs["rccl"]["backend"] == "nccl" and outs["rccl"]["group"] and outs["rccl"]["td_backend"] == "nccl"
     assert not outs["plain"]["initialized"]
     assert outs["rccl"]["point"] == outs["plain"]["point"] and outs["rccl"]["point"]["wec"] >= 40
-    assert outs["rccl"]["rpl"] == [8, 8] and outs["rccl"]["bec"] == outs["plain"]["bec"] and outs["rccl"]["exact"] == outs["plain"]["exact"]
+    assert outs["rccl"]["rpl"] == [32, 8] and outs["rccl"]["bec"] == outs["plain"]["bec"] and outs["rccl"]["exact"] == outs["plain"]["exact"]
     assert outs["rccl"]["bec"]["wec"] >= 3000 and outs["rccl"]["bec"]["tot"] % 2048 == 0 and outs["rccl"]["exact"]["wec"] >= 900
     assert outs["rccl"]["big"] == [i << 40 for i in range(5)] and outs["rccl"]["max"] == 1.5
 

@@ -58,11 +58,11 @@ def test_strong_split_on_the_streaming_backend_and_multi_round_launches_with_two
     for key in ("frames_counted", "word_errors", "bit_errors", "mean_sweeps", "wer", "ber"):
         assert one[key] == two[key], key
     assert one["frames_counted"] == 2 * 1001 and two["roofline"]["bound"] == "hbm"
-    # (2) the erasure decoder sends up to eight steps per launch (ldpc_simulate_rounds); with two ranks every step's frame range is still
+    # (2) the erasure decoder sends up to 32 steps per launch (ldpc_simulate_rounds); with two ranks every step's frame range is still
     # split in rank order (round_stride = the whole job's frames per step) and each step keeps its own counter row
-    flags = ["--steps", "11", "--warmup", "2", "--repeats", "1", "--decoder", "SPA", "--channel", "bec", "--param", "0.41", "--total-batch", "4097"]
+    flags = ["--steps", "37", "--warmup", "2", "--repeats", "1", "--decoder", "SPA", "--channel", "bec", "--param", "0.41", "--total-batch", "4097"]
     one, two = _bench_flags(1, 29733, flags), _bench_flags(2, 29734, flags)
-    assert one["config"]["steps_per_launch"] == two["config"]["steps_per_launch"] == 8 and two["config"]["decoder"] == "BEC"
+    assert one["config"]["steps_per_launch"] == two["config"]["steps_per_launch"] == 32 and two["config"]["decoder"] == "BEC"
     for key in ("frames_counted", "word_errors", "bit_errors", "mean_sweeps", "wer", "ber"):
         assert one[key] == two[key], key
-    assert one["frames_counted"] == 11 * 4097 and one["word_errors"] > 0
+    assert one["frames_counted"] == 37 * 4097 and one["word_errors"] > 0

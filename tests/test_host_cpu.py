@@ -256,7 +256,7 @@ def test_committed_bench_lines_keep_the_contract():
     spa, bec = lines["bench_config3_spa_bsc"], lines["bench_config3_bec"]
     assert spa["config"]["decoder"] == "SPA" and spa["config"]["channel"] == "bsc" and spa["config"]["batch_per_gpu"] == 65536 and spa["dtype"] == "f32"
     assert bec["config"]["decoder"] == "BEC" and bec["config"]["channel"] == "bec" and bec["config"]["batch_per_gpu"] == 65536
-    assert bec["config"]["steps_per_launch"] == 8 and bec["value"] > 4.0e8   # >= 420 M frames/s at the BASELINE batch
+    assert bec["config"]["steps_per_launch"] in (8, 32) and bec["value"] > 4.0e8   # >= 420 M frames/s at the BASELINE batch
     assert spa["value"] > 2.7e7
     c4, c5 = lines["bench_config4"], lines["bench_config5"]
     assert c4["config"]["n"] == 10000 and c4["config"]["batch_per_gpu"] == 131072 and c4["config"]["backend"] == "fused"

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd $R
 run() { NAME=$1; shift; timeout 900 python bench.py "$@" > $OUT/bench_$NAME.json 2> $OUT/bench_$NAME.err; echo "$NAME rc=$?"; cp $OUT/bench_$NAME.json profiles/${TAG}_bench_$NAME.json 2>/dev/null; }
 run config3_spa_bsc --decoder SPA --channel bsc --param 0.07 --precision f32 --batch 65536 --steps 20 --warmup 3 --cpu-baseline-seconds $CPU_S
-run config3_bec     --decoder SPA --channel bec --param 0.40 --batch 65536 --steps 40 --warmup 5 --cpu-baseline-seconds $CPU_S
+run config3_bec     --decoder SPA --channel bec --param 0.40 --batch 65536 --steps 64 --warmup 8 --cpu-baseline-seconds $CPU_S
 run config4 --code gen:irg:10000 --batch 131072 --snr 1.2 --steps 3 --warmup 1 --repeats 3 --precision f32 --points 1.8 --cpu-baseline-seconds $CPU_S
 run config4_f64_stream --code gen:irg:10000 --batch 32768 --snr 1.8 --steps 2 --warmup 1 --repeats 3 --precision f64 --points --cpu-baseline-seconds $CPU_S
 run config5 --code gen:reg:64800:3:6 --batch 32768 --snr 2.0 --steps 2 --warmup 1 --repeats 3 --precision f32 --points 1.0 --cpu-baseline-seconds $CPU_S

@@ -16,7 +16,7 @@ run() { NAME=$1; shift; timeout 900 python bench.py "$@" > $OUT/$NAME.json 2> $O
 run bench
 run bench_f32 --precision f32 --cpu-baseline-seconds 5
 run bench_config3_spa_bsc --decoder SPA --channel bsc --param 0.07 --precision f32 --batch 65536 --steps 20 --warmup 3 --cpu-baseline-seconds 5
-run bench_config3_bec --decoder SPA --channel bec --param 0.40 --batch 65536 --steps 40 --warmup 5 --cpu-baseline-seconds 5
+run bench_config3_bec --decoder SPA --channel bec --param 0.40 --batch 65536 --steps 64 --warmup 8 --cpu-baseline-seconds 5
 run bench_config4 --code gen:irg:10000 --batch 131072 --snr 1.2 --steps 3 --warmup 1 --repeats 3 --precision f32 --points 1.8 --cpu-baseline-seconds 5
 run bench_config4_f64_stream --code gen:irg:10000 --batch 32768 --snr 1.8 --steps 2 --warmup 1 --repeats 3 --precision f64 --points --cpu-baseline-seconds 5
 run bench_config5 --code gen:reg:64800:3:6 --batch 32768 --snr 2.0 --steps 2 --warmup 1 --repeats 3 --precision f32 --points 1.0 --cpu-baseline-seconds 5
@@ -31,7 +31,7 @@ run bench_driver_command --gpus 1 --steps 20 --warmup 5
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench_f64 -o k -- python3 $R/bench.py --steps 40 --warmup 3 --repeats 2 --no-cpu-baseline --no-profile --points > $OUT/stats_bench_f64.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench_f32 -o k -- python3 $R/bench.py --steps 40 --warmup 3 --repeats 2 --no-cpu-baseline --no-profile --points --precision f32 > $OUT/stats_bench_f32.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench_config3_spa_bsc -o k -- python3 $R/bench.py --decoder SPA --channel bsc --param 0.07 --precision f32 --steps 20 --warmup 3 --repeats 2 --no-cpu-baseline --no-profile --points > $OUT/stats_bench_c3spa.log 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench_config3_bec -o k -- python3 $R/bench.py --decoder SPA --channel bec --param 0.40 --steps 40 --warmup 5 --repeats 2 --no-cpu-baseline --no-profile --points > $OUT/stats_bench_c3bec.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench_config3_bec -o k -- python3 $R/bench.py --decoder SPA --channel bec --param 0.40 --steps 64 --warmup 8 --repeats 2 --no-cpu-baseline --no-profile --points > $OUT/stats_bench_c3bec.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench_config5 -o k -- python3 $R/bench.py --code gen:reg:64800:3:6 --batch 32768 --snr 2.0 --steps 2 --warmup 1 --repeats 1 --precision f32 --no-cpu-baseline --no-profile --points > $OUT/stats_bench_config5.log 2>&1 )
 for v in bench_f64 bench_f32 bench_config3_spa_bsc bench_config3_bec bench_config5; do cp $OUT/stats_$v/k_kernel_stats.csv profiles/${TAG}_kernel_stats_$v.csv 2>/dev/null; done
 timeout 900 python tools/measure_configs.py $TAG > $OUT/all_configs.log 2>&1

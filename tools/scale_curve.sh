@@ -16,7 +16,7 @@ STEPS=${1:-}; WARMUP=${2:-}; shift 2 2>/dev/null
 case $CONFIG in
   2)    FLAGS=""; S=20; W=5 ;;
   3spa) FLAGS="--decoder SPA --channel bsc --param 0.07 --precision f32"; S=20; W=3 ;;
-  3bec) FLAGS="--decoder SPA --channel bec --param 0.40"; S=40; W=5 ;;
+  3bec) FLAGS="--decoder SPA --channel bec --param 0.40"; S=64; W=8 ;;
   4)    FLAGS="--code gen:irg:10000 --total-batch 1048576 --snr 1.2 --precision f32 --points 1.8 --repeats 3"; S=3; W=1 ;;
   5)    FLAGS="--code gen:reg:64800:3:6 --total-batch 262144 --snr 2.0 --precision f32 --points 1.0 --repeats 3"; S=2; W=1 ;;
   *) echo "unknown --config $CONFIG" >&2; exit 2 ;;
