@@ -436,8 +436,9 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
         exact_res = None
         try:
             sim4 = DeviceSimulator(h3, "biawgn", args.max_iter, 0, 0x5EED1200, comm, hist_bins=hist_bins, prior_grid=8)
-            exact_res = run_point(sim4, h3, comm, param, max(4, args.steps // 4), 1, per_round, 0, torch, False, 1)
-            exact_res["redone"], exact_res["steps"] = sim4.redone, max(4, args.steps // 4)
+            exact_steps = max(24, args.steps)  # whole blocks of eight guarded launches (one fp64 redo pass per block)
+            exact_res = run_point(sim4, h3, comm, param, exact_steps, 1, per_round, 0, torch, False, 1)
+            exact_res["redone"], exact_res["steps"] = sim4.redone, exact_steps
             exact_res["depth"] = sim4.pipeline_depth()
             del sim4
         except Exception as e:  # a side leg must not cost the benchmark line
