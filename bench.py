@@ -28,12 +28,17 @@ Roofline.  `roofline.bound` / `binding_unit` name the resource that binds the do
                   each pass's own compulsory bytes (check pass s(2E+n), variable pass s(E+2n)); PMC traffic beside it.
 The 8(d) HBM-model figure of an LDS-resident kernel is kept as `hbm_model` (flagged: the messages never leave the CU, it bounds nothing).
 
-Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run, one rank per GPU (RCCL); frames sharded
-by global frame index, ONE all-reduce of the counters per step (per block of steps); rank 0 prints ONE JSON line.  Every line -- N > 1
+Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 one rank per GPU (RCCL) under torch.distributed.run -- started by the
+caller, or, when bench.py is started as a plain process (no WORLD_SIZE), by bench.py itself: the parent makes no GPU call, starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py <same argv>` as a child process and relays rank 0's line (self_launch);
+a node with fewer than N GPUs, or a WORLD_SIZE that is not N, ends with exit code 3 and NO line.  Frames sharded
+by global frame index, ONE all-reduce of the counters per step (per block of steps); rank 0 prints ONE JSON line.  The default command's
+line also carries `baseline_configs`: BASELINE configs 3-5 (sum-product / BSC, erasure decoder / BEC, n = 10 000, n = 64 800), a few steps
+each through the same run_bench, each with its own `roofline` and (N = 1) `cpu_baseline`.  Every line -- N > 1
 included -- carries `roofline` (rank 0's kernels), `cpu_baseline` (rank 0's host, timed BEFORE the process touches a GPU or joins the
 process group: the scipy leg forks one worker per hardware thread) and `collective` (backend + the number of ranks an all-reduce of ones saw).
 `run_bench(args, comm, make_handle, device)` is the whole driver layer with the decoder handle injected -- tests/test_dist_cpu.py runs it on
-8 gloo ranks with a CPU stand-in for the handle; `main()` always passes the HIP handle.
+8 gloo ranks with a CPU stand-in for the handle; `main()` run as a script always builds the HIP handle.
 """
 import argparse
 import json
@@ -114,7 +119,7 @@ def param_label(channel, param):
     return "%.1f dB" % param if channel == "biawgn" else ("p = %g" % param if channel == "bsc" else "eps = %g" % param)
 
 
-def cpu_baseline(code, alg, channel, param, max_iter, precision="f64", budget_s=10.0):
+def cpu_baseline(code, alg, channel, param, max_iter, precision="f64", budget_s=10.0, scipy_leg=True):
     """CPU baselines on THIS host, on a bounded sample of the same workload (the only leg of this file that touches oracle/):
       "port"   oracle/bp_oracle.c -- a plain-C port of the reference algorithm (min-sum, sum-product, erasure decoder; sparse, so it
                also runs the codes the reference's dense H cannot hold), OpenMP over frames, every host thread;
@@ -165,6 +170,9 @@ def cpu_baseline(code, alg, channel, param, max_iter, precision="f64", budget_s=
                                                                              float(it.mean()))}
     if alg == "BEC":
         out["scipy"] = {"skipped": "the scipy.sparse leg restates the LLR decoders (src/bpa.py); the erasure decoder's CPU figure is the C port"}
+        return out
+    if not scipy_leg:
+        out["scipy"] = {"skipped": "baseline_configs entry: C port only (the scipy leg runs on the configuration's own bench line)"}
         return out
     # per-frame scipy.sparse baseline, one process per core, each decoding its own frame stream for about budget_s seconds
     try:
@@ -303,13 +311,49 @@ def committed(name):
         return {}
 
 
+_CODE_HASHES = None
+
+
+def loaded_kernel_hash(kernel_name):
+    """Hash of the machine code of `kernel_name` in the library this process decodes with (tools/kernel_resources.py: file parsing only)."""
+    global _CODE_HASHES
+    if _CODE_HASHES is None:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import kernel_resources
+            from ldpc_decoders_amd import _lib
+
+            _CODE_HASHES = kernel_resources.kernel_code_hashes(_lib.library_path())
+        except Exception as e:  # the check is evidence hygiene, never a reason to lose the line
+            _CODE_HASHES = {"error": repr(e)}
+    return _CODE_HASHES.get(kernel_name)
+
+
+def counters_freshness(entry, kernel_name):
+    """-> (stale, note).  stale True: the counters were collected on ANOTHER body of this kernel (same name, different machine code) -- the
+    line must not price the new timing with the old cycles; None: no hash to compare (entry older than round 6, or the library unreadable)."""
+    want, have = entry.get("kernel_code_sha"), loaded_kernel_hash(kernel_name)
+    if not want or not have:
+        return None, "unverified: %s" % ("the counters entry carries no kernel_code_sha" if not want else "no code hash for the loaded library (%s)" % _CODE_HASHES.get("error"))
+    if want != have:
+        return True, "STALE: counters collected on kernel code %s (lib %s, HEAD %s), the loaded library holds %s -- re-run tools/collect_rooflines.sh" % (
+            want, (entry.get("lib_sha256") or "?")[:12], (entry.get("head") or "?")[:12], have)
+    return False, "kernel code %s == the code the counters were collected on (HEAD %s)" % (have, (entry.get("head") or "?")[:12])
+
+
 def fused_roofline(kernel_name, frame_sweeps_per_s, cus, counters=None):
     """LDS / VALU roofline of an LDS-resident kernel from its committed PMC counters (profiles/roofline_counters.json, keyed by kernel
-    name): busy cycles per frame-sweep x frame-sweeps/s / (CUs x [4 SIMDs x] 2.4 GHz).  None when the kernel has no committed counters."""
+    name): busy cycles per frame-sweep x frame-sweeps/s / (CUs x [4 SIMDs x] 2.4 GHz).  None when the kernel has no committed counters.
+    Every entry names the machine code it was measured on (`kernel_code_sha`); against another body of the same kernel `frac` is null and
+    `counters_stale` true."""
     counters = committed("roofline_counters.json") if counters is None else counters
     e = counters.get(kernel_name)
     if not e:
         return None
+    stale, fresh_note = counters_freshness(e, kernel_name)
+    if stale:
+        return dict(bound="lds", binding_unit=None, frac=None, achieved=None, peak=round(NOMINAL_CLOCK_HZ * cus * 256 / 1e9, 1), unit="GB/s",
+                    counters_stale=True, counters_check=fresh_note, frame_sweeps_per_s=round(frame_sweeps_per_s, 1), counters_kernel=kernel_name)
     lds = frame_sweeps_per_s * e["lds_idx_active_per_frame_sweep"] / (cus * NOMINAL_CLOCK_HZ)
     valu = frame_sweeps_per_s * e["valu_active_cycles_per_frame_sweep"] / (cus * 4 * NOMINAL_CLOCK_HZ)
     array_peak = NOMINAL_CLOCK_HZ * cus * 256 / 1e9  # the LDS array is 64 banks x 4 B wide per clock and CU
@@ -346,7 +390,8 @@ def fused_roofline(kernel_name, frame_sweeps_per_s, cus, counters=None):
                 peak_clock_hz=NOMINAL_CLOCK_HZ, effective_clock_hz_in_pmc_pass=e.get("effective_clock_hz_in_pmc_pass"),
                 lds_busy_frac_in_pmc_pass=e.get("lds_busy_frac_in_pmc_pass"), valu_busy_frac_in_pmc_pass=e.get("valu_busy_frac_in_pmc_pass"),
                 wave_time_shares=dict(waiting=e.get("wait_any_share"), issue_stall=e.get("wait_inst_any_share"), issuing=e.get("active_inst_any_share")),
-                counters_kernel=kernel_name, counters_workload=e.get("workload"), counters_from=e.get("counters_from"))
+                counters_kernel=kernel_name, counters_workload=e.get("workload"), counters_from=e.get("counters_from"),
+                counters_stale=stale, counters_check=fresh_note)
 
 
 def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
@@ -375,7 +420,7 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
     s = 8 if precision == "f64" else 4
     bytes_per_frame_iter = bytes_per_frame_sweep(code, alg, precision)  # SURVEY.md 8(d) for the LLR decoders
     f16 = precision == "f16"
-    side_legs = not args.no_profile and comm.world == 1 and device == "cuda"
+    side_legs = not args.no_profile and comm.world == 1 and device == "cuda" and not getattr(args, "headline_only", False)
     kernel_pass = not args.no_profile and device == "cuda"
     # frames of one step over all ranks: weak scaling (--batch frames per GPU, the default) or strong (--total-batch frames per step
     # whatever N is -- BASELINE configs 4 and 5 state their batch for the whole 8-GPU node; a total that N does not divide is split
@@ -679,25 +724,123 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0, help="CPU work per baseline leg (C port, scipy processes)")
     ap.add_argument("--no-profile", action="store_true", help="headline only: skip the HIP-event kernel pass and the side legs")
+    ap.add_argument("--no-baseline-configs", action="store_true",
+                    help="default workload only: skip the `baseline_configs` block (BASELINE configs 3-5, a few steps each, on the same line)")
     return ap.parse_args(argv)
 
 
-def main():
-    args = parse_args()
+# BASELINE.json configs 3-5 on the line of the DEFAULT command (`baseline_configs`): the selectors of src/main.py:11-12 / src/models.py:3 that
+# the driver's command never passes.  Each entry = the flags of that configuration's own bench line (tools/round_measure.sh), a few steps.
+BASELINE_CONFIGS = [
+    ("config3_spa_bsc", "BASELINE configs[2]: sum-product over BSC p = 0.07, n = 1200 (3,6), 65 536 frames",
+     ["--decoder", "SPA", "--channel", "bsc", "--param", "0.07", "--precision", "f32", "--batch", "65536", "--steps", "20", "--warmup", "3"]),
+    ("config3_bec", "BASELINE configs[2]: the bec selector's ternary erasure decoder over BEC eps = 0.40, n = 1200 (3,6), 65 536 frames",
+     ["--decoder", "SPA", "--channel", "bec", "--param", "0.40", "--batch", "65536", "--steps", "64", "--warmup", "8"]),
+    ("config4", "BASELINE configs[3]: rate-1/2 irregular n = 10 000 min-sum over BI-AWGN, 131 072 frames per GPU (2^20 over 8 GPUs)",
+     ["--code", "gen:irg:10000", "--batch", "131072", "--snr", "1.2", "--precision", "f32", "--steps", "3", "--warmup", "1"]),
+    ("config5", "BASELINE configs[4]: (3,6)-regular n = 64 800 min-sum over BI-AWGN with per-frame early termination, 32 768 frames per GPU (2^18 over 8 GPUs)",
+     ["--code", "gen:reg:64800:3:6", "--batch", "32768", "--snr", "2.0", "--precision", "f32", "--steps", "2", "--warmup", "1"]),
+]
+
+
+def baseline_config_args(args, flags):
+    """argparse namespace of one `baseline_configs` entry: the entry's own flags, headline-only legs, this run's --gpus."""
+    sub = parse_args(flags + ["--gpus", str(args.gpus), "--repeats", "3", "--points", "--max-iter", str(args.max_iter)])
+    sub.headline_only = True
+    return sub
+
+
+def is_default_workload(args):
+    """True for the command the round driver runs (the headline of BASELINE.json, no selector passed): only that line carries `baseline_configs`."""
+    d = parse_args([])
+    return all(getattr(args, k) == getattr(d, k) for k in ("decoder", "channel", "param", "snr", "max_iter", "code", "precision", "backend", "batch",
+                                                            "total_batch")) and not args.no_profile and not args.no_baseline_configs
+
+
+def condense(line):
+    """What a `baseline_configs` entry keeps of a full bench line."""
+    keep = ("value", "unit", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "timed_blocks", "steps", "warmup", "n_gpus", "scaling", "dtype",
+            "mean_sweeps", "wer", "ber", "frames_counted", "kernel_ms_per_step", "side_kernels_ms_per_step", "host_overhead_ms_per_step",
+            "algorithmic_GBps", "bytes_per_frame_sweep", "roofline", "cpu_baseline")
+    out = {"frames_per_s": line["value"], "workload": line["config"]["workload"], "backend": line["config"]["backend"],
+           "steps_per_launch": line["config"]["steps_per_launch"]}
+    out.update({k: line.get(k) for k in keep})
+    return out
+
+
+def self_launch(args, argv, needs_gpus=True):
+    """`python bench.py --gpus N` (N > 1) started as a PLAIN process: this parent -- which has made no GPU call and makes none -- starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... <this script> <same argv>` as a fresh child process (never exec: a
+    process must not be replaced once anything may have touched the GPU), relays rank 0's JSON line and returns the child's exit code.
+    With fewer than N GPUs: one line saying so, exit code 3 -- never an `n_gpus: 1` line for a `--gpus N` request."""
+    import socket
+    import subprocess
+
+    if needs_gpus:
+        import torch  # device_count() enumerates without initialising the runtime
+
+        have = torch.cuda.device_count()
+        # LDPC_DIST_BACKEND=gloo (tests/test_gpu_multirank.py): several ranks may share a GPU -- RCCL needs one GPU per rank
+        if have < (1 if os.environ.get("LDPC_DIST_BACKEND") == "gloo" else args.gpus):
+            print("bench.py: --gpus %d requested but this node has %d GPU(s); no line printed" % (args.gpus, have), file=sys.stderr)
+            return 3
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(sys.argv[0])] + list(argv)
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in child.stdout:  # rank 0's JSON line goes to stdout untouched; anything else the launcher or a rank printed goes to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln)
+        sys.stdout.flush()
+    return child.wait()
+
+
+def main(argv=None, make_handle=None, device="cuda"):
+    """`make_handle` / `device` exist for tests/test_dist_cpu.py (a CPU stand-in for the decoder handle on gloo ranks, entered through a
+    wrapper script so that the self-launch path is the one under test); bench.py itself always runs the HIP handle on a GPU."""
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, argv, needs_gpus=(device == "cuda")))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; refusing to print a line for another N" % (args.gpus, world_env), file=sys.stderr)
+        sys.exit(3)
     # rank 0 times the CPU baselines first: nothing of HIP / torch.cuda / the process group exists in this process yet, so the scipy
-    # leg may fork its workers, and at N > 1 the other ranks simply wait at the rendezvous meanwhile
-    cpu_base = None
-    if int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu_baseline:
+    # leg may fork its workers, and at N > 1 the other ranks simply wait at the rendezvous meanwhile (~25 s headline + ~4 s per
+    # baseline_configs entry at N = 1; the process-group timeout is 10 min)
+    rank0 = int(os.environ.get("RANK", "0")) == 0
+    subs = [(name, what, baseline_config_args(args, flags)) for name, what, flags in BASELINE_CONFIGS] if is_default_workload(args) else []
+    cpu_base, sub_base = None, {}
+    if rank0 and not args.no_cpu_baseline:
         alg, channel, param = resolve_workload(args.decoder, args.channel, args.param, args.snr)
         cpu_base = cpu_baseline(load_code(args.code), alg, channel, param, args.max_iter, args.precision, args.cpu_baseline_seconds)
+        if world_env == 1:  # the contract: the CPU baseline is timed on rank 0 at N = 1 only; the sub-configurations take the C port alone
+            for name, _, sub in subs:
+                alg, channel, param = resolve_workload(sub.decoder, sub.channel, sub.param, sub.snr)
+                sub_base[name] = cpu_baseline(load_code(sub.code), alg, channel, param, sub.max_iter, sub.precision,
+                                              min(3.0, args.cpu_baseline_seconds), scipy_leg=False)
     from ldpc_decoders_amd import dist
 
-    comm = dist.init_from_env()
-    if comm.world != args.gpus and comm.is_root:
-        print("warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, comm.world), file=sys.stderr)
+    comm = dist.init_from_env(prefer_gpu=(device == "cuda"))
     try:
-        out = run_bench(args, comm, cpu_base=cpu_base)
+        out = run_bench(args, comm, make_handle=make_handle, device=device, cpu_base=cpu_base)
+        block = {}
+        for name, what, sub in subs:
+            t0 = time.time()
+            try:  # a sub-configuration must not cost the headline line -- but every rank takes the same branch (collectives inside)
+                line = run_bench(sub, comm, make_handle=make_handle, device=device, cpu_base=sub_base.get(name))
+                if comm.is_root:
+                    block[name] = dict(condense(line), what=what, flags=" ".join(dict((n, f) for n, _, f in BASELINE_CONFIGS)[name]),
+                                       wall_s=round(time.time() - t0, 1))
+            except Exception as e:
+                block[name] = {"error": repr(e), "what": what}
         if comm.is_root:
+            if subs:
+                out["baseline_configs"] = block
             print(json.dumps(out))
     finally:
         dist.finalize()

@@ -92,6 +92,11 @@ class LdpcHipError(RuntimeError):
     pass
 
 
+def library_path():
+    """Path of the shared library `load()` opens (bench.py hashes its kernels against the committed PMC counters)."""
+    return LIB_PATH
+
+
 def load():
     """Load the HIP library (once).  Raises if it has not been built -- there is no CPU path."""
     global _lib

@@ -212,3 +212,84 @@ def test_bench_strong_scaling_split_on_1_2_4_8_ranks(tmp_path):
                 assert stream == stream1 and start == pos and cnt in (T // world, T // world + 1)
                 pos += cnt
             assert pos == start1 + T
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` started as a PLAIN process (the way the round driver starts --gpus 1): bench.self_launch must start the N
+# ranks itself (a fresh torch.distributed.run child, the parent touching no GPU), relay rank 0's line, and never print a line for another N.
+ENTRY = os.path.join(ROOT, "tests", "bench_cpu_entry.py")
+TINY = ["--steps", "3", "--warmup", "1", "--repeats", "2", "--code", "7_4_hamming", "--snr", "2.0", "--max-iter", "10", "--points", "--no-profile",
+        "--cpu-baseline-seconds", "0.2"]
+
+
+def _plain(argv, env_extra=None, script=ENTRY):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, script] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    return p.returncode, [ln for ln in p.stdout.splitlines() if ln.strip()], p.stderr
+
+
+@pytest.mark.timeout(900)
+def test_plain_bench_command_launches_its_own_ranks():
+    rc1, out1, _ = _plain(["--gpus", "1", "--batch", "192"] + TINY)
+    rc2, out2, err2 = _plain(["--gpus", "2", "--batch", "96"] + TINY)
+    assert rc1 == 0 and rc2 == 0, err2
+    assert len(out1) == 1 and len(out2) == 1, out2             # stdout of the parent = rank 0's JSON line and nothing else
+    one, two = json.loads(out1[0]), json.loads(out2[0])
+    assert two["n_gpus"] == 2 and two["collective"]["ranks_seen"] == 2 and two["collective"]["backend"] == "gloo"
+    assert one["n_gpus"] == 1 and one["collective"]["ranks_seen"] == 1
+    assert "torch.distributed.run" in err2 and "--nproc-per-node 2" in err2
+    for k in ("frames_counted", "word_errors", "bit_errors", "mean_sweeps", "wer", "ber"):   # same global frames, same counters
+        assert one[k] == two[k], k
+    assert two["cpu_baseline"]["value"] > 0 and isinstance(two["roofline"], dict)
+
+
+def test_plain_bench_command_never_prints_a_line_for_another_n():
+    # the real bench.py on a host without GPUs: --gpus 2 must end non-zero with no stdout at all (not an `n_gpus: 1` line)
+    rc, out, err = _plain(["--gpus", "2", "--steps", "1"], script=os.path.join(ROOT, "bench.py"))
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        assert rc == 3 and out == [] and "requested" in err
+    # a WORLD_SIZE that is not --gpus is refused the same way
+    rc, out, err = _plain(["--gpus", "4", "--steps", "1"], env_extra={"WORLD_SIZE": "1", "RANK": "0"}, script=os.path.join(ROOT, "bench.py"))
+    assert rc == 3 and out == [] and "WORLD_SIZE=1" in err
+
+
+@pytest.mark.timeout(900)
+def test_default_line_carries_the_baseline_configs_block():
+    """The `baseline_configs` block of the default command (BASELINE configs 3-5 in bench.py; three tiny stand-ins here): every entry runs
+    through the same run_bench on every rank, carries its own roofline object, and -- at N = 1 only -- its own CPU-port baseline."""
+    env = {"BENCH_TEST_BASELINE_CONFIGS": "1"}
+    rc1, out1, err1 = _plain(["--gpus", "1", "--batch", "96"] + TINY, env)
+    rc2, out2, err2 = _plain(["--gpus", "2", "--batch", "48"] + TINY, env)
+    assert rc1 == 0 and rc2 == 0, err1 + err2
+    one, two = json.loads(out1[0]), json.loads(out2[0])
+    for name, frames in (("tiny_spa", 2 * 64), ("tiny_msa", 3 * 48), ("tiny_f64", 2 * 32)):
+        a, b = one["baseline_configs"][name], two["baseline_configs"][name]
+        assert "error" not in a and "error" not in b, (a, b)
+        assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and a["frames_counted"] == frames and b["frames_counted"] == 2 * frames  # weak scaling
+        assert a["frames_per_s"] > 0 and b["frames_per_s"] > 0 and isinstance(a["roofline"], dict) and "frac" in a["roofline"]
+        assert a["cpu_baseline"]["kind"] == "port" and a["cpu_baseline"]["value"] > 0 and "skipped" in a["cpu_baseline"]["scipy"]
+        assert b["cpu_baseline"] is None                          # contract: the CPU baseline is timed at N = 1 only
+        assert a["flags"].startswith("--code") and a["workload"]
+
+
+def test_baseline_configs_table_names_the_baseline_configs():
+    """The real table: one entry per BASELINE.json config 3-5 selector, flags parse, and only the driver's own command carries the block."""
+    import bench
+
+    names = [n for n, _, _ in bench.BASELINE_CONFIGS]
+    assert names == ["config3_spa_bsc", "config3_bec", "config4", "config5"]
+    d = bench.parse_args(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    assert bench.is_default_workload(d)
+    for flags in (["--precision", "f32"], ["--decoder", "SPA"], ["--code", "gen:irg:10000"], ["--no-profile"], ["--no-baseline-configs"], ["--batch", "1024"]):
+        assert not bench.is_default_workload(bench.parse_args(flags)), flags
+    got = {}
+    for name, _, flags in bench.BASELINE_CONFIGS:
+        sub = bench.baseline_config_args(d, flags)
+        got[name] = (bench.resolve_workload(sub.decoder, sub.channel, sub.param, sub.snr), sub.code, sub.batch, sub.precision, sub.points, sub.headline_only)
+    assert got["config3_spa_bsc"] == (("SPA", "bsc", 0.07), "1200_3_6_rand_ldpc_1", 65536, "f32", [], True)
+    assert got["config3_bec"][0] == ("BEC", "bec", 0.40) and got["config3_bec"][2] == 65536
+    assert got["config4"][:3] == (("MSA", "biawgn", 1.2), "gen:irg:10000", 131072)
+    assert got["config5"][:3] == (("MSA", "biawgn", 2.0), "gen:reg:64800:3:6", 32768)

@@ -66,3 +66,27 @@ def test_strong_split_on_the_streaming_backend_and_multi_round_launches_with_two
     for key in ("frames_counted", "word_errors", "bit_errors", "mean_sweeps", "wer", "ber"):
         assert one[key] == two[key], key
     assert one["frames_counted"] == 37 * 4097 and one["word_errors"] > 0
+
+
+@pytest.mark.timeout(1800)
+def test_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as a plain process (no WORLD_SIZE -- the way the round driver starts --gpus 1): bench.self_launch starts the two
+    ranks itself (a torch.distributed.run child; the parent makes no GPU call) and relays rank 0's line -- never an `n_gpus: 1` line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LDPC_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096", "--snr", "2.0",
+           "--points", "--no-cpu-baseline", "--no-baseline-configs"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["collective"]["ranks_seen"] == 2 and two["frames_counted"] == 2 * 8192
+    assert two["roofline"]["kernel"].startswith("k_fused_f64<")
+    # without the gloo override a 1-GPU box must refuse --gpus 2 with no line at all (RCCL needs one GPU per rank)
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        env.pop("LDPC_DIST_BACKEND")
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 3 and out.stdout.strip() == "" and "requested" in out.stderr

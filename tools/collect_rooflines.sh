@@ -32,14 +32,14 @@ CASES=(
  "c3_bec|--code 1200_3_6_rand_ldpc_1 --alg BEC --channel bec --param 0.40 --batch 1048576 --precision f32 --launches 3|sq hbm"
  "c3_spa_biawgn_f64|--code 1200_3_6_rand_ldpc_1 --alg SPA --channel biawgn --param 1.5 --batch 65536 --precision f64 --launches 2|sq hbm"
  "c4_f32|--code gen:irg:10000 --alg MSA --channel biawgn --param 1.2 --batch 16384 --precision f32 --launches 2|sq hbm"
- "c4_stream_f32|--code gen:irg:10000 --alg MSA --channel biawgn --param 1.2 --batch 8192 --precision f32 --backend stream --launches 1|hbm"
- "c4_stream_f64|--code gen:irg:10000 --alg MSA --channel biawgn --param 1.2 --batch 8192 --precision f64 --backend stream --launches 1|hbm"
- "c5_stream_f32|--code gen:reg:64800:3:6 --alg MSA --channel biawgn --param 1.0 --batch 32768 --precision f32 --backend stream --launches 1|hbm"
- "c2_stream_f32|--code 1200_3_6_rand_ldpc_1 --alg MSA --channel biawgn --param 1.0 --batch 65536 --precision f32 --backend stream --launches 1|hbm"
- "c2_stream_f64|--code 1200_3_6_rand_ldpc_1 --alg MSA --channel biawgn --param 1.0 --batch 65536 --precision f64 --backend stream --launches 1|hbm"
- "c5_stream_f16|--code gen:reg:64800:3:6 --alg MSA --channel biawgn --param 1.0 --batch 8192 --precision f16 --launches 1|hbm"
- "c5_bec_stream|--code gen:reg:64800:3:6 --alg BEC --channel bec --param 0.40 --batch 32768 --precision f32 --launches 1|hbm"
- "c4_bec_stream|--code gen:irg:10000 --alg BEC --channel bec --param 0.44 --batch 32768 --precision f32 --launches 1|hbm"
+ "c4_stream_f32|--code gen:irg:10000 --alg MSA --channel biawgn --param 1.2 --batch 8192 --precision f32 --backend stream --launches 1 --warm 1|hbm"
+ "c4_stream_f64|--code gen:irg:10000 --alg MSA --channel biawgn --param 1.2 --batch 8192 --precision f64 --backend stream --launches 1 --warm 1|hbm"
+ "c5_stream_f32|--code gen:reg:64800:3:6 --alg MSA --channel biawgn --param 1.0 --batch 32768 --precision f32 --backend stream --launches 1 --warm 1|hbm"
+ "c2_stream_f32|--code 1200_3_6_rand_ldpc_1 --alg MSA --channel biawgn --param 1.0 --batch 65536 --precision f32 --backend stream --launches 1 --warm 1|hbm"
+ "c2_stream_f64|--code 1200_3_6_rand_ldpc_1 --alg MSA --channel biawgn --param 1.0 --batch 65536 --precision f64 --backend stream --launches 1 --warm 1|hbm"
+ "c5_stream_f16|--code gen:reg:64800:3:6 --alg MSA --channel biawgn --param 1.0 --batch 8192 --precision f16 --launches 1 --warm 1|hbm"
+ "c5_bec_stream|--code gen:reg:64800:3:6 --alg BEC --channel bec --param 0.40 --batch 32768 --precision f32 --launches 1 --warm 1|hbm"
+ "c4_bec_stream|--code gen:irg:10000 --alg BEC --channel bec --param 0.44 --batch 32768 --precision f32 --launches 1 --warm 1|hbm"
 )
 for C in "${CASES[@]}"; do
   NAME=${C%%|*}; REST=${C#*|}; ARGS=${REST%%|*}; PASSES=${REST#*|}

@@ -69,6 +69,74 @@ def kernels_of(lib=DEFAULT_LIB):
     return out
 
 
+def short_name(name):
+    """Demangled kernel symbol -> the name rocprofv3 / ldpc_decoder_kernel_name report: namespaces, `void ` and the argument list cut."""
+    name = name.replace("ldpc::(anonymous namespace)::", "").replace("ldpc::", "").replace("void ", "")
+    depth = 0
+    for i, ch in enumerate(name):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
+def _elf_functions(co):
+    """(mangled name, machine-code bytes) of every function symbol of one ELF64 code object, and {name: kernel-descriptor bytes}."""
+    shoff, = struct.unpack_from("<Q", co, 0x28)
+    shentsize, shnum, _ = struct.unpack_from("<HHH", co, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", co, shoff + i * shentsize) for i in range(shnum)]  # name type flags addr off size link info align entsize
+    funcs, kds = [], {}
+    for sec in secs:
+        if sec[1] != 2:  # SHT_SYMTAB
+            continue
+        stroff = secs[sec[6]][4]
+        for j in range(sec[5] // 24):
+            st_name, st_info, _, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", co, sec[4] + j * 24)
+            if st_shndx == 0 or st_shndx >= shnum or st_size == 0:
+                continue
+            end = co.index(b"\0", stroff + st_name)
+            nm = co[stroff + st_name:end].decode(errors="replace")
+            host = secs[st_shndx]
+            body = co[host[4] + st_value - host[3]:host[4] + st_value - host[3] + st_size]
+            if (st_info & 15) == 2:       # STT_FUNC
+                funcs.append((nm, body))
+            elif nm.endswith(".kd"):      # kernel descriptor (register counts, LDS size, ...)
+                kds[nm[:-3]] = body
+    return funcs, kds
+
+
+def kernel_code_hashes(lib=DEFAULT_LIB):
+    """{kernel name as rocprofv3 prints it: first 16 hex digits of sha256(machine code + kernel descriptor)} for every kernel of the built
+    library -- what profiles/roofline_counters.json records beside a kernel's PMC counters, so that bench.py can tell when the kernel it
+    times is no longer the kernel the counters were collected on.  Pure file parsing: no GPU, no HIP call."""
+    import hashlib
+
+    blob = open(lib, "rb").read()
+    raw = {}
+    for _, co in code_objects(blob):
+        if co[:4] != b"\x7fELF":
+            continue
+        funcs, kds = _elf_functions(co)
+        for nm, body in funcs:
+            if nm in kds:
+                raw[nm] = hashlib.sha256(body + kds[nm]).hexdigest()[:16]
+    names = list(raw)
+    if not names:
+        return {}
+    try:
+        dem = subprocess.run([CXXFILT], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    except OSError:
+        dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    return {short_name(d): raw[m] for d, m in zip(dem, names)}
+
+
+def lib_sha256(lib=DEFAULT_LIB):
+    import hashlib
+
+    return hashlib.sha256(open(lib, "rb").read()).hexdigest()
+
+
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
@@ -119,7 +187,13 @@ if __name__ == "__main__":
     ap.add_argument("--lib", default=DEFAULT_LIB)
     ap.add_argument("--match", default="")
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--hashes", action="store_true", help="print the per-kernel code hashes (kernel_code_hashes) instead of the resources")
     a = ap.parse_args()
+    if a.hashes:
+        for k, v in sorted(kernel_code_hashes(a.lib).items()):
+            if a.match in k:
+                print(v, k)
+        raise SystemExit(0)
     ks = {k: v for k, v in kernels_of(a.lib).items() if a.match in k}
     if a.json:
         print(json.dumps(ks, indent=1))

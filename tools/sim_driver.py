@@ -30,6 +30,7 @@ ap.add_argument("--precision", default="f32")
 ap.add_argument("--backend", default="auto")
 ap.add_argument("--max-iter", type=int, default=50)
 ap.add_argument("--launches", type=int, default=3)
+ap.add_argument("--warm", type=int, default=6, help="launches BEFORE the counted ones (clocks up, workspaces allocated); the summary uses the last --launches dispatches only")
 ap.add_argument("--info", default=None)
 ap.add_argument("--prior-grid", type=int, default=None, help="exact-in-fp32 mode: priors on the 2^-K grid (LDPC_FLAG_PRIOR_GRID): the guarded fp32 kernel")
 ap.add_argument("--calib", action="store_true", help="also run the known 1 GiB -> 1 GiB copy (calibration of FETCH_SIZE / WRITE_SIZE)")
@@ -40,8 +41,10 @@ h = DecoderHandle(code, a.alg, a.precision, a.backend)
 bins = a.max_iter + 1
 flags = _lib.flag_prior_grid(a.prior_grid) if a.prior_grid is not None else 0
 cnt = torch.zeros(4 + bins, dtype=torch.int64, device="cuda")
-h.simulate(a.channel, a.param, 0, 0x5EED1200, 0, 0, a.batch, a.max_iter, cnt, flags=flags, hist_bins=bins)  # first launch: workspaces are allocated here
+for w in range(max(1, a.warm)):  # warm-up: workspaces are allocated by the first launch, the clocks come up over the next ones
+    h.simulate(a.channel, a.param, 0, 0x5EED1200, 0, w * a.batch, a.batch, a.max_iter, cnt, flags=flags, hist_bins=bins)
 torch.cuda.synchronize()
+cnt.zero_()  # frames / frame-sweeps below are those of the COUNTED launches (tools/summarize_rooflines.py takes the last `launches` dispatches)
 t0 = time.perf_counter()
 for s in range(a.launches):
     h.simulate(a.channel, a.param, 0, 0x5EED1200, 1, s * a.batch, a.batch, a.max_iter, cnt, flags=flags, hist_bins=bins)
@@ -58,7 +61,7 @@ kname = (h.kernel_name(True) if hasattr(_lib.load(), "ldpc_decoder_kernel_name")
 if a.prior_grid is not None:  # the guarded sibling of that kernel (min-sum only: one template argument less)
     kname = kname.replace("k_fused_bp<0, ", "k_fused_bp_grid<")
 info = dict(code=a.code, n=code.n, m=code.m, E=code.E, alg=a.alg, channel=a.channel, param=a.param, batch=a.batch, precision=a.precision,
-            max_iter=a.max_iter, backend=backend, kernel=kname, launches=a.launches + 1,
+            max_iter=a.max_iter, backend=backend, kernel=kname, launches=a.launches, warm_launches=max(1, a.warm),
             frames=int(c[0]), frame_sweeps=int(c[3]), mean_sweeps=float(c[3]) / max(int(c[0]), 1), wer=float(c[1]) / max(int(c[0]), 1),
             ms_per_launch_wall=dt * 1e3, frames_per_s_wall=a.batch / dt, cus=torch.cuda.get_device_properties(0).multi_processor_count,
             repacks_last=h.last_repacks(), device=torch.cuda.get_device_name(0))

@@ -35,19 +35,31 @@ def short(name):
 
 
 def pmc(d):
+    """{kernel: {counter: [value per dispatch, in dispatch order]}}"""
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return acc
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append((int(r.get("Dispatch_Id") or 0), float(r["Counter_Value"])))
+    return {k: {c: [v for _, v in sorted(rows)] for c, rows in cs.items()} for k, cs in acc.items()}
 
 
 def durations(d):
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "*kernel_trace.csv")):
         for r in csv.DictReader(open(f)):
-            acc[short(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
-    return acc
+            acc[short(r["Kernel_Name"])].append((float(r["Start_Timestamp"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"])))
+    return {k: [v for _, v in sorted(rows)] for k, rows in acc.items()}
+
+
+def counted(info, series):
+    """The dispatches the driver's frame-sweep count covers: the LAST info['launches'] of the kernel (tools/sim_driver.py runs its warm-up
+    launches first and zeroes its counters behind them)."""
+    n = int((info or {}).get("launches") or 0)
+    if not n or not (info or {}).get("warm_launches"):
+        return series
+    if isinstance(series, dict):
+        return {c: v[-n:] for c, v in series.items()}
+    return series[-n:]
 
 
 def info_of(case, which):
@@ -75,9 +87,9 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
     i1 = info_of(case, "sq1")
     if i1 and i1.get("kernel"):
         k = i1["kernel"]
-        c1, d1 = pmc(os.path.join(case_dir, "sq1")).get(k, {}), durations(os.path.join(case_dir, "sq1")).get(k, [])
-        c2, d2 = pmc(os.path.join(case_dir, "sq2")).get(k, {}), durations(os.path.join(case_dir, "sq2")).get(k, [])
         i2 = info_of(case, "sq2") or i1
+        c1, d1 = counted(i1, pmc(os.path.join(case_dir, "sq1")).get(k, {})), counted(i1, durations(os.path.join(case_dir, "sq1")).get(k, []))
+        c2, d2 = counted(i2, pmc(os.path.join(case_dir, "sq2")).get(k, {})), counted(i2, durations(os.path.join(case_dir, "sq2")).get(k, []))
         if c1 and d1:
             fs, cus = float(i1["frame_sweeps"]), i1["cus"]
             tot = {c: sum(v) for c, v in c1.items()}
@@ -110,8 +122,8 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
             # busy-cycle measure; the fraction below is an ISSUE MODEL on measured instruction counts: 2 cycles per wave64 instruction
             # (v_fma_f32: 2 cycles on a SIMD-32, MI355X_MICROARCH.md), 4 for fp64 add / mul / fma (half rate: 78.6 vs 157.3 TFLOP/s), 8 for
             # transcendentals (quarter rate) -- instruction-mix counters from the sq3 pass where this rocprofv3 has them
-            c3 = pmc(os.path.join(case_dir, "sq3")).get(k, {})
             i3 = info_of(case, "sq3") or i1
+            c3 = counted(i3, pmc(os.path.join(case_dir, "sq3")).get(k, {}))
             mix = {}
             if c3:
                 fs3 = float(i3["frame_sweeps"])
@@ -128,8 +140,8 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
             # registers to the LDS (MI355X_MICROARCH.md, LDS table: ds_write_b64 ~6 cycles of that transfer against 4 array cycles, ds_write_b32 4
             # against 2, ds_write_addtid_b32 2 against 2, reads 2), a path the array counter does not see.  Model: measured load / store
             # instruction counts (SQ_INSTS_LDS_LOAD / _STORE, sq4 pass) x the table's per-instruction cycles for the widths THIS kernel uses.
-            c4 = pmc(os.path.join(case_dir, "sq4")).get(k, {})
             i4 = info_of(case, "sq4") or i1
+            c4 = counted(i4, pmc(os.path.join(case_dir, "sq4")).get(k, {}))
             if c4:
                 fs4 = float(i4["frame_sweeps"])
                 t4 = {c: sum(v) / fs4 for c, v in c4.items()}
@@ -228,6 +240,26 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
         md.append("\n(check / variable pass: compulsory bytes = batch x s x (2E + n) / batch x s x (E + 2n) -- c2v in + out + each marginal once; "
                   "c2v in + prior in + marginal out -- valid where no frame leaves early; the section-8(d) model prices the pair at s(4E + n).)")
 
+# Stamp every entry with the identity of the code it was measured on: sha256 of the library, and -- per kernel -- a hash of that kernel's
+# machine code + descriptor (tools/kernel_resources.py kernel_code_hashes).  bench.py compares the latter with the library it has loaded
+# and prints `counters_stale: true` (frac null) when the kernel body changed under an unchanged name.  This script runs ON THE BOX right
+# behind the collection (tools/round_measure.sh), i.e. on the very library the counters were collected with.
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources  # noqa: E402
+
+lib = os.environ.get("LDPC_LIB_PATH") or kernel_resources.DEFAULT_LIB
+hashes, lib_sha = kernel_resources.kernel_code_hashes(lib), kernel_resources.lib_sha256(lib)
+try:
+    import subprocess
+
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except OSError:
+    head = None
+head = head or os.environ.get("LDPC_HEAD")  # .git does not travel to the GPU box: tools/round_measure.sh passes the HEAD it was started from
+for key, ent in entries.items():
+    ent["kernel_code_sha"] = hashes.get(ent["kernel"])
+    ent["lib_sha256"] = lib_sha
+    ent["head"] = head
 os.makedirs(dst, exist_ok=True)
 json.dump(entries, open(os.path.join(dst, "%s_roofline_counters.json" % tag), "w"), indent=1)
 json.dump(entries, open(os.path.join(dst, "roofline_counters.json"), "w"), indent=1)
