@@ -78,6 +78,9 @@ int ldpc_decoder_last_stats(ldpc_decoder_t dec, int* backend, int* sweeps);
 /* streaming backend: how often the last decode gathered its live frames into dense tiles (per-frame early termination,
  * src/bpa.py:28-29: a frame that has left costs nothing; tiles of 64 frames are re-formed from the live ones) */
 int ldpc_decoder_last_repacks(ldpc_decoder_t dec, int* repacks);
+/* streaming backend: frames per pass through the kernels (sized once from the free HBM: the reference decodes one frame per call,
+ * src/main.py:37-48, so any batch size is the build's own) and how often a failed workspace reservation made ldpc_decode halve it */
+int ldpc_decoder_chunk_state(ldpc_decoder_t dec, int64_t* chunk_frames, int* retries);
 /* exact-in-fp32 mode: frames in which a message left the range where fp32 sums of grid multiples are exact (a frame caught in a
  * trapping set: its min-sum messages grow geometrically; about 1 in 10^4 at 2 dB), since the last reset.  Such a frame is NOT counted
  * by ldpc_simulate, and ldpc_decode marks it with iters = -1 - sweeps; its global frame index (frame0 + position) is listed in

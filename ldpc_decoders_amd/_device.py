@@ -387,6 +387,12 @@ class DecoderHandle:
         _lib.check(_lib.load().ldpc_decoder_last_repacks(self.h, ctypes.byref(r)))
         return r.value
 
+    def chunk_state(self):
+        """Streaming backend: (frames per pass, how often a failed reservation halved it)."""
+        c, r = ctypes.c_int64(0), ctypes.c_int(0)
+        _lib.check(_lib.load().ldpc_decoder_chunk_state(self.h, ctypes.byref(c), ctypes.byref(r)))
+        return c.value, r.value
+
 
 class MlHandle:
     """Codebook of a short code resident in HBM + the exhaustive-search kernels (``ldpc_ml_*``)."""

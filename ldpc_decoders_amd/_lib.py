@@ -46,6 +46,7 @@ SIGNATURES = {
     "ldpc_decoder_destroy": (_c.c_int, [_P]),
     "ldpc_decoder_last_stats": (_c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
     "ldpc_decoder_last_repacks": (_c.c_int, [_P, _c.POINTER(_c.c_int)]),
+    "ldpc_decoder_chunk_state": (_c.c_int, [_P, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int)]),
     "ldpc_decoder_grid_violations": (_c.c_int, [_P, _c.POINTER(_c.c_int64), _P, _c.c_int64, _c.c_int]),
     "ldpc_decoder_grid_list": (_c.c_int, [_P, _c.POINTER(_P), _c.POINTER(_c.c_int64), _P]),
     "ldpc_decoder_grid_list_reset": (_c.c_int, [_P, _P]),

@@ -32,10 +32,25 @@ int DevBuf::reserve(size_t need) {
         bytes = 0;
     }
     const size_t slack = need / 8 < ((size_t)64 << 20) ? need / 8 : ((size_t)64 << 20);  // growth headroom, bounded: workspaces reach 100 GB
-    const size_t want = need + slack + 256;
+    size_t want = need + slack + 256;
+    // fault injection for tests/test_gpu_packed_bits.py (the chunk-halving retry of decode_dev cannot be reached on a 288 GB card without
+    // tens of GB of input): LDPC_TEST_FAIL_RESERVE=K makes the K-th growing reservation from then on ask for 2^50 bytes -- a genuine
+    // hipMalloc failure, sticky error included
+    // (read at every growth, counted from the moment the value changes, so that a test arms it in-process right before the call under test)
+    static std::string armed;
+    static int grown = 0;
+    const char* env = getenv("LDPC_TEST_FAIL_RESERVE");
+    if (armed != (env ? env : "")) {
+        armed = env ? env : "";
+        grown = 0;
+    }
+    if (env && atoi(env) > 0 && ++grown == atoi(env)) want = (size_t)1 << 50;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
         p = nullptr;
+        // since ROCm 7 hipGetLastError() returns the last REAL error, not the last call's status: consume this one, or the
+        // LDPC_HIP_TRY(hipGetLastError()) behind the next successful launch (the retry with a smaller chunk) would report it again
+        (void)hipGetLastError();
         set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
         return LDPC_E_NOMEM;
     }
@@ -100,6 +115,22 @@ int64_t stream_chunk_frames(Decoder* d) {
     d->stream_chunk = step;
     return step;
 }
+
+// Frees the streaming state (both sets): the chunk-halving retry of decode_dev must give back what the failed, larger reservation had
+// already taken -- buffers reserved before the one that failed keep their full size otherwise and the smaller chunk frees nothing.
+static void release_stream_workspaces(Decoder* d) {
+    for (DevBuf* b : {&d->msg, &d->marg, &d->prior, &d->xbits, &d->xera, &d->live, &d->msg2, &d->marg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap,
+                      &d->fmap2})
+        b->release();
+}
+
+// d->out_bits is per-call state of the streaming kernels (packed decisions straight from the planes): reset on EVERY exit path, an
+// exception caught by guarded() included -- a stale pointer would send the next plain ldpc_decode's decisions to freed caller memory.
+struct OutBitsScope {
+    Decoder* d;
+    OutBitsScope(Decoder* dec, uint32_t* bits) : d(dec) { d->out_bits = bits; }
+    ~OutBitsScope() { d->out_bits = nullptr; }
+};
 
 // LDPC_FLAG_PRIOR_GRID arms the exactness guard of the LDS-resident fp32 min-sum kernels.  The streaming kernels have no such guard:
 // a call that asks for it there is refused (as ldpc_simulate refuses it) instead of returning frames nobody vouched for.  fp64 decoders
@@ -329,6 +360,16 @@ int ldpc_decoder_destroy(ldpc_decoder_t h) {
     });
 }
 
+int ldpc_decoder_chunk_state(ldpc_decoder_t h, int64_t* chunk_frames, int* retries) {
+    return guarded("ldpc_decoder_chunk_state", [&]() -> int {
+        Decoder* d = (Decoder*)h;
+        if (!d || !chunk_frames || !retries) return LDPC_E_ARG;
+        *chunk_frames = d->stream_chunk;
+        *retries = d->chunk_retries;
+        return LDPC_OK;
+    });
+}
+
 int ldpc_decoder_last_repacks(ldpc_decoder_t h, int* repacks) {
     return guarded("ldpc_decoder_last_repacks", [&]() -> int {
         Decoder* d = (Decoder*)h;
@@ -478,15 +519,21 @@ static int decode_dev(Decoder* d, const char* who, const void* priors, const uin
         const void* p = priors ? (const char*)priors + (size_t)b0 * n * esz : nullptr;
         const uint8_t* y = y0 ? y0 + (size_t)b0 * n : nullptr;
         uint8_t* xh = bits ? (planes_direct ? nullptr : (uint8_t*)d->h_out.p) : xhat + (size_t)b0 * n;
-        d->out_bits = planes_direct ? bits + (size_t)b0 * W : nullptr;
-        int rc = bk == BK_FUSED ? fused_decode(d, p, y, nb, max_iter, flags, xh, iters + b0, nullptr, st)
+        int rc;
+        {
+            OutBitsScope scope(d, planes_direct ? bits + (size_t)b0 * W : nullptr);
+            rc = bk == BK_FUSED ? fused_decode(d, p, y, nb, max_iter, flags, xh, iters + b0, nullptr, st)
                                 : stream_decode(d, p, y, nb, max_iter, flags, xh, iters + b0, nullptr, st);
-        d->out_bits = nullptr;
+        }
         if (rc == LDPC_E_NOMEM && bk == BK_STREAM && nb > 64) {
             // the chunk was sized from the memory that was free when this decoder first asked (stream_chunk_frames); other allocations
-            // since (a twin decoder, torch tensors) may have taken it: halve the chunk -- for this decoder's lifetime -- and try again
+            // since (a twin decoder, torch tensors) may have taken it: halve the chunk -- for this decoder's lifetime -- give back what
+            // the failed attempt had reserved, and try again
             step = ((nb / 2 + 63) / 64) * 64;
             d->stream_chunk = step;
+            LDPC_HIP_TRY(hipStreamSynchronize(st));
+            release_stream_workspaces(d);
+            ++d->chunk_retries;
             continue;
         }
         if (rc) return rc;
@@ -809,10 +856,12 @@ static int simulate_impl(ldpc_decoder_t h, int channel, double param, int codewo
         for (int64_t b0 = 0; b0 < B; b0 += step) {
             const int64_t nb = (B - b0) < step ? (B - b0) : step;
             if (tiled_noise) {
-                d->out_bits = (uint32_t*)d->h_bits.p;
-                const int rc = stream_simulate_biawgn(d, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, max_iter, flags, nullptr,
-                                                      (int32_t*)d->h_iters.p, st);
-                d->out_bits = nullptr;
+                int rc;
+                {
+                    OutBitsScope scope(d, (uint32_t*)d->h_bits.p);
+                    rc = stream_simulate_biawgn(d, param, codeword, seed, stream_id, frame0 + (uint64_t)b0, nb, max_iter, flags, nullptr,
+                                                (int32_t*)d->h_iters.p, st);
+                }
                 if (rc) return rc;
                 LDPC_TRY(count_errors_bits((const uint32_t*)d->h_bits.p, nullptr, nullptr, codeword, (int32_t*)d->h_iters.p, nb, (int32_t)n, hist_bins, counters, st));
                 continue;

@@ -508,6 +508,10 @@ __global__ __launch_bounds__(64 * NW, NW >= 4 ? (NW == 4 ? 4 : 2) : 2) void k_fu
     // Packed (this kernel sits at its register limits): c_isum -- lanes 0..31 the sweep sums of slot 0's positions, lanes 32..63 those of slot 1
     // (`age` is kept in both halves); c_bec -- bit errors of this wave's variables per lane, slot 0 in the low, slot 1 in the high 16 bits;
     // c_tot / c_wec -- frames / word errors, one 16-bit field per slot, wave-uniform (flush_every <= 4096 frames keeps every field in range).
+    // A lane's c_bec field of one slot grows by at most VRW per frame and is flushed once the slot has counted flush_every (<= BECS_FLUSH_MAX)
+    // frames, checked after up to 32 more have left in the same sweep: (BECS_FLUSH_MAX + 32) * VRW must stay below 2^16 or the sum would
+    // carry into the other slot's field silently.
+    static_assert((BECS_FLUSH_MAX + 32) * VRW < 65536, "packed 16-bit bit-error counters: lower BECS_FLUSH_MAX for this VRW");
     uint32_t c_isum = 0, c_bec = 0;
     uint32_t c_tot = 0, c_wec = 0;
     uint32_t all[3] = {0u, 0u, 0u};  // last exchange: changed, erased, wrong

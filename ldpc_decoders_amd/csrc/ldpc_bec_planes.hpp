@@ -10,6 +10,7 @@ namespace ldpc {
 namespace {
 
 constexpr int BEC_SLAB = 32;  // frames per slab == bits of a plane word
+constexpr int BECS_FLUSH_MAX = 4096;  // Monte-Carlo kernel: frames a counter slot may accumulate before its packed 16-bit sums are flushed
 
 struct P2 {
     uint32_t k, v;

@@ -113,6 +113,7 @@ struct Decoder {
     // ldpc_decode_bits: for the duration of that call the streaming kernels write their decisions here as packed words [B, ceil(n/32)]
     // instead of bytes (null otherwise)
     uint32_t* out_bits = nullptr;
+    int chunk_retries = 0;  // how often decode_dev halved the streaming chunk after a failed reservation (ldpc_decoder_chunk_state)
     DevBuf h_bits, h_era;  // packed staging of ldpc_decode_host (decisions, erased mask)
     int64_t stream_chunk = 0;  // frames per pass through the streaming kernels (0: not decided yet; ldpc_api.hip stream_chunk_frames)
 };

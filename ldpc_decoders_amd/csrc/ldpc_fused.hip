@@ -14,6 +14,7 @@
 #include <string>
 #include <numeric>
 
+#include "ldpc_bec_planes.hpp"
 #include "ldpc_fused_kernels.hpp"
 #include "ldpc_layout.hpp"
 
@@ -335,7 +336,7 @@ static int becs_build_plan(Decoder* d, FusedPlan* p, const ShapeEntry& shape, co
     const uint32_t sum_base = (uint32_t)NW * VNK * 64, sys_base = sum_base + (uint32_t)CR * 64;
     const uint32_t zero_e = sys_base, known0_e = sys_base + 1;
     p->lds_bytes = (size_t)(sys_base + 128) * 8;  // system row + the row of the second accumulator slot's histogram (Monte-Carlo kernel)
-    if (p->lds_bytes > (size_t)160 * 1024 || sys_base + 64 > 65536u || CR > CRW * NW) return LDPC_OK;  // plan stays !ok
+    if (p->lds_bytes > (size_t)160 * 1024 || sys_base + 128 > 65536u || CR > CRW * NW) return LDPC_OK;  // plan stays !ok
     std::vector<uint32_t> cn_tab((size_t)NW * CNW * 64, 0), vn_tab((size_t)NW * VNW * 64, 0);
     std::vector<int32_t> var_of_slot((size_t)NPAD, -1);
     for (int v = 0; v < c->n; ++v) var_of_slot[L.var_slot[v]] = v;
@@ -656,7 +657,7 @@ static int fused_launch(Decoder* d, FusedArgs& a, bool sim, int64_t B, int32_t m
     {  // 32-bit partial counters of a workgroup (sim_count): bit errors <= n and sweeps <= max_iter per frame
         const long long per_frame = a.n > a.max_iter ? a.n : a.max_iter;
         long long fe = ((long long)1 << 31) / (per_frame > 0 ? per_frame : 1);
-        a.flush_every = (int)(fe < 1 ? 1 : (fe > 4096 ? 4096 : fe));
+        a.flush_every = (int)(fe < 1 ? 1 : (fe > BECS_FLUSH_MAX ? BECS_FLUSH_MAX : fe));  // ceiling shared with the kernel's packed 16-bit counters
     }
     // exact-in-fp32 mode: the guarded variant of the kernel, its grid constants and the violation counter
     const int grid_k = LDPC_FLAG_PRIOR_GRID_OF(flags);

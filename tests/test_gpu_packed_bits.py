@@ -153,3 +153,33 @@ def test_random_codeword_simulation_in_the_fp16_storage_mode():
     DecoderHandle(code, "MSA", "f32", "stream").simulate("biawgn", 3.0, -1, 5, 0, 0, 4096, 10, cnt32)
     assert int(cnt16[0]) == 4096 and int(cnt32[0]) == 4096
     assert abs(int(cnt16[1]) - int(cnt32[1])) <= 40  # same frames, same noise: fp16 storage moves only a few borderline frames
+
+
+def test_chunk_halving_retry_after_a_failed_reservation(monkeypatch):
+    """ldpc_decode on the streaming kernels: a workspace reservation that fails (other allocations took the memory the chunk was sized
+    from) halves the chunk, gives back what the failed attempt had reserved, and decodes the SAME result.  The failure is injected
+    (LDPC_TEST_FAIL_RESERVE: the K-th growing reservation asks for 2^50 bytes -- a genuine hipMalloc error, sticky status included,
+    which ROCm 7 would hand to the next hipGetLastError())."""
+    import torch
+
+    from ldpc_decoders_amd import codes
+    from ldpc_decoders_amd._device import DecoderHandle
+
+    code = codes.get_code("1200_3_6_rand_ldpc_1")
+    rng = np.random.RandomState(5)
+    B = 1024
+    pri = torch.from_numpy((2.0 + 1.3 * rng.standard_normal((B, code.n))).astype(np.float32)).cuda()
+    ref = DecoderHandle(code, "MSA", "f32", "stream")
+    x0, it0 = ref.decode_device(pri, None, 30)
+    assert ref.chunk_state()[1] == 0
+    for k in (1, 2, 4):   # the failure lands on different workspaces of the first pass
+        dec = DecoderHandle(code, "MSA", "f32", "stream")
+        monkeypatch.setenv("LDPC_TEST_FAIL_RESERVE", str(k))
+        x1, it1 = dec.decode_device(pri, None, 30)
+        monkeypatch.delenv("LDPC_TEST_FAIL_RESERVE")
+        torch.cuda.synchronize()
+        chunk, retries = dec.chunk_state()
+        assert retries == 1 and chunk == B // 2, (k, chunk, retries)
+        assert torch.equal(x0, x1) and torch.equal(it0, it1), k
+        x2, it2 = dec.decode_device(pri, None, 30)   # the decoder stays usable at the smaller chunk
+        assert torch.equal(x0, x2) and dec.chunk_state() == (B // 2, 1)
