@@ -120,7 +120,7 @@ int64_t stream_chunk_frames(Decoder* d) {
 // already taken -- buffers reserved before the one that failed keep their full size otherwise and the smaller chunk frees nothing.
 static void release_stream_workspaces(Decoder* d) {
     for (DevBuf* b : {&d->msg, &d->marg, &d->prior, &d->xbits, &d->xera, &d->live, &d->msg2, &d->marg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap,
-                      &d->fmap2})
+                      &d->fmap2, &d->rmap})
         b->release();
 }
 
@@ -347,7 +347,7 @@ int ldpc_decoder_destroy(ldpc_decoder_t h) {
         if (!d) return LDPC_OK;
         (void)hipSetDevice(d->code->device);
         fused_plan_destroy(d);
-        for (DevBuf* b : {&d->msg, &d->marg, &d->marg2, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->gridviol, &d->msg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap, &d->fmap2, &d->rbase, &d->h_in, &d->h_y0, &d->h_out,
+        for (DevBuf* b : {&d->msg, &d->marg, &d->marg2, &d->prior, &d->xbits, &d->xera, &d->live, &d->flags, &d->scratch, &d->gridviol, &d->msg2, &d->prior2, &d->xbits2, &d->live2, &d->fmap, &d->fmap2, &d->rbase, &d->rmap, &d->h_in, &d->h_y0, &d->h_out,
                           &d->h_iters, &d->h_bits, &d->h_era})
             b->release();
         if (d->pinned) (void)hipHostFree(d->pinned);

@@ -85,7 +85,7 @@ struct Decoder {
     int alg = ALG_MSA, dtype = DT_F32, backend = BK_AUTO;
     // streaming workspace
     DevBuf msg, marg, prior, xbits, xera, live, flags, scratch;  // msg = check -> variable messages
-    DevBuf msg2, marg2, prior2, xbits2, live2, fmap, fmap2, rbase;  // second state set + frame maps of the early-termination repack
+    DevBuf msg2, marg2, prior2, xbits2, live2, fmap, fmap2, rbase, rmap;  // second state set + frame maps of the early-termination repack
     // fused backend
     FusedPlan* fused = nullptr;
     // staging used by the *_host entry points

@@ -486,7 +486,11 @@ int fused_plan_create(Decoder* d) {
             for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = zero_addr(lane);
         for (int pidx = c->col_ptr[v]; pidx < c->col_ptr[v + 1]; ++pidx) {
             const int k = c->col_edge[pidx], cs = chk_slot[c->edge_chk[k]];
-            vn_addr[(size_t)(vr.first_gather(Q) + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(((cs / 64) * DC + edge_pos[k]) * 64 + cs % 64) * esz;
+            // row of the message of (check row Rg = cs / 64, edge position j): Rg * DC + j; the 16-wave shape interleaves the waves' rows
+            // (local row k of wave w at k * NW + w, see fused_bp_body) so that its c2v stores reach most rows without an address register
+            const int Rg = cs / 64, jj = edge_pos[k];
+            const int row = BIG ? ((Rg % CRW) * DC + jj) * NW + Rg / CRW : Rg * DC + jj;
+            vn_addr[(size_t)(vr.first_gather(Q) + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(row * 64 + cs % 64) * esz;
         }
     }
     if (certain_slot >= 0) {  // the certain slot sums nothing: every gather reads the zero row

@@ -95,6 +95,9 @@ __device__ __forceinline__ void lds_st_tid(float v) {
 // instantiation.  What makes this sound is that the compiler has no M0 use of its own in these kernels, which
 // tests/test_host_cpu.py::test_compiler_never_touches_m0_in_the_fused_kernels checks on the disassembly of the built library.)
 __device__ __forceinline__ void lds_set_m0(uint32_t base) { asm volatile("s_mov_b32 m0, %0" ::"s"(base) : "memory"); }
+// the same in the middle of a run of add-TID stores (the 16-wave shape switches its base once per check phase): an SALU write of M0 needs
+// one wait state before an LDS add-TID instruction reads it, and inline asm is invisible to the compiler's hazard recogniser
+__device__ __forceinline__ void lds_switch_m0(uint32_t base) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(base) : "memory"); }
 
 // The few words the waves of a frame hand each other (syndrome verdicts, frame numbers, error counts) are accessed as LDS words:
 // through a generic `volatile uint32_t*` the compiler emits flat_store / flat_load ... sc0 sc1 -- the aperture check of the vector
@@ -147,6 +150,12 @@ __device__ __forceinline__ void lds_st2_rows(uint32_t vaddr, float a, float b) {
 #else
     asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(vaddr), "v"(a), "v"(b), "n"(R0), "n"(R1) : "memory");
 #endif
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_st_row(uint32_t vaddr, float a) {
+    static_assert(OFF >= 0 && OFF < 65536, "16-bit DS offset");
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vaddr), "v"(a), "n"(OFF) : "memory");
 }
 
 // one row of 8-byte elements, lane-contiguous: ds_write_b64 with an immediate row offset.  Written as inline asm so that the
@@ -331,12 +340,27 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
         if (threadIdx.x == 0) *sysw(33) = 0u;  // published by the barrier at the top of the frame loop
     }
 
+    // BIG: the c2v rows of the 16 waves are INTERLEAVED -- local row k = r*DC + j of wave w is row k*NW + w of the c2v area -- so that the
+    // wave-dependent part of a row address is small (w * 256 B) and the large part (k * NW * 256 B) is a compile-time immediate:
+    // ds_write_addtid_b32 reaches M0[15:0] + a 16-bit immediate, i.e. the first 128 KB of the 160 KB frame, with TWO bases per wave
+    // (rows k < BIG_KA from M0_a = c2v area + w*256, rows BIG_KA <= k < BIG_KB from M0_b = 65 535 - (NW-1-w)*256).  Only the rows beyond
+    // (k >= BIG_KB: 8 of a wave's 30, four paired stores) keep an address register.  Why it matters: every store that carries an address VGPR is charged
+    // ~3.2 LDS-array cycles by the hardware whatever its addresses (profiles/r04_big_store_pairing.txt: 240 paired stores = 787 of the
+    // 4 562 array cycles per frame-sweep), an add-TID store none, and 2.2 instead of 3 store-path cycles per row.
+    constexpr int BIG_C2V = NPAD * 4;                                                      // byte offset of the c2v area
+    constexpr int BIG_ROWB = NW * 256;                                                     // bytes between two local rows of a wave
+    constexpr int BIG_KA = BIG ? (65535 / BIG_ROWB + 1 < CRW * DC ? 65535 / BIG_ROWB + 1 : CRW * DC) : 0;
+    constexpr int BIG_MB = 65535 - (NW - 1) * 256;                                         // M0_b without its w * 256: the last wave's is 65 535 (the sum M0 + immediate + 4 * lane is what must be aligned)
+    constexpr int BIG_KB = BIG ? ((65535 + BIG_MB - BIG_C2V) / BIG_ROWB + 1 < CRW * DC ? (65535 + BIG_MB - BIG_C2V) / BIG_ROWB + 1 : CRW * DC) : 0;
+    static_assert(!BIG || (BIG_C2V + (NW - 1) * 256 < 65536 && BIG_C2V + BIG_KA * BIG_ROWB >= BIG_MB), "add-TID bases of the 16-wave shape");
+    static_assert(!BIG || ((CRW * DC - BIG_KB) * NW < 256), "8-bit row offsets of the paired address-register stores");
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
-    const uint32_t m0_c2v = lds_base + (uint32_t)(NPAD + w * CRW * DC * 64) * 4;  // this wave's c2v rows
+    const uint32_t m0_c2v = BIG ? lds_base + (uint32_t)(BIG_C2V + w * 256) : lds_base + (uint32_t)(NPAD + w * CRW * DC * 64) * 4;  // this wave's c2v rows
+    const uint32_t m0_c2v_b = lds_base + (uint32_t)(BIG_MB + w * 256);               // BIG: second add-TID base
     const uint32_t m0_marg = lds_base + (uint32_t)(w * VRW * 64) * 4;            // this wave's marginal rows
     const uint32_t my_sync = (uint32_t)A.sync_off[SYS ? 0 : w];
     const uint32_t my_msync = (uint32_t)A.msync_off[SYS ? 0 : w];
-    const uint32_t c2v_vaddr = m0_c2v + (uint32_t)lane * 4u;  // BIG: address register of the c2v stores
+    const uint32_t c2v_vaddr = m0_c2v + (uint32_t)(BIG_KB * BIG_ROWB) + (uint32_t)lane * 4u;  // BIG: address register of the c2v rows beyond add-TID reach (k >= BIG_KB)
     const bool early = !(A.flags & FLAG_NO_EARLY_EXIT);
     // SIM: per-workgroup counters live in wave 0 (scalars + one histogram bin per lane), flushed once at the end
     unsigned valid = 0;  // bit q: slot (q, lane) holds a real variable
@@ -672,14 +696,27 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                         float c;  // mag | ((vx ^ v[j]) & sign bit)
                         asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(c) : "v"(vx ^ __float_as_uint(v[j])), "s"(sign_mask), "v"(mag));
                         c2v_old[r][j] = c;
-                        if constexpr (!BIG) lds_st_tid<(r * DC + j) * 256>(c);
+                        constexpr int k = r * DC + j;
+                        if constexpr (!BIG) {
+                            lds_st_tid<k * 256>(c);
+                        } else if constexpr (k < BIG_KA) {
+                            lds_st_tid<(k < BIG_KA ? k : 0) * BIG_ROWB>(c);
+                        } else if constexpr (k < BIG_KB) {
+                            if constexpr (k == BIG_KA) lds_switch_m0(m0_c2v_b);
+                            lds_st_tid<(k >= BIG_KA && k < BIG_KB ? BIG_C2V + k * BIG_ROWB - BIG_MB : 0)>(c);
+                        }
                     });
                     if constexpr (BIG) {
-                        static_assert(!BIG || DC % 2 == 0, "paired row stores");
-                        static_for<0, DC / 2>([&](auto P_) {
-                            constexpr int pj = 2 * decltype(P_)::value;
-                            lds_st2_rows<r * DC + pj, r * DC + pj + 1>(c2v_vaddr, c2v_old[r][pj], c2v_old[r][pj + 1]);
-                        });
+                        // rows of this check row beyond add-TID reach: address register, two rows per instruction where two are left
+                        constexpr int k0 = r * DC < BIG_KB ? BIG_KB : r * DC, k1 = (r + 1) * DC;  // [k0, k1)
+                        if constexpr (k0 < k1) {
+                            constexpr int np = (k1 - k0) / 2;
+                            static_for<0, np>([&](auto P_) {
+                                constexpr int ka = k0 + 2 * decltype(P_)::value;
+                                lds_st2_rows<(ka - BIG_KB) * NW, (ka + 1 - BIG_KB) * NW>(c2v_vaddr, c2v_old[r][ka - r * DC], c2v_old[r][ka + 1 - r * DC]);
+                            });
+                            if constexpr ((k1 - k0) % 2 == 1) lds_st_row<(k1 - 1 - BIG_KB) * BIG_ROWB>(c2v_vaddr, c2v_old[r][DC - 1]);
+                        }
                     }
                 });
                 const bool unsat = any_unsat(__ballot((synd & 0x80000000u) != 0u) != 0);  // NW > 1: contains the barrier

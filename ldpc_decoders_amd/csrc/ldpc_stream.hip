@@ -186,11 +186,16 @@ __device__ __forceinline__ T v2c_of(T marg, T c_old) {
     return marg - c_old;  // src/bpa.py:37
 }
 
-template <typename T, int ALG, int DCMAX, int FIXED_DC, int UNR>
+// GATHER (the frame repack folded into the sweep that follows it, see run()): `tile` is a tile of the DENSE destination tiling; lane j
+// reads its old messages and marginals from the (source tile, source lane) of the j-th live frame (srcmap) -- `c2v_in` / `src` are the
+// SOURCE set -- and the new messages are stored as whole lines of the destination set `c2v`.  The lanes of a destination tile cover a
+// contiguous run of source positions, so every source sector is fetched by one destination tile (two at a run's ends).
+template <typename T, int ALG, int DCMAX, int FIXED_DC, int UNR, bool GATHER = false>
 __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ edge_var,
                                             T* __restrict__ c2v, const T* __restrict__ src,
                                             const u64* __restrict__ live, int m, int n, int64_t E, int tiles, int chunks,
-                                            int cpw, int first, int xcd_aware, int freeze) {
+                                            int cpw, int first, int xcd_aware, int freeze, const T* __restrict__ c2v_in = nullptr,
+                                            const int32_t* __restrict__ srcmap = nullptr) {
     const int lane = threadIdx.x;
     int tile, chunk;
     if (!task_of(tiles, chunks, xcd_aware, &tile, &chunk)) return;
@@ -203,7 +208,14 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
     const bool on = freeze ? (bool)((lv >> lane) & 1ull) : true;
     const bool dense = E * 4 >= (int64_t)m * DCMAX * 3;  // average row length at least three quarters of DCMAX (wave-uniform)
     T* ct = c2v + (int64_t)tile * E * 64 + lane;
+    const T* ci = ct;                                    // old messages in
     const T* st = src + (int64_t)tile * n * 64 + lane;
+    if constexpr (GATHER) {
+        int sm = srcmap[(int64_t)tile * 64 + lane];
+        if (sm < 0) sm = srcmap[(int64_t)tile * 64];      // a lane beyond the live frames (tail of the last tile) shadows lane 0: defined values, never looked at
+        ci = c2v_in + (int64_t)(sm >> 6) * E * 64 + (sm & 63);
+        st = src + (int64_t)(sm >> 6) * n * 64 + (sm & 63);
+    }
     const int c_end = min(m, (chunk + 1) * cpw);
     for (int c = chunk * cpw; c < c_end; c += UNR) {
         T v[UNR][DCMAX], o[UNR][DCMAX];
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
                     for (int j = 0; j < DCMAX; ++j) {
                         const int kk = FIXED_DC > 0 ? k0[u] + j : (deg[u] > 0 ? k0[u] + (j < deg[u] ? j : deg[u] - 1) : 0);
                         v[u][j] = st[(int64_t)edge_var[kk] * 64];
-                        if (!first) o[u][j] = msg_ld<LDPC_CN_NTL != 0>(ct + (int64_t)kk * 64);
+                        if (!first) o[u][j] = msg_ld<LDPC_CN_NTL != 0>(ci + (int64_t)kk * 64);
                     }
                 }
             } else {
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
                     for (int j = 0; j < DCMAX; ++j) {
                         if (j < deg[u]) {
                             v[u][j] = st[(int64_t)edge_var[k0[u] + j] * 64];
-                            if (!first) o[u][j] = msg_ld<LDPC_CN_NTL != 0>(ct + (int64_t)(k0[u] + j) * 64);
+                            if (!first) o[u][j] = msg_ld<LDPC_CN_NTL != 0>(ci + (int64_t)(k0[u] + j) * 64);
                         }
                     }
                 }
@@ -270,11 +282,14 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
 // Variable pass: marginal = prior + ordered sum of c2v (c2v is only read) ; decision bit.
 // FIXED_DV > 0: every variable has exactly that many edges (edge list of variable v at v * FIXED_DV): no col_ptr loads and no branch
 // per line, so the lines of a group of variables are fetched together
-template <typename T, int ALG, int DVMAX, int UNR, int FIXED_DV>
+// GATHER (second half of the folded repack): messages, marginals and decision words are those of the destination tiling already; the
+// priors are still read from the source position of each lane's frame (srcmap) and copied into the destination set on the way.
+template <typename T, int ALG, int DVMAX, int UNR, int FIXED_DV, bool GATHER = false>
 __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ col_edge,
                                             const T* __restrict__ c2v, const T* __restrict__ prior_t, T* __restrict__ marg_t,
                                             const u64* __restrict__ live, u64* __restrict__ xbits,
-                                            int n, int64_t E, int tiles, int chunks, int vpw, int xcd_aware, int freeze) {
+                                            int n, int64_t E, int tiles, int chunks, int vpw, int xcd_aware, int freeze,
+                                            T* __restrict__ prior_out = nullptr, const int32_t* __restrict__ srcmap = nullptr) {
     const int lane = threadIdx.x;
     int tile, chunk;
     if (!task_of(tiles, chunks, xcd_aware, &tile, &chunk)) return;
@@ -283,6 +298,13 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
     const bool on = freeze ? (bool)((lv >> lane) & 1ull) : true;  // (see k_cn; the decision words below keep the bits of departed frames either way)
     const T* ct = c2v + (int64_t)tile * E * 64 + lane;
     const T* pt = prior_t + (int64_t)tile * n * 64 + lane;
+    T* po = nullptr;
+    if constexpr (GATHER) {
+        int sm = srcmap[(int64_t)tile * 64 + lane];
+        if (sm < 0) sm = srcmap[(int64_t)tile * 64];
+        pt = prior_t + (int64_t)(sm >> 6) * n * 64 + (sm & 63);
+        po = prior_out + (int64_t)tile * n * 64 + lane;
+    }
     T* mt = marg_t + (int64_t)tile * n * 64 + lane;
     u64* xb = xbits + plane_at(tile, 0, n);  // word of variable v at xb[8 * v]
     const int v_end = min(n, (chunk + 1) * vpw);
@@ -295,7 +317,7 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
         for (int u = 0; u < UNR; ++u) {
             const int vv = vbase + u;
             // decisions of frames that have left, read ahead of the lines (a read behind this variable's marginal store would wait for it)
-            if (lv != ~0ull) old[u] = uniform_ld64(xb + 8 * (vv < v_end ? vv : v_end - 1));
+            if (lv != ~0ull) old[u] = GATHER ? 0ull : uniform_ld64(xb + 8 * (vv < v_end ? vv : v_end - 1));  // (GATHER: the destination words hold nothing yet)
             if constexpr (FIXED_DV > 0) {
                 p0[u] = (vv < v_end ? vv : v_end - 1) * FIXED_DV;  // past the end: the last variable's lines once more, result unused
                 deg[u] = vv < v_end ? FIXED_DV : -1;
@@ -335,6 +357,7 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
                     if (j < du) s += c[u][j];
                 const T marg = pr[u] + s;
                 msg_st<LDPC_VN_NTS != 0>(mt + (int64_t)(vbase + u) * 64, marg);
+                if constexpr (GATHER) po[(int64_t)(vbase + u) * 64] = pr[u];
                 b_one = marg < T(0);  // NaN marginal -> 0 (src/bpa.py:38,62)
             }
             const u64 one = __ballot(b_one);
@@ -432,14 +455,14 @@ __global__ __launch_bounds__(256) void k_repack(const T* __restrict__ msg_src, T
     T* md = msg_dst + (int64_t)dt * E * 64 + lane;
     const int64_t so = (int64_t)st * n * 64 + sl, dof = (int64_t)dt * n * 64 + lane;
     for (int64_t r = r0; r < r1; ++r) {
+        // lanes beyond the live frames (the tail of the last destination tile) get zeros, not whatever the buffer held: every lane of a
+        // live tile computes and stores in the passes that follow, and whole-line stores are the cheaper ones anyway
         if (r < E) {
-            if (has) md[r * 64] = ms[r * 64];
+            md[r * 64] = has ? ms[r * 64] : T(0);
         } else {
             const int64_t v = r - E;
-            if (has) {
-                prior_dst[dof + v * 64] = prior_src[so + v * 64];
-                marg_dst[dof + v * 64] = marg_src[so + v * 64];
-            }
+            prior_dst[dof + v * 64] = has ? prior_src[so + v * 64] : T(0);
+            marg_dst[dof + v * 64] = has ? marg_src[so + v * 64] : T(0);
             const u64 w = has ? xb_src[plane_at(st, v, n)] : 0ull;
             const u64 plane = __ballot(has && ((w >> sl) & 1ull));
             if (lane == 0) xb_dst[plane_at(dt, v, n)] = plane;
@@ -450,6 +473,24 @@ __global__ __launch_bounds__(256) void k_repack(const T* __restrict__ msg_src, T
         const u64 lv = __ballot(has);
         if (lane == 0) live_dst[dt] = lv;
     }
+}
+
+// The repack FOLDED into the next sweep (LLR decoders, node degrees up to 8): instead of copying E + 2n lines per tile, only the map is
+// built -- srcmap[dt][lane] = source tile * 64 + source lane of the frame that destination lane will hold (-1 beyond the live frames),
+// the frame indices and the live words of the destination tiling -- and the sweep that follows runs the GATHER variants of the two passes:
+// they read the old state through the map and write the new state densely into the other buffer set.  A separate repack read all of the
+// source and wrote the live part (13.7 ms at n = 64 800 / 59 % live) before a sweep that read and wrote the live part again; folded, the
+// sweep reads the source once and writes the live part once.
+__global__ __launch_bounds__(64) void k_repack_map(const u64* __restrict__ live_src, u64* __restrict__ live_dst, const int32_t* __restrict__ base,
+                                                   const int32_t* __restrict__ frame_src, int32_t* __restrict__ frame_dst,
+                                                   int32_t* __restrict__ srcmap, int tiles_src) {
+    const int lane = threadIdx.x, dt = blockIdx.x;
+    int st, sl;
+    const bool has = repack_source(base, live_src, tiles_src, dt * 64 + lane, &st, &sl);
+    srcmap[(int64_t)dt * 64 + lane] = has ? st * 64 + sl : -1;
+    frame_dst[(int64_t)dt * 64 + lane] = has ? (frame_src ? frame_src[(int64_t)st * 64 + sl] : st * 64 + sl) : -1;
+    const u64 lv = __ballot(has);
+    if (lane == 0) live_dst[dt] = lv;
 }
 
 // Frames that hit max_iter: iters = sweeps ; then planes -> x_hat bytes [B,n] in {0,1}.
@@ -556,6 +597,37 @@ void launch_vn(const Code* c, const T* c2v, const T* prior, T* marg, const u64* 
                        c2v, prior, marg, live, xbits, c->n, c->E, g.tiles, g.vn_chunks, g.vpw, g.xcd_aware, g.freeze);
 }
 
+// GATHER variants of the two passes (folded repack): built for the node degrees the LDPC ensembles of the reference have (dc <= 8, dv <= 8)
+template <typename T, int ALG, int DCMAX, int FIXED_DC>
+void launch_cn_gather(const Code* c, T* c2v, const T* c2v_in, const T* src, const u64* live, const int32_t* srcmap, const Geometry& g, hipStream_t st) {
+    constexpr int UNR = unroll_for(2 * DCMAX * (int)sizeof(T));
+    hipLaunchKernelGGL((k_cn<T, ALG, DCMAX, FIXED_DC, UNR, true>), dim3(task_blocks(g.tiles, g.cn_chunks, g.xcd_aware)), dim3(64, 4), 0, st, c->d_row_ptr,
+                       c->d_edge_var, c2v, src, live, c->m, c->n, c->E, g.tiles, g.cn_chunks, g.cpw, 0, g.xcd_aware, 0, c2v_in, srcmap);
+}
+template <typename T, int ALG, int DVMAX, int FIXED_DV = 0>
+void launch_vn_gather(const Code* c, const T* c2v, const T* prior_in, T* prior_out, T* marg, const u64* live, u64* xbits, const int32_t* srcmap,
+                      const Geometry& g, hipStream_t st) {
+    constexpr int UNR = unroll_for((DVMAX + 1) * (int)sizeof(T));
+    hipLaunchKernelGGL((k_vn<T, ALG, DVMAX, UNR, FIXED_DV, true>), dim3(task_blocks(g.tiles, g.vn_chunks, g.xcd_aware)), dim3(64, 4), 0, st, c->d_col_ptr,
+                       c->d_col_edge, c2v, prior_in, marg, live, xbits, c->n, c->E, g.tiles, g.vn_chunks, g.vpw, g.xcd_aware, 0, prior_out, srcmap);
+}
+inline bool gather_passes_built(const Code* c) { return c->max_dc <= 8 && c->max_dv <= 8; }
+template <typename T, int ALG>
+void dispatch_cn_gather(const Code* c, T* c2v, const T* c2v_in, const T* src, const u64* live, const int32_t* srcmap, const Geometry& g, hipStream_t st) {
+    if (c->min_dc == c->max_dc && c->max_dc == 6) launch_cn_gather<T, ALG, 6, 6>(c, c2v, c2v_in, src, live, srcmap, g, st);
+    else if (c->max_dc > 4 && c->max_dc <= 6) launch_cn_gather<T, ALG, 6, 0>(c, c2v, c2v_in, src, live, srcmap, g, st);
+    else if (c->max_dc <= 4) launch_cn_gather<T, ALG, 4, 0>(c, c2v, c2v_in, src, live, srcmap, g, st);
+    else launch_cn_gather<T, ALG, 8, 0>(c, c2v, c2v_in, src, live, srcmap, g, st);
+}
+template <typename T, int ALG>
+void dispatch_vn_gather(const Code* c, const T* c2v, const T* prior_in, T* prior_out, T* marg, const u64* live, u64* xbits, const int32_t* srcmap,
+                        const Geometry& g, hipStream_t st) {
+    if (c->min_dv == c->max_dv && c->max_dv == 3) launch_vn_gather<T, ALG, 3, 3>(c, c2v, prior_in, prior_out, marg, live, xbits, srcmap, g, st);
+    else if (c->min_dv == c->max_dv && c->max_dv == 4) launch_vn_gather<T, ALG, 4, 4>(c, c2v, prior_in, prior_out, marg, live, xbits, srcmap, g, st);
+    else if (c->max_dv <= 4) launch_vn_gather<T, ALG, 4>(c, c2v, prior_in, prior_out, marg, live, xbits, srcmap, g, st);
+    else launch_vn_gather<T, ALG, 8>(c, c2v, prior_in, prior_out, marg, live, xbits, srcmap, g, st);
+}
+
 template <typename T, int ALG>
 int dispatch_cn(const Code* c, T* c2v, const T* src, const u64* live, const Geometry& g, int first, hipStream_t st) {
     const bool regular = c->min_dc == c->max_dc;
@@ -645,9 +717,12 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
         if (d->msg2.reserve(nt * E * 64 * sizeof(T)) || d->marg2.reserve(nt * n * 64 * sizeof(T)) ||
             d->prior2.reserve(nt * n * 64 * sizeof(T)) || d->xbits2.reserve(plane_words((int)nt, n) * 8) || d->live2.reserve(nt * 8) ||
             d->fmap2.reserve(nt * 64 * sizeof(int32_t)) || d->fmap.reserve(nt * 64 * sizeof(int32_t)) ||
-            d->rbase.reserve(((size_t)tiles + 1) * sizeof(int32_t)))
+            d->rbase.reserve(((size_t)tiles + 1) * sizeof(int32_t)) || d->rmap.reserve(nt * 64 * sizeof(int32_t)))
             repack_ok = false;  // no room for a second set: decode without repacking
     }
+    // the repack folded into the sweep behind it (k_repack_map + GATHER passes) where those passes are built; LDPC_STREAM_REPACK_FOLD=0: the
+    // separate copy kernel (k_repack), kept for the degrees beyond and as the A/B reference
+    const bool fold_repack = gather_passes_built(c) && env_int("LDPC_STREAM_REPACK_FOLD", 1) != 0;
     T* msg = (T*)d->msg.p;
     T* marg = (T*)d->marg.p;
     T* prior = (T*)d->prior.p;
@@ -724,6 +799,7 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     int repacks = 0;
     int sweeps = 0;
     int polls = 0;
+    const T *gather_msg = nullptr, *gather_marg = nullptr, *gather_prior = nullptr;  // non-null: the next sweep carries a folded repack out of that set
     std::vector<PendingPoll> pending;
     std::vector<ProfSpan> spans;
     bool all_left = false;
@@ -792,12 +868,21 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                         // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs later)
                         launch_unpack(d, xbits, xhat, B, n, cur_tiles, fmap, st);
                         hipLaunchKernelGGL(k_repack_plan, dim3(1), dim3(1024), 0, st, live, cur_tiles, (int32_t*)d->rbase.p);
-                        const int rows_per_wave = 128;
-                        const int chunks = (int)((E + n + rows_per_wave - 1) / rows_per_wave);
-                        hipLaunchKernelGGL((k_repack<T>), dim3((chunks + 3) / 4, nt), dim3(64, 4), 0, st, msg, (T*)set_msg[nx]->p, marg,
-                                           (T*)set_marg[nx]->p, prior, (T*)set_prior[nx]->p, xbits, (u64*)set_xbits[nx]->p, live,
-                                           (u64*)set_live[nx]->p, (const int32_t*)d->rbase.p, fmap, (int32_t*)set_fmap[nx]->p, cur_tiles, n, E,
-                                           rows_per_wave);
+                        if (fold_repack) {
+                            // only the map now; the sweep enqueued below moves the state (GATHER passes: old set in, new set out)
+                            hipLaunchKernelGGL(k_repack_map, dim3(nt), dim3(64), 0, st, live, (u64*)set_live[nx]->p, (const int32_t*)d->rbase.p, fmap,
+                                               (int32_t*)set_fmap[nx]->p, (int32_t*)d->rmap.p, cur_tiles);
+                            gather_msg = msg;
+                            gather_marg = marg;
+                            gather_prior = prior;
+                        } else {
+                            const int rows_per_wave = 128;
+                            const int chunks = (int)((E + n + rows_per_wave - 1) / rows_per_wave);
+                            hipLaunchKernelGGL((k_repack<T>), dim3((chunks + 3) / 4, nt), dim3(64, 4), 0, st, msg, (T*)set_msg[nx]->p, marg,
+                                               (T*)set_marg[nx]->p, prior, (T*)set_prior[nx]->p, xbits, (u64*)set_xbits[nx]->p, live,
+                                               (u64*)set_live[nx]->p, (const int32_t*)d->rbase.p, fmap, (int32_t*)set_fmap[nx]->p, cur_tiles, n, E,
+                                               rows_per_wave);
+                        }
                         cur = nx;
                         msg = (T*)set_msg[cur]->p;
                         marg = (T*)set_marg[cur]->p;
@@ -821,9 +906,16 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
             LDPC_TRY(prof_event(d, ev_next++, &e2));
             LDPC_HIP_TRY(hipEventRecord(e0, st));
         }
-        dispatch_cn<T, ALG>(c, msg, it == 0 ? prior : marg, live, g, it == 0 ? 1 : 0, st);
-        if (d->profile) LDPC_HIP_TRY(hipEventRecord(e1, st));
-        dispatch_vn<T, ALG>(c, msg, prior, marg, live, xbits, g, st);
+        if (gather_msg) {  // the sweep that carries a repack: state read from the old set through the map, written densely into the new one
+            dispatch_cn_gather<T, ALG>(c, msg, gather_msg, gather_marg, live, (const int32_t*)d->rmap.p, g, st);
+            if (d->profile) LDPC_HIP_TRY(hipEventRecord(e1, st));
+            dispatch_vn_gather<T, ALG>(c, msg, gather_prior, prior, marg, live, xbits, (const int32_t*)d->rmap.p, g, st);
+            gather_msg = gather_marg = gather_prior = nullptr;
+        } else {
+            dispatch_cn<T, ALG>(c, msg, it == 0 ? prior : marg, live, g, it == 0 ? 1 : 0, st);
+            if (d->profile) LDPC_HIP_TRY(hipEventRecord(e1, st));
+            dispatch_vn<T, ALG>(c, msg, prior, marg, live, xbits, g, st);
+        }
         if (d->profile) {
             LDPC_HIP_TRY(hipEventRecord(e2, st));
             spans.push_back({0, e0, e1});

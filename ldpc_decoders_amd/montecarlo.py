@@ -176,15 +176,16 @@ class DeviceSimulator:
         blk["busy"] = True
         return blk
 
-    def finish_rounds(self, blk):
-        """Wait for one ``launch_rounds`` ticket; returns its whole-job counter rows (numpy int64 [rounds, 4 + hist_bins])."""
+    def finish_rounds(self, blk, counted=True):
+        """Wait for one ``launch_rounds`` ticket; returns its whole-job counter rows (numpy int64 [rounds, 4 + hist_bins]).
+        ``counted=False``: a speculative block that the stopping rule discards -- its fp64 redo frames do not enter ``redone``."""
         if blk["done"] is not None:
             blk["done"].synchronize()
         blk["busy"] = False
         out = blk["host"].numpy().copy()
         if self.prior_grid is not None:
             k = 4 + self.hist_bins
-            self._check_redo(out[0, k:])
+            self._check_redo(out[0, k:], counted)
             out = out[:, :k]
         return out
 
@@ -207,22 +208,25 @@ class DeviceSimulator:
         slot["busy"] = True
         return slot
 
-    def _check_redo(self, extra):
+    def _check_redo(self, extra, counted=True):
         """extra = [frames re-decoded in fp64, redo-list overflows] of a finished round / block."""
+        if not counted:
+            return
         if extra[1] != 0:
             raise _lib.LdpcHipError("prior grid 2^-%d: more than %d frames of one block of rounds beyond the exactness guard -- the grid is too fine "
                                     "for this operating point" % (self.prior_grid, self.h.REDO_ROWS))
         self.redone += int(extra[0])
 
-    def finish_round(self, slot):
-        """Wait for one launched round; returns its whole-job counters (numpy int64)."""
+    def finish_round(self, slot, counted=True):
+        """Wait for one launched round; returns its whole-job counters (numpy int64).  ``counted=False``: a speculative round that the
+        stopping rule discards (its fp64 redo frames do not enter ``redone``)."""
         if slot["done"] is not None:
             slot["done"].synchronize()
         slot["busy"] = False
         out = slot["host"].numpy().copy()
         if self.prior_grid is not None:
             k = 4 + self.hist_bins
-            self._check_redo(out[k:])
+            self._check_redo(out[k:], counted)
             out = out[:k]
         return out
 
@@ -271,15 +275,16 @@ class DeviceSimulator:
             while more() and len(inflight) < depth:
                 inflight.append(self.launch_rounds(param, stream_id, frame0, per_round, rpl))
                 frame0 += per_round * rpl
-            for row in self.finish_rounds(inflight.pop(0)):
+            for row in self.finish_rounds(inflight.pop(0), counted=more()):  # (the redo count is per block: in, if its first row is)
                 if more():
                     count(row)
         while more() or inflight:
             while more() and len(inflight) < depth:
                 inflight.append(self.launch_round(param, stream_id, frame0, per_round))
                 frame0 += per_round
-            got = self.finish_round(inflight.pop(0))
-            if more():
+            keep = more()
+            got = self.finish_round(inflight.pop(0), counted=keep)
+            if keep:
                 count(got)
         if tot[_lib.CNT_WEC] < min_wec:
             capped = True  # stopped by max_frames, not by the word-error target

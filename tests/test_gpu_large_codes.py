@@ -164,7 +164,10 @@ def test_config3_spa_bsc_full_batch(tmp_path):
     print("config 3 sum-product / BSC: oracle sweeps of the differing frames %s; %d frames of the batch need >= 15 sweeps (mean %.2f)" % (
         sorted(io[differ].tolist()), int(slow.sum()), float(io.mean())))
     assert slow[differ].all(), "a frame that converges quickly differs from the fp64 oracle"
-    assert len(differ) <= 40, "more than 0.06 % of the batch differ"
+    # ... and the GPU's own run of those frames is just as slow: a regression that broke slow-converging but decodable frames would show
+    # as differing frames the GPU leaves early (or as many more of them than the 26 +- a few that re-association moves around)
+    assert (it[idx][differ] >= 15).all(), "the fp32 kernel leaves a differing frame early: %s" % sorted(it[idx][differ].tolist())
+    assert len(differ) <= 32, "%d frames differ (rounds 4 and 5: 26)" % len(differ)
     assert (np.abs(it[idx] - io) <= 1)[io < 50].mean() >= 0.999
     # the published curve, in the reference's arithmetic
     ref = _published_point("bsc", "1200_3_6_rand_ldpc_1", "SPA", 10, 0, "0.06")

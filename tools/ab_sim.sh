@@ -14,6 +14,8 @@ CASES=(
  "c5_stream|--code gen:reg:64800:3:6 --alg MSA --channel biawgn --param 1.0 --batch 16384 --precision f32 --backend stream --launches 1"
  "c4_stream|--code gen:irg:10000 --alg MSA --channel biawgn --param 1.8 --batch 32768 --precision f32 --backend stream --launches 1"
  "c4_f32|--code gen:irg:10000 --alg MSA --channel biawgn --param 1.2 --batch 32768 --precision f32 --launches 2"
+ "c4_grid|--code gen:irg:10000 --alg MSA --channel biawgn --param 1.2 --batch 32768 --precision f32 --prior-grid 8 --launches 2"
+ "c4_spa|--code gen:irg:10000 --alg SPA --channel biawgn --param 1.2 --batch 16384 --precision f32 --launches 2"
  "c3_bec|--code 1200_3_6_rand_ldpc_1 --alg BEC --channel bec --param 0.40 --batch 65536 --precision f32 --launches 6"
  "c3_spa_bsc|--code 1200_3_6_rand_ldpc_1 --alg SPA --channel bsc --param 0.07 --batch 65536 --precision f32 --launches 6"
  "c2_f32|--code 1200_3_6_rand_ldpc_1 --alg MSA --channel biawgn --param 1.0 --batch 65536 --precision f32 --launches 6"
