@@ -110,6 +110,10 @@ def bytes_per_frame_sweep(code, alg, precision):
     check -- (4E + m + 3n) / 4 bytes (erasure decoder)."""
     if alg == "BEC":
         return (4 * code.E + code.m + 3 * code.n) / 4.0
+    if alg == "ADMM":  # one ADMM iteration with z, lambda, x, gamma, d1, d2 in HBM (the streaming kernels): x pass z, lambda, gamma in + x out;
+        return 8 * (9 * code.E + 2 * code.n)  # z pass x gather, lambda in / out, z in / out, d1, d2 out; stopping test d1, d2 in (fp64)
+    if alg == "ML":    # per FRAME: nothing but the counters leaves the kernel; the model prices the observation vector the search reads
+        return (8 if precision == "f64" else 4) * code.n
     if precision == "f16":
         return 8 * code.E + 4 * code.n
     return (8 if precision == "f64" else 4) * (4 * code.E + code.n)
@@ -133,6 +137,8 @@ def cpu_baseline(code, alg, channel, param, max_iter, precision="f64", budget_s=
     import bp_oracle as O
     import c_oracle as C
 
+    if alg in ("ADMM", "ML"):
+        return cpu_baseline_aux(code, alg, channel, param, max_iter, budget_s)
     g = O.Edges(code.m, code.n, code.edge_chk, code.edge_var)
     cores = os.cpu_count() or 1
     dt_np = np.float64 if precision == "f64" else np.float32  # (fp16 storage has no CPU counterpart: its arithmetic is fp32)
@@ -210,6 +216,108 @@ def cpu_baseline(code, alg, channel, param, max_iter, precision="f64", budget_s=
     except Exception as e:  # the baseline is a report, never a reason to lose the benchmark line
         out["scipy"] = {"error": repr(e)}
     return out
+
+
+def cpu_baseline_aux(code, alg, channel, param, max_iter, budget_s):
+    """CPU baselines of the SURVEY 8(f) decoders: ADMM = oracle/admm_oracle.c (OpenMP over frames, every host thread; its projection is pinned
+    to the reference's own projection.cpp), ML = oracle/ml_oracle.py (numpy, the reference's expressions, ONE core)."""
+    import bp_oracle as O
+
+    rng = np.random.RandomState(2024)
+    cores = os.cpu_count() or 1
+    zero = np.zeros(code.n, dtype=np.int64)
+    if alg == "ADMM":
+        import admm_oracle as A
+
+        class G:
+            m, n, chk, var = code.m, code.n, code.edge_chk, code.edge_var
+
+        def decode(nf):
+            gamma = O.biawgn_priors(O.biawgn_send(np.broadcast_to(zero, (nf, code.n)), param, rng), param)
+            t0 = time.time()
+            _, it, _ = A.admm_decode(G, gamma, 3.0, 1e-5, max_iter)
+            return time.time() - t0, it
+
+        probe = max(cores, min(4 * cores, 2_000_000 // code.n))
+        rate = probe / max(decode(probe)[0], 1e-6)
+        nf = int(max(probe, min(rate * budget_s, 200000)))
+        dt, it = decode(nf)
+        return {"value": round(nf / dt, 1), "unit": "frames/s", "cores": cores, "physical_cores": physical_cores(), "kind": "port",
+                "sample": "%d frames, same H / ADMM (mu 3, eps 1e-5) over %s at %s / max_iter %d, fp64 C port of the reference algorithm incl. its "
+                          "parity-polytope projection (oracle/admm_oracle.c), %d OpenMP threads, %.1f s, mean %.1f iterations/frame" % (
+                              nf, channel, param_label(channel, param), max_iter, cores, dt, float(it.mean())),
+                "scipy": {"skipped": "the scipy.sparse leg restates the BP decoders (src/bpa.py)"}}
+    import ml_oracle as M
+    from ldpc_decoders_amd.models import models
+
+    chan = models[channel].Channel(param)
+    coef = M.ml_coefficients(channel, param)
+    np.random.seed(1)
+    nf, t0 = 0, time.time()
+    with np.errstate(all="ignore"):
+        while time.time() - t0 < min(budget_s, 5.0):
+            M.ml_decode(channel, code.cb, chan.send(zero), coef)
+            nf += 1
+    dt = time.time() - t0
+    return {"value": round(nf / dt, 1), "unit": "frames/s", "cores": 1, "physical_cores": physical_cores(), "kind": "port",
+            "sample": "%d frames, exhaustive search over the %d codewords of %s over %s at %s, numpy restatement of the reference's expressions "
+                      "(oracle/ml_oracle.py), one core, %.1f s (channel draw included)" % (nf, len(code.cb), "the code", channel, param_label(channel, param), dt),
+            "scipy": {"skipped": "the scipy.sparse leg restates the BP decoders (src/bpa.py)"}}
+
+
+class AuxHandle:
+    """What run_bench asks of a decoder handle, for the SURVEY 8(f) decoders (ADMM: _device.AdmmHandle, ML: _device.MlHandle)."""
+
+    def __init__(self, code, alg, precision, channel):
+        from ldpc_decoders_amd import _device
+
+        self.alg, self.code = alg, code
+        if alg == "ADMM":
+            self.inner = _device.AdmmHandle(code)
+            self.inner.mu, self.inner.eps = 3.0, 1e-5
+        else:
+            self.inner = _device.MlHandle(code.cb, channel, precision)
+
+    def simulate(self, *a, **k):
+        return self.inner.simulate(*a, **k)
+
+    def last_stats(self):
+        return ("admm-" + self.inner.last_backend() if self.alg == "ADMM" else "ml"), 0
+
+    def kernel_name(self, simulate=False):
+        if self.alg == "ADMM":
+            return "k_admm_lds<6, 3, 2, %d>" % ((self.code.m + 63) // 64) if self.inner.last_backend() == "lds" else "k_admm_z_fixed<6>"
+        return "k_ml"
+
+    def timed_launches(self, channel, param, frames, max_iter, steps, torch):
+        """HIP-event time of `steps` launches of the dominant kernel ALONE on torch's current stream (the library launches on it), with
+        inputs resident in HBM -> (ms per launch, frame-iterations [ADMM] or frames [ML] per launch)."""
+        from ldpc_decoders_amd import _lib
+
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if self.alg == "ADMM":
+            gamma = torch.empty((frames, self.code.n), dtype=torch.float64, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.load().ldpc_channel(_lib.CHANNEL[channel], _lib.DTYPE["f64"], float(param), 0, 0x5EED1200, 9, 0, frames, self.code.n,
+                                                gamma.data_ptr(), None, st))
+            _, it, _ = self.inner.decode_device(gamma, 3.0, 1e-5, max_iter)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(steps):
+                self.inner.decode_device(gamma, 3.0, 1e-5, max_iter)
+            e1.record()
+            torch.cuda.synchronize()
+            # the estimate buffers of decode_device are torch allocations from the caching allocator: no device synchronisation in the loop
+            return e0.elapsed_time(e1) / steps, float(it.sum().item()) + frames  # (the iteration that meets the test counts: it + 1 per frame)
+        cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+        self.inner.simulate(channel, param, 0, 0x5EED1200, 9, 0, frames, 0, cnt)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(steps):
+            self.inner.simulate(channel, param, 0, 0x5EED1200, 9, i * frames, frames, 0, cnt)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps, float(frames)
 
 
 def _scipy_probe(task):
@@ -407,21 +515,26 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
 
     from ldpc_decoders_amd.montecarlo import DeviceSimulator
 
-    if make_handle is None:
-        from ldpc_decoders_amd._device import DecoderHandle as make_handle  # noqa: N813
     code = load_code(args.code)
     alg, channel, param = resolve_workload(args.decoder, args.channel, args.param, args.snr)
-    precision = "f32" if alg == "BEC" else args.precision  # the erasure decoder has no floating-point state (2-bit messages in bit planes)
+    if make_handle is None and alg not in ("ADMM", "ML"):
+        from ldpc_decoders_amd._device import DecoderHandle as make_handle  # noqa: N813
+    aux = alg in ("ADMM", "ML")
+    precision = "f32" if alg == "BEC" else ("f64" if alg == "ADMM" else args.precision)  # the erasure decoder has no floating-point state (2-bit messages in bit planes)
+    if aux and make_handle is None:
+        make_handle = lambda code_, alg_, prec_, backend_: AuxHandle(code_, alg_, prec_, channel)  # noqa: E731
     points = args.points if args.points is not None else {"biawgn": [2.0, 3.0], "bsc": [0.05], "bec": [0.35]}[channel]
     hist_bins = min(args.max_iter + 1, 60)  # the in-kernel histogram has 60 bins: sweeps >= 59 share the last one (reported on the line)
     msa_biawgn = alg == "MSA" and channel == "biawgn"
+    if aux and args.points is None:
+        points = []
     handle = make_handle(code, alg, precision, args.backend)
     sim = DeviceSimulator(handle, channel, args.max_iter, 0, 0x5EED1200, comm, hist_bins=hist_bins, device=device)
     s = 8 if precision == "f64" else 4
     bytes_per_frame_iter = bytes_per_frame_sweep(code, alg, precision)  # SURVEY.md 8(d) for the LLR decoders
     f16 = precision == "f16"
-    side_legs = not args.no_profile and comm.world == 1 and device == "cuda" and not getattr(args, "headline_only", False)
-    kernel_pass = not args.no_profile and device == "cuda"
+    side_legs = not args.no_profile and comm.world == 1 and device == "cuda" and not getattr(args, "headline_only", False) and not aux
+    kernel_pass = not args.no_profile and device == "cuda" and not aux
     # frames of one step over all ranks: weak scaling (--batch frames per GPU, the default) or strong (--total-batch frames per step
     # whatever N is -- BASELINE configs 4 and 5 state their batch for the whole 8-GPU node; a total that N does not divide is split
     # as evenly as possible by Comm.shard)
@@ -609,7 +722,20 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
         roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
                     algorithmic_bytes_per_frame_sweep=bytes_per_frame_iter, kernel="whole step",
                     note="no per-pass HIP events on this backend: executed frame-sweeps x algorithmic bytes / WALL time of the step")
-    decoder_name = {"MSA": "min-sum", "SPA": "sum-product", "BEC": "erasure decoder"}[alg]
+    if aux and device == "cuda" and not args.no_profile and hasattr(handle, "timed_launches"):
+        # the dominant kernel alone (k_admm_lds / k_ml), HIP events on the stream it is launched on, inputs resident in HBM
+        ms, units = handle.timed_launches(channel, param, rank_batch, args.max_iter, max(2, min(args.steps, 8)), torch)
+        kname = handle.kernel_name(True)
+        ups = units / (ms * 1e-3)  # frame-iterations/s (ADMM) or frames/s (ML) of that kernel
+        roof = fused_roofline(kname, ups, cus) or dict(bound="valu", frac=None, achieved=None, peak=round(cus * 4 * NOMINAL_CLOCK_HZ / 1e9, 1),
+                                                        unit="G VALU issue cycles/s (all SIMDs)", note="no committed PMC counters for %s: run tools/collect_rooflines.sh" % kname)
+        gbs = ups * bytes_per_frame_iter / 1e9
+        roof.update(kernel=kname, kernel_class="admm_decode" if alg == "ADMM" else "ml_simulate", avg_launch_ms=round(ms, 4), traffic=None,
+                    units_per_s=round(ups, 1), unit_of_work="frame-iteration" if alg == "ADMM" else "frame",
+                    hbm_model={"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "hbm_model_frac": round(gbs / HBM_PEAK_GBS, 4),
+                               "flag": "on-chip kernel: the state never leaves the CU, this bounds nothing" if handle.last_stats()[0] != "admm-stream" else "streaming kernels",
+                               "note": "%s x %d B / HIP-event time of the kernel" % ("frame-iterations" if alg == "ADMM" else "frames", bytes_per_frame_iter)})
+    decoder_name = {"MSA": "min-sum", "SPA": "sum-product", "BEC": "erasure decoder", "ADMM": "ADMM LP decoder (mu 3, eps 1e-5)", "ML": "ML (exhaustive search)"}[alg]
     channel_name = {"biawgn": "BI-AWGN", "bsc": "BSC", "bec": "BEC"}[channel]
     out = {
         "metric": ("decoded frames/s, n=1200 (3,6) min-sum max_iter=50 (+ roofline of the dominant kernel)"
@@ -626,7 +752,7 @@ def run_bench(args, comm, make_handle=None, device="cuda", cpu_base=None):
                        channel_name, args.max_iter,
                        ("batch=%d frames per step over all GPUs" % per_round) if strong else ("batch=%d frames/GPU" % args.batch),
                        param_label(channel, param), head["mean_sweeps"]),
-                   "code": args.code, "n": code.n, "m": code.m, "E": code.E, "decoder": args.decoder if alg != "BEC" else alg, "channel": channel,
+                   "code": args.code, "n": code.n, "m": code.m, "E": int(code.E), "decoder": args.decoder if alg != "BEC" else alg, "channel": channel,
                    ("snr_db" if channel == "biawgn" else "param"): param,
                    "max_iter": args.max_iter, "batch_per_gpu": rank_batch if strong else args.batch, "total_batch": per_round, "backend": backend_used,
                    "sweep_histogram_bins": hist_bins, "steps_per_launch": sim.rounds_per_launch() if hasattr(sim, "rounds_per_launch") else 1,
@@ -709,7 +835,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=65536, help="frames per GPU per step (weak scaling: the whole job decodes N x this per step)")
     ap.add_argument("--total-batch", type=int, default=None,
                     help="frames per step over ALL GPUs (strong scaling: each rank decodes its shard; BASELINE configs 4 / 5 state 2^20 / 2^18 for 8 GPUs)")
-    ap.add_argument("--decoder", default="MSA", choices=["MSA", "SPA", "BEC"], help="decoder selector of the reference's CLI (src/main.py:12, src/utils.py:16)")
+    ap.add_argument("--decoder", default="MSA", choices=["MSA", "SPA", "BEC", "ADMM", "ML"],
+                    help="decoder selector of the reference's CLI (src/main.py:12, src/utils.py:16); ADMM (src/admm.py:42-69, mu = 3, eps = 1e-5) and ML "
+                         "(exhaustive search over the codebook of a short code, src/biawgn.py:66-78) are the SURVEY 8(f) decoders")
     ap.add_argument("--channel", default="biawgn", choices=["biawgn", "bsc", "bec"],
                     help="channel selector (src/models.py:3); `bec` pairs with the ternary erasure decoder whatever --decoder says, as in the registry")
     ap.add_argument("--param", type=float, default=None, help="channel parameter: SNR in dB / crossover probability / erasure probability (default: --snr, 0.07, 0.40)")

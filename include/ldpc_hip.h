@@ -236,6 +236,10 @@ int ldpc_admm_decode(ldpc_admm_t admm, const double* gamma_dev, int64_t B, doubl
 
 /* how often the last ldpc_admm_decode gathered its live frames into dense tiles (frames leave one by one, src/admm.py:65-66) */
 int ldpc_admm_last_repacks(ldpc_admm_t admm, int* repacks);
+/* which kernels the last ldpc_admm_decode ran on: 0 = the streaming kernels (state in HBM, any code), 1 = the LDS-resident kernel (one
+ * workgroup per frame, z / lambda / x in the LDS of the CU: codes whose checks all have six edges and whose frame fits 160 KB).
+ * Same arithmetic either way: estimates and iteration counts are bit-identical.  LDPC_ADMM_BACKEND=stream forces 0. */
+int ldpc_admm_last_backend(ldpc_admm_t admm, int* backend);
 
 /* Profiling aid: coalesced 4-byte-per-lane device copy of a known size, used to calibrate the profiler's HBM byte
  * counters for the access width of the streaming kernels. */

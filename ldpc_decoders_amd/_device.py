@@ -499,6 +499,12 @@ class AdmmHandle:
         _lib.check(_lib.load().ldpc_admm_last_repacks(self.h, ctypes.byref(r)))
         return r.value
 
+    def last_backend(self):
+        """Kernels of the last decode: "stream" (state in HBM) or "lds" (one workgroup per frame, state in the LDS)."""
+        r = ctypes.c_int(0)
+        _lib.check(_lib.load().ldpc_admm_last_backend(self.h, ctypes.byref(r)))
+        return "lds" if r.value == 1 else "stream"
+
     def simulate(self, channel, param, codeword, seed, stream_id, frame0, B, max_iter, counters, flags=0, hist_bins=0):
         """Same call shape as DecoderHandle.simulate: device channel kernel -> LLRs -> ADMM -> pseudo_to_cw -> counters, all
         on the GPU (a composition of ldpc_channel / ldpc_admm_decode / torch element-wise ops; no host noise)."""

@@ -81,6 +81,7 @@ SIGNATURES = {
     "ldpc_admm_create": (_c.c_int, [_P, _c.POINTER(_P)]),
     "ldpc_admm_destroy": (_c.c_int, [_P]),
     "ldpc_admm_last_repacks": (_c.c_int, [_P, _c.POINTER(_c.c_int)]),
+    "ldpc_admm_last_backend": (_c.c_int, [_P, _c.POINTER(_c.c_int)]),
     "ldpc_admm_decode": (_c.c_int, [_P, _P, _c.c_int64, _c.c_double, _c.c_double, _c.c_int32, _P, _P, _P, _P]),
     "ldpc_ml_simulate": (_c.c_int, [_P, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_uint64, _c.c_uint64, _c.c_uint64,
                                     _c.c_int64, _P, _P]),

@@ -12,8 +12,10 @@
 #include "ldpc_common.hpp"
 #include "ldpc_repack.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <new>
+#include <string>
 #include <vector>
 
 namespace ldpc {
@@ -29,6 +31,14 @@ struct AdmmDecoder {
     int leaves = 0, prog_len = 0;
     void* pinned = nullptr;
     int last_iters = 0;
+    // LDS-resident kernel (k_admm_lds): the split tree of numpy's pairwise sum as a level schedule -- node i (leaves first, then the
+    // additions) = node lvl_a[i] + node lvl_b[i]; the additions of level l are [lvl_start[l], lvl_start[l + 1])
+    int32_t* d_lvl_a = nullptr;
+    int32_t* d_lvl_b = nullptr;
+    int32_t* d_lvl_start = nullptr;
+    int levels = 0, nodes = 0;
+    unsigned long long* d_ticket = nullptr;  // frame dispenser of the LDS-resident kernel
+    int last_backend = 0;                    // 0: streaming kernels, 1: LDS-resident kernel
 };
 
 namespace {
@@ -569,6 +579,196 @@ __global__ __launch_bounds__(256) void k_admm_repack(const double* __restrict__ 
     }
 }
 
+
+// =====================================================================================================================================
+// LDS-resident ADMM (round 6): ONE workgroup owns ONE frame for all its iterations; z, lambda, lambda / mu, the two squared-distance
+// vectors of the stopping test and x live in the LDS of the CU (n = 1200 (3,6): 5 x 28.8 KB + 9.6 KB), only gamma in / the estimate out
+// touch HBM.  The streaming kernels above move 8 (9E + 2n) bytes per frame-iteration through HBM and keep every tile in lockstep with
+// its slowest frame; here a frame leaves at its own iteration (src/admm.py:65-66) and the workgroup takes the next one from a
+// dispenser.  Same arithmetic, operation by operation (pp_project_fixed; the ordered column sum; numpy's pairwise stopping sums):
+// estimates and iteration counts are bit-identical to the streaming kernels' and the reference's.
+//
+// Codes whose checks all have L edges (edge k = L c + j).  Edge arrays are kept POSITION-major in the LDS -- element (c, j) at
+// j * m + c -- so that the check phase (lane == check) reads and writes them lane-contiguously; the variable phase gathers.
+//   phase A  x update (src/admm.py:54-55), lane == variable (VPL variables per lane): s = sum over its edges in ascending edge order
+//            of z - lambda / mu; x = clip((s - gamma / mu) / deg).  lambda / mu is kept from the check phase (the same division,
+//            done once), gamma / mu once per frame.
+//   phase B  z / lambda update (src/admm.py:58-63), lane == check: projection in registers (pp_project_fixed), d1 = (x - z')^2,
+//            d2 = (z - z')^2 (src/admm.py:18-19).
+//   phase C  stopping test (src/admm.py:21,65): numpy's pairwise sums of d1 and d2 -- per block of <= 128 elements eight strided
+//            accumulators (one lane per accumulator chain), the block sums folded up the split tree level by level (one wave).
+struct AdmmLdsArgs {
+    const double* gamma;
+    double* x_out;
+    int32_t* iters;
+    uint8_t* converged;
+    const int32_t *col_ptr, *col_edge, *edge_var, *leaf_off, *leaf_len, *lvl_a, *lvl_b, *lvl_start;
+    int m, n, E, leaves, levels, nodes;
+    long long B;
+    double mu, thresh;
+    int max_iter, cap;
+    unsigned long long* ticket;
+};
+
+template <int L, int DVMAX, int VPL, int NW>
+__global__ __launch_bounds__(64 * NW) void k_admm_lds(const AdmmLdsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, T = 64 * NW;
+    const int m = A.m, n = A.n, E = A.E;
+    double* const z = reinterpret_cast<double*>(smem);
+    double* const lam = z + E;
+    double* const q = lam + E;    // lambda / mu
+    double* const d1 = q + E;
+    double* const d2 = d1 + E;
+    double* const x = d2 + E;
+    double* const racc = x + n;                        // [2][leaves][8] accumulator chains
+    double* const val = racc + 2 * A.leaves * 8;        // [2][nodes] block sums and the tree above them
+    volatile int* const word = reinterpret_cast<volatile int*>(val + 2 * A.nodes);  // [0] frame hand-out (lo), [1] (hi), [2] verdict
+    const double mu = A.mu;
+    auto eidx = [&](int k) { return (k % L) * m + k / L; };  // canonical edge index -> LDS position
+
+    for (;;) {
+        // ---- next frame
+        __syncthreads();  // everybody is done with the previous frame's LDS state and hand-out words
+        if (tid == 0) {
+            const unsigned long long t = atomicAdd(A.ticket, 1ull);
+            word[0] = (int)(unsigned)(t & 0xffffffffull);
+            word[1] = (int)(unsigned)(t >> 32);
+        }
+        __syncthreads();
+        const long long fr = (long long)(((unsigned long long)(unsigned)word[1] << 32) | (unsigned)word[0]);
+        if (fr >= A.B) break;
+        // ---- state: z = 0.5, lambda = 0 (src/admm.py:44); gamma / mu in registers
+        for (int k = tid; k < E; k += T) {
+            z[k] = 0.5;
+            lam[k] = 0.0;
+            q[k] = 0.0 / mu;
+        }
+        double gq[VPL];
+#pragma unroll
+        for (int r = 0; r < VPL; ++r) {
+            const int v = tid + r * T;
+            gq[r] = v < n ? A.gamma[fr * n + v] / mu : 0.0;
+        }
+        __syncthreads();
+        int it = 0, result_iters = 0;
+        bool conv = false;
+        for (;; ++it) {
+            // ---- phase A: x update
+#pragma unroll
+            for (int r = 0; r < VPL; ++r) {
+                const int v = tid + r * T;
+                if (v < n) {
+                    const int p0 = A.col_ptr[v], p1 = A.col_ptr[v + 1];
+                    int kk[DVMAX];
+#pragma unroll
+                    for (int j = 0; j < DVMAX; ++j) kk[j] = eidx(A.col_edge[p0 + j < p1 ? p0 + j : p0]);
+                    double s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < DVMAX; ++j) {
+                        const double t = z[kk[j]] - q[kk[j]];
+                        s = (p0 + j < p1) ? s + t : s;
+                    }
+                    x[v] = clamp01((s - gq[r]) / (double)(p1 - p0));
+                }
+            }
+            __syncthreads();
+            // ---- phase B: z / lambda update, lane == check
+            if (tid < m) {
+                double xs[L], lm[L], zo[L], v[L];
+#pragma unroll
+                for (int j = 0; j < L; ++j) {
+                    const int o = j * m + tid;
+                    xs[j] = x[A.edge_var[tid * L + j]];
+                    lm[j] = lam[o];
+                    zo[j] = z[o];
+                    v[j] = xs[j] + q[o];
+                }
+                pp_project_fixed<L>(v);
+#pragma unroll
+                for (int j = 0; j < L; ++j) {
+                    const int o = j * m + tid;
+                    const double a = xs[j] - v[j], b = zo[j] - v[j];
+                    const double ln = lm[j] + mu * a;
+                    lam[o] = ln;
+                    q[o] = ln / mu;
+                    d1[o] = a * a;
+                    d2[o] = b * b;
+                    z[o] = v[j];
+                }
+            }
+            __syncthreads();
+            // ---- phase C1: the eight strided accumulators of every block (np_block), one lane per chain
+            for (int idx = tid; idx < 2 * A.leaves * 8; idx += T) {
+                const int arr = idx / (A.leaves * 8), rem = idx - arr * (A.leaves * 8), leaf = rem >> 3, kacc = rem & 7;
+                const int off = A.leaf_off[leaf], len = A.leaf_len[leaf];
+                const double* a = arr ? d2 : d1;
+                if (len >= 8) {
+                    double rsum = a[eidx(off + kacc)];
+                    for (int i = 8; i < len - (len % 8); i += 8) rsum += a[eidx(off + i + kacc)];
+                    racc[idx] = rsum;
+                }
+            }
+            __syncthreads();
+            // ---- phase C2 + C3 (one wave): block sums, then the additions of the split tree level by level
+            if (tid < 64) {
+                for (int idx = tid; idx < 2 * A.leaves; idx += 64) {
+                    const int arr = idx / A.leaves, leaf = idx - arr * A.leaves;
+                    const int off = A.leaf_off[leaf], len = A.leaf_len[leaf];
+                    const double* a = arr ? d2 : d1;
+                    double res;
+                    int i;
+                    if (len < 8) {
+                        res = -0.0;
+                        i = 0;
+                    } else {
+                        const double* r8 = racc + (arr * A.leaves + leaf) * 8;
+                        res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+                        i = len - (len % 8);
+                    }
+                    for (; i < len; ++i) res += a[eidx(off + i)];
+                    val[arr * A.nodes + leaf] = res;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int lv = 0; lv < A.levels; ++lv) {
+                    const int s0 = A.lvl_start[lv], s1 = A.lvl_start[lv + 1];
+                    for (int idx = tid; idx < 2 * (s1 - s0); idx += 64) {
+                        const int arr = idx / (s1 - s0), node = s0 + idx - arr * (s1 - s0);
+                        val[arr * A.nodes + node] = val[arr * A.nodes + A.lvl_a[node]] + val[arr * A.nodes + A.lvl_b[node]];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (tid == 0) {
+                    const double aa1 = 0.0 + val[A.nodes - 1], aa2 = 0.0 + val[2 * A.nodes - 1];
+                    word[2] = (aa1 < A.thresh && aa2 < A.thresh) ? 1 : 0;
+                }
+            }
+            __syncthreads();
+            const bool close = word[2] != 0;
+            const bool capped = (A.max_iter > 0 && it + 1 >= A.max_iter) || it + 1 >= A.cap;
+            if (close) {
+                conv = true;
+                result_iters = it;
+                break;
+            }
+            if (capped) {
+                result_iters = it + 1;
+                break;
+            }
+        }
+        // ---- estimate out (the x of the iteration that ended the loop, src/admm.py:66-69)
+#pragma unroll
+        for (int r = 0; r < VPL; ++r) {
+            const int v = tid + r * T;
+            if (v < n) A.x_out[fr * n + v] = x[v];
+        }
+        if (tid == 0) {
+            A.iters[fr] = result_iters;
+            if (A.converged) A.converged[fr] = conv ? 1 : 0;
+        }
+    }
+}
+
 }  // namespace
 
 int admm_create(Code* code, AdmmDecoder** out) {
@@ -599,6 +799,46 @@ int admm_create(Code* code, AdmmDecoder** out) {
     Split::run(0, code->E, off, len, prog);
     d->leaves = (int)off.size();
     d->prog_len = (int)prog.size();
+    // the same tree as a level schedule (k_admm_lds): replay the stack program, every addition becomes a node one level above its deeper child
+    std::vector<int32_t> lvl_a, lvl_b, lvl_start;
+    {
+        const int leaves = d->leaves;
+        std::vector<int> stack, node_level((size_t)leaves, 0), ea, eb;  // additions in program order
+        for (int32_t op : prog) {
+            if (op >= 0) {
+                stack.push_back(op);
+            } else {
+                const int b = stack.back(); stack.pop_back();
+                const int a = stack.back(); stack.pop_back();
+                const int id = leaves + (int)ea.size();
+                ea.push_back(a);
+                eb.push_back(b);
+                node_level.push_back(1 + std::max(node_level[a], node_level[b]));
+                stack.push_back(id);
+            }
+        }
+        // renumber the additions level by level (the root last), children before parents
+        int maxl = 0;
+        for (int v : node_level) maxl = std::max(maxl, v);
+        std::vector<int> newid((size_t)leaves + ea.size());
+        for (int i = 0; i < leaves; ++i) newid[i] = i;
+        int next = leaves;
+        lvl_a.assign((size_t)leaves + ea.size(), 0);
+        lvl_b.assign((size_t)leaves + ea.size(), 0);
+        for (int l = 1; l <= maxl; ++l) {
+            lvl_start.push_back(next);
+            for (size_t i = 0; i < ea.size(); ++i)
+                if (node_level[leaves + i] == l) {
+                    newid[leaves + i] = next;
+                    lvl_a[next] = newid[ea[i]];
+                    lvl_b[next] = newid[eb[i]];
+                    ++next;
+                }
+        }
+        lvl_start.push_back(next);
+        d->levels = maxl;
+        d->nodes = next;
+    }
     hipError_t e = hipSetDevice(code->device);
     if (e == hipSuccess) e = hipHostMalloc(&d->pinned, 64);
     if (e == hipSuccess) e = hipMalloc((void**)&d->d_leaf_off, off.size() * 4);
@@ -607,6 +847,13 @@ int admm_create(Code* code, AdmmDecoder** out) {
     if (e == hipSuccess) e = hipMemcpy(d->d_leaf_off, off.data(), off.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_leaf_len, len.data(), len.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_prog, prog.data(), prog.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->d_lvl_a, lvl_a.size() * 4 + 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->d_lvl_b, lvl_b.size() * 4 + 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->d_lvl_start, lvl_start.size() * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->d_ticket, 64);
+    if (e == hipSuccess) e = hipMemcpy(d->d_lvl_a, lvl_a.data(), lvl_a.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d->d_lvl_b, lvl_b.data(), lvl_b.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d->d_lvl_start, lvl_start.data(), lvl_start.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         set_error("admm_create: %s", hipGetErrorString(e));
         admm_destroy(d);  // frees whatever was allocated
@@ -617,16 +864,65 @@ int admm_create(Code* code, AdmmDecoder** out) {
 }
 
 int admm_last_repacks(const AdmmDecoder* d) { return d ? d->last_repacks : 0; }
+int admm_last_backend(const AdmmDecoder* d) { return d ? d->last_backend : 0; }
 
 void admm_destroy(AdmmDecoder* d) {
     if (!d) return;
     for (DevBuf* b : {&d->z, &d->lam, &d->d1, &d->d2, &d->x, &d->gam, &d->live, &d->flags, &d->part, &d->z2, &d->lam2, &d->x2, &d->gam2, &d->live2, &d->fmap, &d->fmap2,
                       &d->rbase})
         b->release();
-    for (void* q : {(void*)d->d_leaf_off, (void*)d->d_leaf_len, (void*)d->d_prog})
+    for (void* q : {(void*)d->d_leaf_off, (void*)d->d_leaf_len, (void*)d->d_prog, (void*)d->d_lvl_a, (void*)d->d_lvl_b, (void*)d->d_lvl_start, (void*)d->d_ticket})
         if (q) (void)hipFree(q);
     if (d->pinned) (void)hipHostFree(d->pinned);
     delete d;
+}
+
+// LDS-resident path of admm_decode: returns 1 where the code is not eligible (checks of unequal degree, a frame beyond the LDS, a code
+// too small to fill a workgroup -- the streaming kernels serve those), else LDPC_OK / an error.  LDPC_ADMM_BACKEND=stream forces the
+// streaming kernels (A/B and the parity tests of both).
+template <int L, int DVMAX, int VPL, int NW>
+static int admm_launch_lds(const AdmmLdsArgs& a, size_t lds_bytes, int grid, hipStream_t st) {
+    LDPC_HIP_TRY(hipFuncSetAttribute((const void*)k_admm_lds<L, DVMAX, VPL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((k_admm_lds<L, DVMAX, VPL, NW>), dim3(grid), dim3(64 * NW), lds_bytes, st, a);
+    return LDPC_OK;
+}
+
+static int admm_decode_lds(AdmmDecoder* d, const double* gamma, int64_t B, double mu, double eps, int32_t max_iter, double* x_out, int32_t* iters,
+                           uint8_t* converged, hipStream_t st) {
+    const Code* c = d->code;
+    if (const char* e = std::getenv("LDPC_ADMM_BACKEND"))
+        if (std::string(e) == "stream") return 1;
+    if (c->min_dc != c->max_dc || c->max_dc != 6 || c->max_dv > 3 || c->min_dv < 1) return 1;  // built: (3,6)-type codes (every check six edges, variables up to three)
+    const int nw = (c->m + 63) / 64;
+    if (nw != 4 && nw != 8 && nw != 10) return 1;
+    if (c->n > 2 * 64 * nw) return 1;
+    const size_t lds_bytes = ((size_t)5 * c->E + c->n + (size_t)2 * d->leaves * 8 + (size_t)2 * d->nodes) * 8 + 64;
+    if (lds_bytes > (size_t)160 * 1024) return 1;
+    AdmmLdsArgs a;
+    a.gamma = gamma; a.x_out = x_out; a.iters = iters; a.converged = converged;
+    a.col_ptr = c->d_col_ptr; a.col_edge = c->d_col_edge; a.edge_var = c->d_edge_var;
+    a.leaf_off = d->d_leaf_off; a.leaf_len = d->d_leaf_len; a.lvl_a = d->d_lvl_a; a.lvl_b = d->d_lvl_b; a.lvl_start = d->d_lvl_start;
+    a.m = c->m; a.n = c->n; a.E = (int)c->E; a.leaves = d->leaves; a.levels = d->levels; a.nodes = d->nodes;
+    a.B = B; a.mu = mu; a.thresh = (eps * eps) * (double)c->E;
+    a.max_iter = max_iter; a.cap = max_iter > 0 ? max_iter : 100000;
+    a.ticket = d->d_ticket;
+    LDPC_HIP_TRY(hipMemsetAsync(d->d_ticket, 0, 8, st));
+    hipDeviceProp_t prop;
+    LDPC_HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    const int per_cu = std::max(1, (int)((size_t)160 * 1024 / lds_bytes));
+    const int64_t want = (int64_t)prop.multiProcessorCount * per_cu;
+    const int grid = (int)(B < want ? B : want);
+    int rc = LDPC_OK;
+    switch (nw) {
+        case 4: rc = admm_launch_lds<6, 3, 2, 4>(a, lds_bytes, grid, st); break;
+        case 8: rc = admm_launch_lds<6, 3, 2, 8>(a, lds_bytes, grid, st); break;
+        default: rc = admm_launch_lds<6, 3, 2, 10>(a, lds_bytes, grid, st); break;
+    }
+    if (rc) return rc;
+    LDPC_HIP_TRY(hipGetLastError());
+    d->last_repacks = 0;
+    d->last_backend = 1;
+    return LDPC_OK;
 }
 
 int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, double eps, int32_t max_iter, double* x_out, int32_t* iters,
@@ -644,6 +940,11 @@ int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, doubl
         return LDPC_E_ARG;
     }
     LDPC_HIP_TRY(hipSetDevice(c->device));
+    {
+        const int rc = admm_decode_lds(d, gamma, B, mu, eps, max_iter, x_out, iters, converged, st);
+        if (rc != 1) return rc;  // 1: not eligible for the LDS-resident kernel -> the streaming kernels below
+    }
+    d->last_backend = 0;
     const int tiles = (int)((B + 63) / 64);
     const size_t es = (size_t)tiles * E * 64 * sizeof(double), vs = (size_t)tiles * n * 64 * sizeof(double);
     LDPC_TRY(d->z.reserve(es));

@@ -973,6 +973,14 @@ int ldpc_admm_destroy(ldpc_admm_t h) {
     });
 }
 
+int ldpc_admm_last_backend(ldpc_admm_t h, int* backend) {
+    return guarded("ldpc_admm_last_backend", [&]() -> int {
+        if (!h || !backend) return LDPC_E_ARG;
+        *backend = admm_last_backend((AdmmDecoder*)h);
+        return LDPC_OK;
+    });
+}
+
 int ldpc_admm_last_repacks(ldpc_admm_t h, int* repacks) {
     return guarded("ldpc_admm_last_repacks", [&]() -> int {
         if (!h || !repacks) return LDPC_E_ARG;

@@ -182,6 +182,7 @@ struct AdmmDecoder;
 int admm_create(Code* code, AdmmDecoder** out);
 void admm_destroy(AdmmDecoder* d);
 int admm_last_repacks(const AdmmDecoder* d);
+int admm_last_backend(const AdmmDecoder* d);
 int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, double eps, int32_t max_iter, double* x_out, int32_t* iters,
                 uint8_t* converged, hipStream_t st);
 

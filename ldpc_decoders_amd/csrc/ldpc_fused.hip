@@ -489,7 +489,7 @@ int fused_plan_create(Decoder* d) {
             // row of the message of (check row Rg = cs / 64, edge position j): Rg * DC + j; the 16-wave shape interleaves the waves' rows
             // (local row k of wave w at k * NW + w, see fused_bp_body) so that its c2v stores reach most rows without an address register
             const int Rg = cs / 64, jj = edge_pos[k];
-            const int row = BIG ? ((Rg % CRW) * DC + jj) * NW + Rg / CRW : Rg * DC + jj;
+            const int row = (BIG && esz == 4) ? ((Rg % CRW) * DC + jj) * NW + Rg / CRW : Rg * DC + jj;  // (k_fused_bp's 16-wave shape only: the fp64 kernels keep the plain order)
             vn_addr[(size_t)(vr.first_gather(Q) + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(row * 64 + cs % 64) * esz;
         }
     }

@@ -82,6 +82,7 @@ def test_admm_frame_repack_is_bit_transparent(monkeypatch):
     import torch
     from ldpc_decoders_amd._device import AdmmHandle
 
+    monkeypatch.setenv("LDPC_ADMM_BACKEND", "stream")  # the repack belongs to the streaming kernels (the LDS-resident kernel has no tiles)
     rng = np.random.RandomState(9)
     for name, B, snr, max_iter, with_oracle in (("1200_3_6_rand_ldpc_1", 64 * 9 + 5, 2.3, 200, 96), ("1200_rho_x5_rand_ldpc_5", 64 * 6, 2.0, 120, 0),
                                                 ("7_4_hamming", 64 * 40 + 3, 2.0, 100, 64 * 40 + 3)):
@@ -106,6 +107,38 @@ def test_admm_frame_repack_is_bit_transparent(monkeypatch):
         if with_oracle:
             xo, io, co = A.admm_decode(graph_of(name), gamma[:with_oracle], 3.0, 1e-5, max_iter)
             assert np.array_equal(ref[1][:with_oracle], io) and np.array_equal(ref[0][:with_oracle], xo, equal_nan=True)
+
+
+def test_admm_lds_resident_kernel_equals_streaming_kernels_and_oracle(monkeypatch):
+    """The LDS-resident kernel (one workgroup per frame; codes whose checks all have six edges) against the streaming kernels on the same
+    frames -- estimates, iteration counts, convergence flags bit for bit -- and a prefix against the C oracle: frames leaving at every
+    iteration count, frames that run into the cap, max_iter = 1 and an uncapped run, batches that do not fill the chip and that do."""
+    import torch
+    from ldpc_decoders_amd._device import AdmmHandle
+
+    rng = np.random.RandomState(21)
+    for name, B, snr, max_iter, with_oracle in (("1200_3_6_rand_ldpc_1", 777, 2.2, 120, 64), ("512_3_6_rand_ldpc_2", 1500, 2.6, 80, 64),
+                                                ("1200_3_6_rand_ldpc_2", 300, 3.0, 1, 32), ("1200_3_6_rand_ldpc_3", 130, 3.2, -1, 32)):
+        code = _code(name)
+        gamma = -2 * (-1 + rng.normal(0, np.sqrt(10 ** (-snr / 10)), (B, code.n))) / 10 ** (-snr / 10)
+        gd = torch.from_numpy(gamma).cuda()
+        got = {}
+        for mode in ("lds", "stream"):
+            if mode == "stream":
+                monkeypatch.setenv("LDPC_ADMM_BACKEND", "stream")
+            else:
+                monkeypatch.delenv("LDPC_ADMM_BACKEND", raising=False)
+            h = AdmmHandle(code)
+            x, it, cv = h.decode_device(gd, 3.0, 1e-5, max_iter)
+            got[mode] = (x.cpu().numpy(), it.cpu().numpy(), cv.cpu().numpy())
+            assert h.last_backend() == mode
+        assert np.array_equal(got["lds"][1], got["stream"][1]) and np.array_equal(got["lds"][2], got["stream"][2])
+        assert np.array_equal(got["lds"][0], got["stream"][0], equal_nan=True)
+        if max_iter > 1:
+            assert len(np.unique(got["lds"][1])) > 5
+        xo, io, co = A.admm_decode(graph_of(name), gamma[:with_oracle], 3.0, 1e-5, max_iter)
+        assert np.array_equal(got["lds"][1][:with_oracle], io) and np.array_equal(got["lds"][2][:with_oracle], co)
+        assert np.array_equal(got["lds"][0][:with_oracle], xo, equal_nan=True)
 
 
 def _admm_main_cases():

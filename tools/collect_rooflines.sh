@@ -31,6 +31,8 @@ CASES=(
  "c3_spa_bsc_f32|--code 1200_3_6_rand_ldpc_1 --alg SPA --channel bsc --param 0.07 --batch 65536 --precision f32 --launches 3|sq hbm"
  "c3_bec|--code 1200_3_6_rand_ldpc_1 --alg BEC --channel bec --param 0.40 --batch 1048576 --precision f32 --launches 3|sq hbm"
  "c3_spa_biawgn_f64|--code 1200_3_6_rand_ldpc_1 --alg SPA --channel biawgn --param 1.5 --batch 65536 --precision f64 --launches 2|sq hbm"
+ "f_admm|--code 1200_3_6_rand_ldpc_1 --alg ADMM --channel biawgn --param 2.2 --batch 8192 --precision f64 --max-iter 300 --launches 2 --warm 2|sq"
+ "f_ml|--code 7_4_hamming --alg ML --channel biawgn --param 2.0 --batch 16777216 --precision f32 --max-iter 0 --launches 3 --warm 2|sq"
  "c4_f32|--code gen:irg:10000 --alg MSA --channel biawgn --param 1.2 --batch 16384 --precision f32 --launches 2|sq hbm"
  "c4_stream_f32|--code gen:irg:10000 --alg MSA --channel biawgn --param 1.2 --batch 8192 --precision f32 --backend stream --launches 1 --warm 1|hbm"
  "c4_stream_f64|--code gen:irg:10000 --alg MSA --channel biawgn --param 1.2 --batch 8192 --precision f64 --backend stream --launches 1 --warm 1|hbm"

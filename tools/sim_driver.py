@@ -19,6 +19,7 @@ import torch  # noqa: E402
 from bench import load_code  # noqa: E402
 from ldpc_decoders_amd import _lib  # noqa: E402
 from ldpc_decoders_amd._device import DecoderHandle  # noqa: E402
+from bench import AuxHandle  # noqa: E402  (ADMM / ML: the adapter bench.py times)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--code", default="1200_3_6_rand_ldpc_1")
@@ -37,8 +38,9 @@ ap.add_argument("--calib", action="store_true", help="also run the known 1 GiB -
 a = ap.parse_args()
 
 code = load_code(a.code)
-h = DecoderHandle(code, a.alg, a.precision, a.backend)
-bins = a.max_iter + 1
+aux = a.alg in ("ADMM", "ML")
+h = AuxHandle(code, a.alg, a.precision, a.channel) if aux else DecoderHandle(code, a.alg, a.precision, a.backend)
+bins = min(a.max_iter + 1, 60) if aux else a.max_iter + 1
 flags = _lib.flag_prior_grid(a.prior_grid) if a.prior_grid is not None else 0
 cnt = torch.zeros(4 + bins, dtype=torch.int64, device="cuda")
 for w in range(max(1, a.warm)):  # warm-up: workspaces are allocated by the first launch, the clocks come up over the next ones
@@ -57,14 +59,16 @@ if a.calib:
     torch.cuda.synchronize()
 c = cnt.cpu().numpy()
 backend = h.last_stats()[0]
-kname = (h.kernel_name(True) if hasattr(_lib.load(), "ldpc_decoder_kernel_name") else "?") if backend == "fused" else ""
+kname = (h.kernel_name(True) if hasattr(_lib.load(), "ldpc_decoder_kernel_name") else "?") if backend == "fused" else (h.kernel_name(True) if aux else "")
 if a.prior_grid is not None:  # the guarded sibling of that kernel (min-sum only: one template argument less)
     kname = kname.replace("k_fused_bp<0, ", "k_fused_bp_grid<")
 info = dict(code=a.code, n=code.n, m=code.m, E=code.E, alg=a.alg, channel=a.channel, param=a.param, batch=a.batch, precision=a.precision,
             max_iter=a.max_iter, backend=backend, kernel=kname, launches=a.launches, warm_launches=max(1, a.warm),
-            frames=int(c[0]), frame_sweeps=int(c[3]), mean_sweeps=float(c[3]) / max(int(c[0]), 1), wer=float(c[1]) / max(int(c[0]), 1),
+            frames=int(c[0]), mean_sweeps=float(c[3]) / max(int(c[0]), 1), wer=float(c[1]) / max(int(c[0]), 1),
+            # unit of work the counters are divided by: frame-sweeps (BP), frame-ITERATIONS incl. the one that meets the test (ADMM), frames (ML)
+            frame_sweeps=int(c[3]) + int(c[0]) if a.alg == "ADMM" else (int(c[0]) if a.alg == "ML" else int(c[3])),
             ms_per_launch_wall=dt * 1e3, frames_per_s_wall=a.batch / dt, cus=torch.cuda.get_device_properties(0).multi_processor_count,
-            repacks_last=h.last_repacks(), device=torch.cuda.get_device_name(0))
+            repacks_last=0 if aux else h.last_repacks(), device=torch.cuda.get_device_name(0))
 print(json.dumps(info))
 if a.info:
     json.dump(info, open(a.info, "w"))

@@ -148,13 +148,14 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
                 ld, st_, at = t4.get("SQ_INSTS_LDS_LOAD", 0.0), t4.get("SQ_INSTS_LDS_STORE", 0.0), t4.get("SQ_INSTS_LDS_ATOMIC", 0.0)
                 # per-instruction cycles on the issue / transfer path by kernel family: (read, row store, note)
                 fam = ("k_fused_f64", 2.0, 6.0, "ds_read_b64 2, ds_write_b64 6") if k.startswith("k_fused_f64") else \
+                      ("k_admm_lds", 2.0, 6.0, "ds_read_b64 2, ds_write_b64 6") if k.startswith("k_admm_lds") else \
                       ("k_fused_becs", 2.0, 6.0, "ds_read_b64 2, ds_write_b64 6") if k.startswith("k_fused_becs") else \
                       ("k_fused_bp 16-wave", 2.0, 3.0, "ds_read_b32 2, ds_write2st64_b32 6 per two rows / addtid 2") if ", 16, " in k else \
                       ("k_fused_bp", 2.0, 2.0, "ds_read_b32 2, ds_write_addtid_b32 2")
                 path = ld * fam[1] + st_ * fam[2] + at * 8.0
                 # the same split with the constants MEASURED on this chip for 8-byte elements (profiles/r04_lds_store_path.txt: ds_read_b64 2.55,
                 # ds_write_b64 6.3 cycles per wave-instruction per CU, ds_add_f64 8.07; a 2-load + 1-store mix runs at their sum: the path is additive)
-                if fam[0] in ("k_fused_f64", "k_fused_becs"):
+                if fam[0] in ("k_fused_f64", "k_fused_becs", "k_admm_lds"):
                     e["lds_path_cycles_per_frame_sweep_measured_constants"] = round(ld * 2.55 + st_ * 6.3 + at * 8.07, 1)
                     e["lds_path_measured_constants"] = "ds_read_b64 2.55, ds_write_b64 6.3"
                 elif fam[0] == "k_fused_bp":  # 4-byte elements: ds_read_b32 2.88, ds_write_addtid_b32 2.2 (third run of the same file)
