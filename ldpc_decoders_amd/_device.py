@@ -301,13 +301,6 @@ class DecoderHandle:
         _lib.check(_lib.load().ldpc_decoder_grid_violations(self.h, ctypes.byref(c), frames.ctypes.data, len(frames), 1 if reset else 0))
         return c.value, frames[:min(c.value, len(frames))].copy()
 
-    def twin(self):
-        """A second decoder of the same kind (own workspace, own frame dispensers): lets the Monte-Carlo driver keep two rounds on two
-        HIP streams, so that the tail of one launch -- CUs idling while the last frames finish -- overlaps the head of the next."""
-        if getattr(self, "_twin", None) is None:
-            self._twin = DecoderHandle(self.code, self.alg, self.precision, self.backend, self.code_handle.device)
-        return self._twin
-
     def _fp64_sibling(self):
         """The same decoder in the reference's own arithmetic: re-decodes the few frames the exactness guard sets aside."""
         if getattr(self, "_sib64", None) is None:

@@ -986,9 +986,7 @@ int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, doubl
     int done = 0;
     for (int it = 0; it < cap; ++it) {
         hipLaunchKernelGGL(k_admm_x, dim3(gv, cur_tiles), dim3(256), 0, st, c->d_col_ptr, c->d_col_edge, z, lam, gam, x, live, n, E, cur_tiles, mu);
-        static const bool lds_arrays = !(std::getenv("LDPC_ADMM_REGARR") && std::getenv("LDPC_ADMM_REGARR")[0] == '1');
-        static const bool fixed_ok = !(std::getenv("LDPC_ADMM_FIXED") && std::getenv("LDPC_ADMM_FIXED")[0] == '0');
-        const int Lfix = (fixed_ok && c->min_dc == c->max_dc && c->max_dc >= 2 && c->max_dc <= 8) ? c->max_dc : 0;
+        const int Lfix = (c->min_dc == c->max_dc && c->max_dc >= 2 && c->max_dc <= 8) ? c->max_dc : 0;
         if (Lfix) {  // every check has the same degree: the register-only projection
 #define LDPC_ADMM_FIXED_CASE(LL) \
     case LL: hipLaunchKernelGGL((k_admm_z_fixed<LL>), dim3(gc, cur_tiles), dim3(256), 0, st, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu); break;
@@ -997,11 +995,9 @@ int admm_decode(AdmmDecoder* d, const double* gamma, int64_t B, double mu, doubl
                 LDPC_ADMM_FIXED_CASE(6) LDPC_ADMM_FIXED_CASE(7) LDPC_ADMM_FIXED_CASE(8)
             }
 #undef LDPC_ADMM_FIXED_CASE
-        } else if (c->max_dc <= 8 && lds_arrays) {
+        } else if (c->max_dc <= 8) {  // unequal check degrees: the projection's work arrays in the LDS (data-dependent indices)
             const unsigned gcl = (unsigned)((m + 1) / 2 < 1024 ? (m + 1) / 2 : 1024);
             hipLaunchKernelGGL((k_admm_z<8, true>), dim3(gcl, cur_tiles), dim3(128), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
-        } else if (c->max_dc <= 8) {
-            hipLaunchKernelGGL((k_admm_z<8, false>), dim3(gc, cur_tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
         } else {
             hipLaunchKernelGGL((k_admm_z<16, false>), dim3(gc, cur_tiles), dim3(256), 0, st, c->d_row_ptr, c->d_edge_var, z, lam, x, d1, d2, live, m, n, E, mu);
         }

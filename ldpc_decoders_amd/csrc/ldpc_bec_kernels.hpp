@@ -87,11 +87,7 @@ struct BecShape {
     static constexpr uint32_t SUM_BASE = (uint32_t)NW * VNK * 512u, SYS_BASE = SUM_BASE + (uint32_t)CR * 512u;
     // the variable's own last outgoing messages stay in registers where the budget allows, else they are re-read from its rows
     // (lane-contiguous, 2 LDS cycles a row): the Monte-Carlo kernel of the four-wave shape would spill 19 registers with them
-#ifdef LDPC_BEC_OWN_REGS_MC
-    static constexpr bool OWN_REGS = VNK <= 16;
-#else
     static constexpr bool OWN_REGS = VNK <= 16 && !MC_;
-#endif
     static constexpr int NOWN = OWN_REGS ? VNK : 1;
     static_assert(CR <= CRW * NW, "check rows fit the waves");
     static_assert(VR <= NW * VNK, "staging area fits the v2c rows");

@@ -71,7 +71,6 @@ __device__ __forceinline__ void cn_msa(T (&v)[DCMAX], int deg) {
 // case at its measured 100 % (a numpy model of these functions keeps all 2 770 golden frames: tests/test_spa64_functions_cpu.py); in a
 // Monte-Carlo run one frame of 131 072 changes its word-error status against the library-function build.  The whole rule is BRANCH-FREE
 // on purpose (NaN by arithmetic, selects after an empty asm on their operands): exec-mask regions keep a row's six edges from interleaving.
-#ifndef LDPC_SPA_F64_LIBRARY_FUNCTIONS  // define to get the device library's functions back (A/B, tools/build_variant.sh)
 __device__ __forceinline__ double spa64_nan() { return __builtin_nan(""); }
 // tanh(x / 2) with em = expm1(|x|), r = 1 / (em + 2):  1 - 2 r for |x| > 1/2 -- ONE rounding of an exactly representable 1 minus a tiny,
 // accurately known term: correctly rounded wherever the saturation artefacts live (the row product is compared with +-1 for EQUALITY
@@ -152,11 +151,6 @@ __device__ __forceinline__ double spa64_atanh(double q) {
     t = (a <= 1.0) ? t : spa64_nan();  // |q| > 1 or NaN (|q| == 1 is taken out by the caller)
     return __builtin_copysign(t, q);
 }
-#else
-__device__ __forceinline__ double spa64_tanh_half(double x) { return tanh(x / 2.0); }
-__device__ __forceinline__ double spa64_log(double t) { return log(t); }
-__device__ __forceinline__ double spa64_atanh(double q) { return atanh(q); }
-#endif
 template <int DCMAX>
 __device__ __forceinline__ void cn_spa(double (&v)[DCMAX], int deg) {
     double t[DCMAX];
@@ -175,13 +169,9 @@ __device__ __forceinline__ void cn_spa(double (&v)[DCMAX], int deg) {
     for (int j = 0; j < DCMAX; ++j) {
         if (j < deg) {
             const double q = prod / t[j];
-#ifndef LDPC_SPA_F64_LIBRARY_FUNCTIONS
             double at = spa64_atanh(q);  // at |q| == 1 its value is discarded (2 / 0 = inf inside: no trap, no NaN test on it)
             asm volatile("" : "+v"(at));
             v[j] = 2.0 * ((fabs(q) == 1.0) ? (__builtin_huge_val() * q) : at);
-#else
-            v[j] = 2.0 * ((fabs(q) == 1.0) ? (__builtin_huge_val() * q) : spa64_atanh(q));
-#endif
         }
     }
 }

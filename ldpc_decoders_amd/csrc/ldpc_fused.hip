@@ -390,7 +390,6 @@ static int becs_build_plan(Decoder* d, FusedPlan* p, const ShapeEntry& shape, co
     p->num_cu = prop.multiProcessorCount;
     const int by_lds = (int)((size_t)160 * 1024 / p->lds_bytes);
     int cap = 8;
-    if (const char* wenv = std::getenv("LDPC_FUSED_WAVES")) cap = atoi(wenv) > 0 ? atoi(wenv) : cap;
     p->groups_per_cu = by_lds < cap ? by_lds : cap;
     LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
     LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel_sim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
@@ -540,30 +539,6 @@ int fused_plan_create(Decoder* d) {
     }
     fill_padding(cn_addr, 0);
     fill_padding(vn_addr, c2v_base);
-    if (std::getenv("LDPC_FUSED_DEBUG")) {
-        // bank-conflict cycles of the FINAL gather tables (padding included), by the model of MI355X_MICROARCH.md: a wave64 gather is served
-        // in two half-waves; within one, every extra distinct address on a bank costs a cycle (4-byte reads: 32 banks, 8-byte: 64)
-        auto table_conflicts = [&](const std::vector<int64_t>& addr) {
-            long extra = 0;
-            const int banks = esz == 8 ? 64 : 32;
-            for (size_t g0 = 0; g0 + 32 <= addr.size(); g0 += 32) {
-                int worst = 1;
-                for (int b = 0; b < banks; ++b) {
-                    std::vector<int64_t> seen;
-                    for (int l = 0; l < 32; ++l) {
-                        const int64_t a = addr[g0 + l];
-                        if ((int)((a / 4) % banks) != b && !(esz == 8 && (int)((a / 4 + 1) % banks) == b)) continue;
-                        if (std::find(seen.begin(), seen.end(), a) == seen.end()) seen.push_back(a);
-                    }
-                    worst = std::max(worst, (int)seen.size());
-                }
-                extra += worst - 1;
-            }
-            return extra;
-        };
-        fprintf(stderr, "ldpc fused tables: conflict cycles per sweep: check-phase gathers %ld, variable-phase gathers %ld (planner: %g)\n",
-                table_conflicts(cn_addr), table_conflicts(vn_addr), L.extra_cycles_planned);
-    }
     for (int K = 0; K < CR * DC; ++K)
         for (int lane = 0; lane < 64; ++lane) put16(cn_tab, CNW, CRW * DC, K, lane, (uint32_t)(cn_addr[(size_t)K * 64 + lane] >> tab_shift));
     for (int K = 0; K < vr.total_gathers(); ++K)
@@ -605,7 +580,6 @@ int fused_plan_create(Decoder* d) {
     // resident frames per CU (waves: NW x that): 8 for the n = 1200 shapes (LDS-bound anyway); the small one-wave shape
     // (n <= 512, 8 KB of LDS, built for 128 VGPRs) runs 16 -- measured +13 % on 512_3_6_rand_ldpc_2
     int cap = (NW == 1 && CRW <= 4) ? 16 : 8;
-    if (const char* wenv = std::getenv("LDPC_FUSED_WAVES")) cap = atoi(wenv) > 0 ? atoi(wenv) : cap;  // experiment knob
     p->groups_per_cu = by_lds < cap ? by_lds : cap;
     LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
     if (shape.kernel_sim) LDPC_HIP_TRY(hipFuncSetAttribute(shape.kernel_sim, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));

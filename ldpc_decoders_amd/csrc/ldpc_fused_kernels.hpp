@@ -144,12 +144,8 @@ __device__ __forceinline__ float gat_tab(const unsigned char* base, const uint32
 template <int R0, int R1>
 __device__ __forceinline__ void lds_st2_rows(uint32_t vaddr, float a, float b) {
     static_assert(R0 >= 0 && R0 < 256 && R1 >= 0 && R1 < 256, "8-bit row offsets");
-#ifdef LDPC_BIG_UNPAIRED_STORES  // A/B (profiles/r04_big_store_pairing.txt): the same two rows as two ds_write_b32 -- 4 + 4 store-path cycles instead of 6
-    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vaddr), "v"(a), "n"(R0 * 256) : "memory");
-    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(vaddr), "v"(b), "n"(R1 * 256) : "memory");
-#else
+    // (the same two rows as two ds_write_b32 -- 4 + 4 store-path cycles instead of 6 -- measured 12 % slower: profiles/r04_big_store_pairing.txt)
     asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(vaddr), "v"(a), "v"(b), "n"(R0), "n"(R1) : "memory");
-#endif
 }
 
 template <int OFF>
@@ -220,10 +216,6 @@ constexpr int GRID_REDO_CAP = 4095;
 // sweep loop, or table entries that are reloaded from scratch in every sweep.  An opaque word keeps its two unpacking instructions
 // in the sweep instead.  Counts found by compiling each shape over a grid of values (tools/kernel_resources.py; the CPU test
 // tests/test_host_cpu.py::test_simulate_kernels_do_not_spill pins the result): the smallest counts with no spilled register.
-#ifdef LDPC_SIM_OPAQUE_CN_WORDS  // experiments: one pair of values for every shape
-constexpr int sim_opaque_cn(int, int, int) { return LDPC_SIM_OPAQUE_CN_WORDS; }
-constexpr int sim_opaque_vn(int, int, int) { return LDPC_SIM_OPAQUE_VN_WORDS; }
-#else
 constexpr int sim_opaque_cn(int alg, int nw, int vrx) {
     if (nw > 4) return alg == ALG_MSA ? 0 : 15;           // one frame per CU (16 waves): min-sum by the compiler's own allocation (see MAD in the kernel)
     if (vrx == 0) return alg == ALG_MSA ? 0 : 6;          // regular shapes: min-sum 0 + 2; sum-product 6 + 8 (round 5: the pair-tree rule needs
@@ -235,21 +227,12 @@ constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
     if (vrx == 0) return alg == ALG_SPA ? 8 : 2;
     return alg == ALG_MSA ? 8 : 15;
 }
-#endif
 // the guarded (exact-in-fp32) variants carry one more live register (the guard's running maximum): more table words stay packed
-#ifndef LDPC_GRID_OPAQUE_CN
-#define LDPC_GRID_OPAQUE_CN 15
-#define LDPC_GRID_OPAQUE_VN 15
-#endif
 // (measured, round 5, tools/ab_grid2.sh / ab_grid.sh: the regular two-wave shape of n = 1200 -- whose guard no longer watches marginals --
 // is fastest with the plain kernel's own 0 + 2 packed words: 3.00-3.04 ms per 65 536 frames against 3.17 (8 + 8) and 3.33 (15 + 15); the
 // irregular and the 16-wave shapes are fastest with all of them packed)
-#ifndef LDPC_GRID2_OPAQUE_CN
-#define LDPC_GRID2_OPAQUE_CN 0
-#define LDPC_GRID2_OPAQUE_VN 2
-#endif
-constexpr int grid_opaque_cn(int nw, int vrx) { return (nw == 2 && vrx == 0) ? LDPC_GRID2_OPAQUE_CN : LDPC_GRID_OPAQUE_CN; }
-constexpr int grid_opaque_vn(int nw, int vrx) { return (nw == 2 && vrx == 0) ? LDPC_GRID2_OPAQUE_VN : LDPC_GRID_OPAQUE_VN; }
+constexpr int grid_opaque_cn(int nw, int vrx) { return (nw == 2 && vrx == 0) ? 0 : 15; }
+constexpr int grid_opaque_vn(int nw, int vrx) { return (nw == 2 && vrx == 0) ? 2 : 15; }
 constexpr int SIM_ACC_LANE0 = 60;  // hist_bins <= 60 (fused_simulate_supported)
 __device__ __forceinline__ void sim_count(unsigned& accv, int lane, int err, int it, int hist_bins) {
     const int bin = it < hist_bins ? it : hist_bins - 1;  // no histogram: -1, no lane
@@ -1083,14 +1066,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                 if (max_iter > 0 && it >= max_iter) break;
                 if constexpr (NW == 4) {  // 128 VGPRs: the packed tables stay packed (unpacked once per use); hoisted out of the loop, the
                                           // unpacked addresses would be spilled and re-read from scratch in every sweep
-#ifndef LDPC_F64_OPAQUE_CN  // how many table words stay packed: every check-phase word, six of the eight variable-phase words -- the most the
-#define LDPC_F64_OPAQUE_CN 64  // 128 registers take unpacked without a spill (round 5, tools/ab_sim.sh c2_f64: 5.48-5.52 ms per 65 536 frames against
-#define LDPC_F64_OPAQUE_VN 6   // 5.53-5.56 with all of them packed; nothing packed: 5.45-5.48 with 17 spilled registers)
-#endif
+                    // how many table words stay packed: every check-phase word, six of the eight variable-phase words -- the most the 128 registers
+                    // take unpacked without a spill (round 5, tools/ab_sim.sh c2_f64: 5.48-5.52 ms per 65 536 frames against 5.53-5.56 with all of
+                    // them packed; nothing packed: 5.45-5.48 with 17 spilled registers)
 #pragma unroll
-                    for (int i = 0; i < CNW && i < LDPC_F64_OPAQUE_CN; ++i) asm volatile("" : "+v"(cn_idx[i]));
+                    for (int i = 0; i < CNW; ++i) asm volatile("" : "+v"(cn_idx[i]));
 #pragma unroll
-                    for (int i = 0; i < VNW && i < LDPC_F64_OPAQUE_VN; ++i) asm volatile("" : "+v"(vn_idx[i]));
+                    for (int i = 0; i < VNW && i < 6; ++i) asm volatile("" : "+v"(vn_idx[i]));
                 }
                 // ---- check phase (+ syndrome of the previous decisions: sign of the gathered marginals)
                 uint32_t synd = 0;   // min-sum: bit 31 = some owned check is unsatisfied (XOR of IEEE sign bits)
@@ -1180,11 +1162,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                 };
                 check_rows(std::integral_constant<int, CRW>{});
                 // narrow variable rounds, VG of them per pipeline stage (see the variable phase below)
-#ifdef LDPC_F64_NW4_VG  // experiment: variable rounds per pipeline stage of the four-wave shape
-                constexpr int VG = ALG == ALG_MSA ? (NW == 4 ? LDPC_F64_NW4_VG : 3) : 1;
-#else
                 constexpr int VG = ALG == ALG_MSA ? 3 : 1;
-#endif
                 constexpr int NVG = (VRN + VG - 1) / VG;
                 constexpr bool EARLY_GATHERS = NW > 1 && VRX == 0 && ALG == ALG_MSA;
                 double cv[2][VG][DV];

@@ -10,9 +10,6 @@ const ShapeEntry* fused_shapes_bec(int* count) {
         shape_entry_becs<6, 3, 3, 5, 4>(),          // (3,6)-regular, n <= 1248: four waves per slab, 36 KB of LDS -> 4 slabs = 128 frames per CU
         shape_entry_becs<6, 3, 5, 10, 2>(),         // the two-wave sibling (LDPC_FUSED_NW=2)
         shape_entry_becs<6, 3, 5, 10, 2, 2, 8>(),   // irregular n <= 1215 (check degrees <= 6, variable degrees <= 8)
-#ifdef LDPC_BEC_NW8_PROBE
-        shape_entry_becs<6, 3, 2, 3, 8>(),          // experiment: eight waves per slab for n <= 1504 (LDPC_FUSED_NW=8)
-#endif
         shape_entry_becs<6, 3, 3, 6, 8>(),          // (3,6)-regular n <= 3008 (Margulis n = 2640): one slab per CU
         shape_entry_becs<4, 3, 8, 10, 2>(),         // (3,4)-regular
         shape_entry_becs<8, 4, 5, 10, 2>(),         // (4,8)-regular

@@ -270,8 +270,6 @@ void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint6
     // ---- annealing: one chain; the schedule is a function of the move count only, so a plan depends on (code, shape, seed, moves)
     // and not on the machine it was computed on.  (Independent or best-state-sharing replicas on several host threads were
     // measured: 8 x 2.5 M moves end where ONE chain of 2.5 M moves ends -- the result is set by the length of the chain.)
-    const auto t_start = std::chrono::steady_clock::now();
-    auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     const long max_moves = moves < 1 ? 1 : moves;
     Anneal chain(c, DC, CR, vr, *L, &edge_vj);
     Anneal champion = chain;
@@ -279,7 +277,6 @@ void plan_fused_layout(const Code& c, int DC, int CR, const VarRounds& vr, uint6
     chain.run(rng, 0, max_moves, max_moves, &champion);
     const std::vector<int>&cgrp = champion.cgrp, &cbank = champion.cbank, &vgrp = champion.vgrp, &vbank = champion.vbank;
     auto vpos = [&](int v, int j) { return champion.vpos(v, j); };
-    if (std::getenv("LDPC_PLAN_DEBUG")) fprintf(stderr, "[plan] annealing: surrogate cost %ld after %.2fs\n", champion.cost, elapsed());
 
     for (int cc = 0; cc < m; ++cc) L->chk_slot[cc] = slot_of(cgrp[cc], cbank[cc]);
     for (int v = 0; v < n; ++v) L->var_slot[v] = slot_of(vgrp[v], vbank[v]);

@@ -44,18 +44,7 @@ using u64 = unsigned long long;
 // streaming (non-temporal) access, selectable per pass and per direction (measured): the check pass streams
 // its c2v lines through with non-temporal loads AND stores so that they do not push the marginal lines (re-used dv times) out of
 // the caches
-#ifndef LDPC_CN_NTL
-#define LDPC_CN_NTL 1
-#endif
-#ifndef LDPC_CN_NTS
-#define LDPC_CN_NTS 1
-#endif
-#ifndef LDPC_VN_NTL
-#define LDPC_VN_NTL 0
-#endif
-#ifndef LDPC_VN_NTS
-#define LDPC_VN_NTS 0
-#endif
+constexpr bool CN_NTL = true, CN_NTS = true, VN_NTL = false, VN_NTS = false;
 template <bool NT, typename T> __device__ __forceinline__ T msg_ld(const T* p) {
     if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
 }
@@ -247,7 +236,7 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
                     for (int j = 0; j < DCMAX; ++j) {
                         const int kk = FIXED_DC > 0 ? k0[u] + j : (deg[u] > 0 ? k0[u] + (j < deg[u] ? j : deg[u] - 1) : 0);
                         v[u][j] = st[(int64_t)edge_var[kk] * 64];
-                        if (!first) o[u][j] = msg_ld<LDPC_CN_NTL != 0>(ci + (int64_t)kk * 64);
+                        if (!first) o[u][j] = msg_ld<CN_NTL>(ci + (int64_t)kk * 64);
                     }
                 }
             } else {
@@ -257,7 +246,7 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
                     for (int j = 0; j < DCMAX; ++j) {
                         if (j < deg[u]) {
                             v[u][j] = st[(int64_t)edge_var[k0[u] + j] * 64];
-                            if (!first) o[u][j] = msg_ld<LDPC_CN_NTL != 0>(ci + (int64_t)(k0[u] + j) * 64);
+                            if (!first) o[u][j] = msg_ld<CN_NTL>(ci + (int64_t)(k0[u] + j) * 64);
                         }
                     }
                 }
@@ -271,7 +260,7 @@ __global__ __launch_bounds__(256) void k_cn(const int32_t* __restrict__ row_ptr,
                 cn_rule<T, ALG, DCMAX>(v[u], deg[u]);
 #pragma unroll
                 for (int j = 0; j < DCMAX; ++j) {
-                    if (j < deg[u]) msg_st<LDPC_CN_NTS != 0>(ct + (int64_t)(k0[u] + j) * 64, v[u][j]);
+                    if (j < deg[u]) msg_st<CN_NTS>(ct + (int64_t)(k0[u] + j) * 64, v[u][j]);
                 }
             }
         }
@@ -335,12 +324,12 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
                 if constexpr (FIXED_DV > 0) {
                     pr[u] = pt[(int64_t)(vbase + u < v_end ? vbase + u : v_end - 1) * 64];
 #pragma unroll
-                    for (int j = 0; j < FIXED_DV; ++j) c[u][j] = msg_ld<LDPC_VN_NTL != 0>(ct + (int64_t)col_edge[p0[u] + j] * 64);
+                    for (int j = 0; j < FIXED_DV; ++j) c[u][j] = msg_ld<VN_NTL>(ct + (int64_t)col_edge[p0[u] + j] * 64);
                 } else {
                     if (deg[u] >= 0) pr[u] = pt[(int64_t)(vbase + u) * 64];
 #pragma unroll
                     for (int j = 0; j < DVMAX; ++j) {
-                        if (j < deg[u]) c[u][j] = msg_ld<LDPC_VN_NTL != 0>(ct + (int64_t)col_edge[p0[u] + j] * 64);
+                        if (j < deg[u]) c[u][j] = msg_ld<VN_NTL>(ct + (int64_t)col_edge[p0[u] + j] * 64);
                     }
                 }
             }
@@ -356,7 +345,7 @@ __global__ __launch_bounds__(256) void k_vn(const int32_t* __restrict__ col_ptr,
                 for (int j = 0; j < DVMAX; ++j)
                     if (j < du) s += c[u][j];
                 const T marg = pr[u] + s;
-                msg_st<LDPC_VN_NTS != 0>(mt + (int64_t)(vbase + u) * 64, marg);
+                msg_st<VN_NTS>(mt + (int64_t)(vbase + u) * 64, marg);
                 if constexpr (GATHER) po[(int64_t)(vbase + u) * 64] = pr[u];
                 b_one = marg < T(0);  // NaN marginal -> 0 (src/bpa.py:38,62)
             }
@@ -566,15 +555,9 @@ int pick_pow2_ge(int x, int lo, int hi) {
 }
 
 // nodes kept in flight per wave: about 32 VGPRs (128 bytes per lane) of messages, at most 4 nodes
-#ifndef LDPC_STREAM_UNR_BYTES
-#define LDPC_STREAM_UNR_BYTES 128
-#endif
-#ifndef LDPC_STREAM_UNR_MAX
-#define LDPC_STREAM_UNR_MAX 4
-#endif
 constexpr int unroll_for(int row_bytes) {
-    int u = LDPC_STREAM_UNR_BYTES / row_bytes;
-    u = u > LDPC_STREAM_UNR_MAX ? LDPC_STREAM_UNR_MAX : u;
+    int u = 128 / row_bytes;
+    u = u > 4 ? 4 : u;
     return u >= 8 ? 8 : (u >= 4 ? 4 : (u >= 2 ? 2 : 1));
 }
 
@@ -748,15 +731,15 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
         while ((long)((nodes + v - 1) / v) * tiles > (1L << 22) && v < 256) v *= 2;
         return (int)(v > nodes ? ((nodes + 3) / 4 * 4) : v);
     };
-    g.cpw = per_wave(m, env_int("LDPC_STREAM_CPW", 4));
+    g.cpw = per_wave(m, 4);
     g.cn_chunks = (m + g.cpw - 1) / g.cpw;
-    g.vpw = per_wave(n, env_int("LDPC_STREAM_VPW", 16));
+    g.vpw = per_wave(n, 16);
     g.vn_chunks = (n + g.vpw - 1) / g.vpw;
     // XCD-aware task order (task_of) where a tile's marginal rows fit one XCD's 4 MB L2: measured (profiles/r03_stream_xcd.txt) the check
     // pass then fetches E + n lines per tile -- its compulsory minimum -- instead of ~2E (n = 1200: 1.78 -> 1.24 GB per launch of 65 536
     // frames, n = 10 000: 3.63 -> 2.68 GB), at unchanged time (the re-reads were being served by the Infinity Cache); at n = 64 800
     // (16.6 MB of marginals per tile) nothing is re-used either way and the plain order is 2.5 % faster
-    g.xcd_aware = env_int("LDPC_STREAM_XCD", (size_t)n * 64 * sizeof(T) <= ((size_t)4 << 20) ? 1 : 0);
+    g.xcd_aware = (size_t)n * 64 * sizeof(T) <= ((size_t)4 << 20) ? 1 : 0;
 
     hipEvent_t e_begin = nullptr, e_end = nullptr;
     if (d->profile) {
@@ -787,12 +770,6 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
     DevBuf* set_xbits[2] = {&d->xbits, &d->xbits2};
     DevBuf* set_live[2] = {&d->live, &d->live2};
     DevBuf* set_fmap[2] = {&d->fmap, &d->fmap2};
-    const bool rent_policy = [] {
-        const char* e = std::getenv("LDPC_STREAM_REPACK_POLICY");
-        return e && std::string(e) == "rent";
-    }();
-    double rent_waste = 0.0;
-    int rent_last_it = 0;
     int cur = 0;                 // which buffer set holds the state
     int32_t* fmap = nullptr;     // frame index of (tile, lane); null = identity (never repacked)
     int cur_tiles = tiles;
@@ -847,22 +824,11 @@ int run(Decoder* d, const void* priors_v, const uint8_t* y0, int64_t B, int32_t 
                         sweeps = pp.sweeps;
                         break;
                     }
-                    // When to repack.  Default: the live frames fill at most `repack_fill` (0.75) of the live tiles.
-                    // LDPC_STREAM_REPACK_POLICY=rent selects "rent or buy" instead -- repack as soon as the tile-sweeps spent on departed
-                    // lanes since the last repack have reached what a repack would cost now (measured: about 0.95 sweep-equivalents per
-                    // tile of the mean of source and destination tiles) -- within a factor two of the best schedule for any departure
-                    // curve.  Measured round 5 (tools/ab_repack_policy.sh, two boxes): it skips the repack at 59 % fill of the n = 64 800
-                    // batch at 2 dB (4 repacks instead of 5) for -1.2 % ... +-0 step time, n = 10 000 fp64 -0.4 ... -0.7 %, fp32 +-0:
-                    // inside the run-to-run spread, so the threshold rule stays the default.
-                    bool want_repack = (double)lf <= repack_fill * 64.0 * lt;
-                    if (rent_policy) {
-                        const int ntr = (lf + 63) / 64;
-                        rent_waste += (double)(lt - ntr) * (double)(pp.it - rent_last_it);
-                        rent_last_it = pp.it;
-                        want_repack = ntr < lt && rent_waste >= 0.95 * 0.5 * (double)(lt + ntr);
-                    }
+                    // When to repack: the live frames fill at most `repack_fill` (0.75) of the live tiles.  (A "rent or buy" schedule -- repack once
+                    // the tile-sweeps spent on departed lanes reach the cost of a repack -- was measured within the run-to-run spread of this
+                    // rule in round 5 and removed in round 6: HISTORY.md.)
+                    const bool want_repack = (double)lf <= repack_fill * 64.0 * lt;
                     if (repack_ok && pp.tiling_current && pp.it > 0 && lt >= 2 && want_repack && it + 1 < cap) {
-                        rent_waste = 0.0;
                         const int nt = (lf + 63) / 64;
                         const int nx = 1 - cur;
                         // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs later)
@@ -1235,9 +1201,6 @@ __global__ __launch_bounds__(256) void k_repack16(const __half2* __restrict__ v2
     }
 }
 
-#ifndef LDPC_CN16_UNR
-#define LDPC_CN16_UNR 2
-#endif
 template <int ALG>
 int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t max_iter, uint32_t flags_in, uint8_t* xhat, int32_t* iters,
           float* soft_out, hipStream_t st, const SimSource* sim) {
@@ -1307,14 +1270,7 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
     DevBuf* set_fmap[2] = {&d->fmap, &d->fmap2};
     int32_t* fmap = nullptr;  // frame of (tile, lane); null = identity (never repacked)
     int cur = 0, repacks = 0;
-    const bool rent_policy = [] {
-        const char* e = std::getenv("LDPC_STREAM_REPACK_POLICY");
-        return e && std::string(e) == "rent";
-    }();
-    double rent_waste = 0.0;
-    int rent_last_it = 0;
-
-    const int cpw = env_int("LDPC_STREAM_CPW", 4), vpw = env_int("LDPC_STREAM_VPW", 16);
+    const int cpw = 4, vpw = 16;
     const int cn_chunks = (m + cpw - 1) / cpw, vn_chunks = (n + vpw - 1) / vpw;
     const int cap = max_iter > 0 ? max_iter : 100000;
     // the live counters are read (synchronously) every fourth sweep; every sweep where a sweep is more than ~1.5 ms of streaming work
@@ -1346,15 +1302,8 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
                     all_left = true;
                     break;
                 }
-                bool want_repack = (double)lf <= repack_fill * 64.0 * lt;
-                if (rent_policy) {  // rent or buy, as in run<T>()
-                    const int ntr = (lf + 63) / 64;
-                    rent_waste += (double)(lt - ntr) * (double)(it - rent_last_it);
-                    rent_last_it = it;
-                    want_repack = ntr < lt && rent_waste >= 0.95 * 0.5 * (double)(lt + ntr);
-                }
+                const bool want_repack = (double)lf <= repack_fill * 64.0 * lt;
                 if (repack_ok && it > 0 && lt >= 2 && want_repack && it + 1 < cap) {
-                    rent_waste = 0.0;
                     const int nt = (lf + 63) / 64, np = (nt + 1) / 2, nx = 1 - cur;
                     // the decisions of every frame of the old tiles (those that left keep them; the moved ones overwrite theirs at the end)
                     launch_unpack(d, xbits, xhat, B, n, tiles, fmap, st);
@@ -1391,7 +1340,7 @@ int run16(Decoder* d, const float* priors, const uint8_t* y0, int64_t B, int32_t
         if (first) LDPC_CN16_LAUNCH(DCM, FDC, UNR, true); \
         else LDPC_CN16_LAUNCH(DCM, FDC, UNR, false);      \
     } while (0)
-        if (reg36) LDPC_CN16(6, 6, LDPC_CN16_UNR);
+        if (reg36) LDPC_CN16(6, 6, 2);
         else if (c->max_dc <= 4) LDPC_CN16(4, 0, 2);
         else if (c->max_dc <= 6) LDPC_CN16(6, 0, 2);
         else if (c->max_dc <= 8) LDPC_CN16(8, 0, 1);

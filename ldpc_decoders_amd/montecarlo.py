@@ -85,29 +85,12 @@ class DeviceSimulator:
                             done=torch.cuda.Event() if on_gpu else None, busy=False) for _ in range(self.DEPTH + 1)]
 
         self._next = 0
-        # lanes = (decoder, HIP stream) pairs that rounds alternate over.  One lane (default): everything on the caller's stream.  Two
-        # (LDPC_SIM_STREAMS=2, pipelined rounds of the in-kernel path): consecutive rounds run on two streams with two decoders (own frame
-        # dispensers), so the tail of one launch -- CUs idling while its last frames finish -- is filled by the head of the next.  Measured
-        # (round 4, same box): 65 536-frame rounds of the n = 1200 kernels +0.35 % (fp64, 5.28 ms per round) and +0.85 % (fp32, 2.75 ms), but
-        # the 0.25 ms rounds of the erasure decoder -15 %: an opt-in, not the default.
-        self._lanes = [(handle, None)]
-        self._round = 0
+        # (A two-stream variant -- consecutive rounds on two HIP streams with two decoders -- was measured in round 4: +0.35 % / +0.85 % on the
+        # 5.3 / 2.75 ms rounds of the n = 1200 kernels, -15 % on the erasure decoder's 0.25 ms rounds; removed in round 6, HISTORY.md.)
         self._multi = []  # slots of launch_rounds: [rounds, k] counter blocks
-
-    def _lane(self):
-        import os
-
-        if len(self._lanes) == 1 and self.device == "cuda" and hasattr(self.h, "twin") and os.environ.get("LDPC_SIM_STREAMS", "1") == "2" \
-                and self.pipeline_depth() >= 2:
-            self._lanes.append((self.h.twin(), self.torch.cuda.Stream()))
-        lane = self._lanes[self._round % len(self._lanes)]
-        self._round += 1
-        return lane
 
     def launch_round(self, param, stream_id, frame0, frames_total, flags=0):
         """Enqueue the decode of global frames [frame0, frame0+frames_total), split over ranks; returns a ticket for finish_round."""
-        import contextlib
-
         slot = self._slots[self._next]
         if slot["busy"]:
             raise RuntimeError("more than %d rounds in flight" % len(self._slots))
@@ -115,16 +98,14 @@ class DeviceSimulator:
         start, cnt = self.comm.shard(frame0, frames_total)
         if self.prior_grid is not None:
             return self._launch_exact_round(slot, param, stream_id, start, cnt)
-        h, stream = self._lane()
-        with (self.torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
-            slot["dev"].zero_()
-            if cnt > 0:
-                h.simulate(self.channel, param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
-                           flags=flags, hist_bins=self.hist_bins)
-            self.comm.all_reduce_sum(slot["dev"], async_on_stream=True)
-            slot["host"].copy_(slot["dev"], non_blocking=True)
-            if slot["done"] is not None:
-                slot["done"].record()
+        slot["dev"].zero_()
+        if cnt > 0:
+            self.h.simulate(self.channel, param, self.codeword, self.seed, stream_id, start, cnt, self.max_iter, slot["dev"],
+                            flags=flags, hist_bins=self.hist_bins)
+        self.comm.all_reduce_sum(slot["dev"], async_on_stream=True)
+        slot["host"].copy_(slot["dev"], non_blocking=True)
+        if slot["done"] is not None:
+            slot["done"].record()
         slot["busy"] = True
         return slot
 
@@ -132,15 +113,11 @@ class DeviceSimulator:
         """Rounds worth sending in ONE launch (``launch_rounds``): > 1 only where the kernel keeps its frame positions busy across round
         boundaries (the LDS-resident erasure decoder).  Every round keeps its own counter row, so counters stay a function of the round
         size alone."""
-        import os
-
         h = self.h
         if self.codeword == -1 or self.device != "cuda" or not hasattr(h, "rounds_per_launch"):
             return 1
         if self.prior_grid is not None:  # exact-in-fp32 mode: one fp64 redo pass per block of eight guarded launches
             return 8 if h.last_stats()[0] == "fused" else 1
-        if os.environ.get("LDPC_SIM_STREAMS", "1") == "2":  # the two-stream experiment alternates single rounds over two decoders
-            return 1
         return int(h.rounds_per_launch())
 
     def launch_rounds(self, param, stream_id, frame0, frames_total, rounds, flags=0):

@@ -63,20 +63,6 @@ def test_pipelined_rounds_equal_the_synchronous_loop():
     assert got["hist"] == tot[4:].tolist() and got["tot"] >= 3 * 512  # several rounds, so the pipeline really overlapped
 
 
-@pytest.mark.parametrize("alg,prec,channel,param", [("MSA", "f64", "biawgn", 2.2), ("BEC", "f32", "bec", 0.41), ("SPA", "f32", "bsc", 0.06)])
-def test_two_stream_rounds_equal_one_stream(monkeypatch, alg, prec, channel, param):
-    # LDPC_SIM_STREAMS=2 (opt-in): consecutive rounds on two streams / two decoders -- the counters are a function of the frame indices alone
-    from ldpc_decoders_amd.montecarlo import DeviceSimulator
-
-    outs = []
-    for streams in ("1", "2"):
-        monkeypatch.setenv("LDPC_SIM_STREAMS", streams)
-        sim = DeviceSimulator(_handle(alg, prec), channel, 50, 0, 4321, hist_bins=51)
-        outs.append(sim.run_point(param, 2, min_wec=1200, batch_per_rank=1024))
-        assert len(sim._lanes) == int(streams)
-    assert outs[0] == outs[1] and outs[0]["tot"] >= 4 * 1024
-
-
 WORKER = r'''
 import json, os, sys
 sys.path[:0] = [%(root)r, %(root)r + "/tests", %(root)r + "/oracle"]

@@ -17,12 +17,16 @@ def _priors(seed, B, n, snr):
     return O.biawgn_priors(y, snr)
 
 
+@pytest.mark.parametrize("fold", ["1", "0"], ids=["folded", "separate"])
 @pytest.mark.parametrize("prec,dt", [("f64", np.float64), ("f32", np.float32)])
 @pytest.mark.parametrize("alg", ["MSA", "SPA"])
-def test_repack_is_bit_transparent(monkeypatch, prec, dt, alg):
+def test_repack_is_bit_transparent(monkeypatch, prec, dt, alg, fold):
+    # both forms of the repack: folded into the sweep behind it (k_repack_map + the GATHER passes, the default where those passes are built)
+    # and the separate copy kernel (k_repack: LDPC_STREAM_REPACK_FOLD=0, and every code with node degrees beyond 8)
     from ldpc_decoders_amd import bpa
     from ldpc_decoders_amd.codes import Code
 
+    monkeypatch.setenv("LDPC_STREAM_REPACK_FOLD", fold)
     g = golden_edges("1200_3_6_rand_ldpc_1")
     code = Code.from_edges(g.m, g.n, g.chk, g.var)
     B = 64 * 40 + 17  # ragged last tile
@@ -96,6 +100,29 @@ def test_repack_with_received_word(monkeypatch):
     xo, io = C.bp_decode(g, "MSA", y, pri, 200, dtype=np.float64)
     assert dec.handle.last_repacks() >= 1
     assert (i1[:5] == 0).all() and (x1 == xo).all() and (i1 == io).all()
+
+
+@pytest.mark.parametrize("name", ["1200_rho_x5_rand_ldpc_5", "margulis"])
+def test_folded_repack_on_irregular_and_large_codes(monkeypatch, name):
+    # GATHER passes of the other instantiations: irregular degrees (dc <= 6, dv <= 8: no fixed row / column length) and the n = 2640 code,
+    # fp32 and fp64, several repacks per decode; against the decode without any repack and (min-sum) the C oracle
+    from ldpc_decoders_amd import bpa
+    from ldpc_decoders_amd.codes import Code
+
+    g = golden_edges(name)
+    code = Code.from_edges(g.m, g.n, g.chk, g.var)
+    B = 64 * 13 + 5
+    for prec, dt in (("f32", np.float32), ("f64", np.float64)):
+        pri = _priors(23, B, g.n, 2.1).astype(dt)
+        monkeypatch.setenv("LDPC_STREAM_REPACK", "0")
+        x0, i0 = bpa.MSA(code, max_iter=40, precision=prec, backend="stream").decode_batch(None, pri)
+        monkeypatch.setenv("LDPC_STREAM_REPACK", "1")
+        monkeypatch.setenv("LDPC_STREAM_REPACK_FILL", "0.97")
+        dec = bpa.MSA(code, max_iter=40, precision=prec, backend="stream")
+        x1, i1 = dec.decode_batch(None, pri)
+        assert dec.handle.last_repacks() >= 2 and (x1 == x0).all() and (i1 == i0).all() and len(np.unique(i1)) > 4
+        xo, io = C.bp_decode(g, "MSA", None, pri, 40, dtype=dt)
+        assert (x1 == xo).all() and (i1 == io).all()
 
 
 def test_repack_large_code_mid_snr():

@@ -393,7 +393,7 @@ SIM_KERNELS_WITH_A_SPILL_BUDGET = {
     "k_fused_bp<0, 6, 3, 5, 10, 16, true, 3, 8>": 24,  # config 4, one frame per CU: 19 spilled, 17.86 ms against 18.70 (spill-free) per 32 768 frames
     # config 3, fp32 sum-product (BSC / BI-AWGN), round 5: with the pair-tree rule the kernel is fastest with 6 + 8 of its gather-table words
     # kept packed and 6 registers spilled (2.21 ms per 65 536 frames at p = 0.07); every spill-free setting (15 + 15: 2.34 ms) is 5.7 %
-    # slower, 0 + 0 / 4 + 4 / 8 + 8 / 10 + 10 lie in between -- same box, tools/ab_spa.sh, gpurun_out/r05s2
+    # slower, 0 + 0 / 4 + 4 / 8 + 8 / 10 + 10 lie in between -- same box, round 5 (HISTORY.md)
     "k_fused_bp<1, 6, 3, 5, 10, 2, true, 0, 3>": 8,
 }
 
