@@ -286,7 +286,9 @@ class AuxHandle:
 
     def kernel_name(self, simulate=False):
         if self.alg == "ADMM":
-            return "k_admm_lds<6, 3, 2, %d>" % ((self.code.m + 63) // 64) if self.inner.last_backend() == "lds" else "k_admm_z_fixed<6>"
+            rows = (self.code.m + 63) // 64  # the shape ldpc_admm.hip picks: 4 or 8 waves, one or two passes of the check phase
+            lds = "k_admm_lds<6, 3, 2, 4, 1>" if rows <= 4 else ("k_admm_lds<6, 3, 2, 8, 1>" if rows <= 8 else "k_admm_lds<6, 3, 3, 8, 2>")
+            return lds if self.inner.last_backend() == "lds" else "k_admm_z_fixed<6>"
         return "k_ml"
 
     def timed_launches(self, channel, param, frames, max_iter, steps, torch):

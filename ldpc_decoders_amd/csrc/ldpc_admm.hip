@@ -176,9 +176,15 @@ __device__ void pp_project(AD v, AD s, AD c, AD bp, AI who, AI bp_who, int len) 
 // operation by operation, as pp_project: results are bit-identical.
 template <int L>
 __device__ __forceinline__ double dyn_get(const double (&a)[L], int idx) {
+    // a select chain that STAYS one: left to itself the optimiser turns the chain back into a[idx], i.e. a private array with a dynamic
+    // index -- promoted to the LDS where the kernel's LDS size is static (k_admm_z_fixed: one ds_read per access), but placed in SCRATCH
+    // under a dynamic LDS allocation (k_admm_lds: 14 dependent scratch loads per projection, 60 % of the kernel's time spent waiting)
     double r = a[0];
 #pragma unroll
-    for (int i = 1; i < L; ++i) r = (idx == i) ? a[i] : r;
+    for (int i = 1; i < L; ++i) {
+        r = (idx == i) ? a[i] : r;
+        asm("" : "+v"(r));
+    }
     return r;
 }
 
@@ -610,7 +616,7 @@ struct AdmmLdsArgs {
     unsigned long long* ticket;
 };
 
-template <int L, int DVMAX, int VPL, int NW>
+template <int L, int DVMAX, int VPL, int NW, int CPL>
 __global__ __launch_bounds__(64 * NW) void k_admm_lds(const AdmmLdsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, T = 64 * NW;
@@ -624,12 +630,49 @@ __global__ __launch_bounds__(64 * NW) void k_admm_lds(const AdmmLdsArgs A) {
     double* const racc = x + n;                        // [2][leaves][8] accumulator chains
     double* const val = racc + 2 * A.leaves * 8;        // [2][nodes] block sums and the tree above them
     volatile int* const word = reinterpret_cast<volatile int*>(val + 2 * A.nodes);  // [0] frame hand-out (lo), [1] (hi), [2] verdict
+    // the schedule of the stopping sums, copied into the LDS once per workgroup (a global load per tree level on the one wave that
+    // folds the tree was a third of the iteration): additions of the tree (lvl_a, lvl_b per node), level boundaries, blocks (offset, length)
+    int* const s_lvl_a = const_cast<int*>(reinterpret_cast<volatile int*>(word)) + 16;
+    int* const s_lvl_b = s_lvl_a + A.nodes;
+    int* const s_lvl_start = s_lvl_b + A.nodes;
+    int* const s_leaf_off = s_lvl_start + A.levels + 1;
+    int* const s_leaf_len = s_leaf_off + A.leaves;
     const double mu = A.mu;
     auto eidx = [&](int k) { return (k % L) * m + k / L; };  // canonical edge index -> LDS position
+    for (int i = tid; i < A.nodes; i += T) {
+        s_lvl_a[i] = A.lvl_a[i];
+        s_lvl_b[i] = A.lvl_b[i];
+    }
+    for (int i = tid; i <= A.levels; i += T) s_lvl_start[i] = A.lvl_start[i];
+    for (int i = tid; i < A.leaves; i += T) {
+        s_leaf_off[i] = A.leaf_off[i];
+        s_leaf_len[i] = A.leaf_len[i];
+    }
+    // graph indices of this lane, resident for the whole launch: LDS positions of the edges of its variables (ascending edge order),
+    // variables of its check's edges, its accumulator chain of the stopping sums
+    int vk[VPL][DVMAX], vdeg[VPL];
+#pragma unroll
+    for (int r = 0; r < VPL; ++r) {
+        const int v = tid + r * T;
+        const int p0 = v < n ? A.col_ptr[v] : 0, p1 = v < n ? A.col_ptr[v + 1] : 0;
+        vdeg[r] = p1 - p0;
+#pragma unroll
+        for (int j = 0; j < DVMAX; ++j) vk[r][j] = eidx(A.col_edge[p0 + j < p1 ? p0 + j : p0]);
+    }
+    int ev[CPL][L];  // CPL checks per lane: check tid + cp * T
+#pragma unroll
+    for (int cp = 0; cp < CPL; ++cp)
+#pragma unroll
+        for (int j = 0; j < L; ++j) ev[cp][j] = tid + cp * T < m ? A.edge_var[(tid + cp * T) * L + j] : 0;
+    // chain `tid`: array (d1 / d2), block, accumulator; at most one per lane (2 * 8 * leaves chains, leaves ~ E / 112, T >= E / L)
+    const int chain_arr = tid / (A.leaves * 8), chain_rem = tid - chain_arr * (A.leaves * 8);
+    const bool has_chain = tid < 2 * A.leaves * 8;
+    const int chain_off = has_chain ? A.leaf_off[chain_rem >> 3] + (chain_rem & 7) : 0;
+    const int chain_len = has_chain ? A.leaf_len[chain_rem >> 3] : 0;
 
     for (;;) {
         // ---- next frame
-        __syncthreads();  // everybody is done with the previous frame's LDS state and hand-out words
+        __syncthreads();  // everybody is done with the previous frame's LDS state and hand-out words (first trip: the tables above are written)
         if (tid == 0) {
             const unsigned long long t = atomicAdd(A.ticket, 1ull);
             word[0] = (int)(unsigned)(t & 0xffffffffull);
@@ -659,82 +702,87 @@ __global__ __launch_bounds__(64 * NW) void k_admm_lds(const AdmmLdsArgs A) {
             for (int r = 0; r < VPL; ++r) {
                 const int v = tid + r * T;
                 if (v < n) {
-                    const int p0 = A.col_ptr[v], p1 = A.col_ptr[v + 1];
-                    int kk[DVMAX];
-#pragma unroll
-                    for (int j = 0; j < DVMAX; ++j) kk[j] = eidx(A.col_edge[p0 + j < p1 ? p0 + j : p0]);
                     double s = 0.0;
 #pragma unroll
                     for (int j = 0; j < DVMAX; ++j) {
-                        const double t = z[kk[j]] - q[kk[j]];
-                        s = (p0 + j < p1) ? s + t : s;
+                        const double t = z[vk[r][j]] - q[vk[r][j]];
+                        s = (j < vdeg[r]) ? s + t : s;
                     }
-                    x[v] = clamp01((s - gq[r]) / (double)(p1 - p0));
+                    x[v] = clamp01((s - gq[r]) / (double)vdeg[r]);
                 }
             }
             __syncthreads();
-            // ---- phase B: z / lambda update, lane == check
-            if (tid < m) {
-                double xs[L], lm[L], zo[L], v[L];
+            // ---- phase B: z / lambda update, lane == check (CPL passes: T lanes take the checks T at a time)
+#pragma unroll 1
+            for (int cp = 0; cp < CPL; ++cp) {
+                const int c = tid + cp * T;
+                if (c < m) {
+                    double xs[L], lm[L], zo[L], v[L];
 #pragma unroll
-                for (int j = 0; j < L; ++j) {
-                    const int o = j * m + tid;
-                    xs[j] = x[A.edge_var[tid * L + j]];
-                    lm[j] = lam[o];
-                    zo[j] = z[o];
-                    v[j] = xs[j] + q[o];
-                }
-                pp_project_fixed<L>(v);
+                    for (int j = 0; j < L; ++j) {
+                        const int o = j * m + c;
+                        xs[j] = x[CPL == 1 ? ev[0][j] : (cp == 0 ? ev[0][j] : ev[CPL - 1][j])];
+                        lm[j] = lam[o];
+                        zo[j] = z[o];
+                        v[j] = xs[j] + q[o];
+                    }
+                    pp_project_fixed<L>(v);
 #pragma unroll
-                for (int j = 0; j < L; ++j) {
-                    const int o = j * m + tid;
-                    const double a = xs[j] - v[j], b = zo[j] - v[j];
-                    const double ln = lm[j] + mu * a;
-                    lam[o] = ln;
-                    q[o] = ln / mu;
-                    d1[o] = a * a;
-                    d2[o] = b * b;
-                    z[o] = v[j];
+                    for (int j = 0; j < L; ++j) {
+                        const int o = j * m + c;
+                        const double a = xs[j] - v[j], b = zo[j] - v[j];
+                        const double ln = lm[j] + mu * a;
+                        lam[o] = ln;
+                        q[o] = ln / mu;
+                        d1[o] = a * a;
+                        d2[o] = b * b;
+                        z[o] = v[j];
+                    }
                 }
             }
             __syncthreads();
             // ---- phase C1: the eight strided accumulators of every block (np_block), one lane per chain
-            for (int idx = tid; idx < 2 * A.leaves * 8; idx += T) {
-                const int arr = idx / (A.leaves * 8), rem = idx - arr * (A.leaves * 8), leaf = rem >> 3, kacc = rem & 7;
-                const int off = A.leaf_off[leaf], len = A.leaf_len[leaf];
-                const double* a = arr ? d2 : d1;
-                if (len >= 8) {
-                    double rsum = a[eidx(off + kacc)];
-                    for (int i = 8; i < len - (len % 8); i += 8) rsum += a[eidx(off + i + kacc)];
-                    racc[idx] = rsum;
-                }
+            if (has_chain && chain_len >= 8) {
+                // a block has at most 128 elements, 16 per accumulator: every load of the chain is issued before the first add (the adds stay in
+                // np_block's order); element positions past the chain read the chain's first element and are not added
+                const double* a = chain_arr ? d2 : d1;
+                const int nel = (chain_len - (chain_len % 8)) >> 3;  // elements of this chain, >= 1
+                double e[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) e[t] = a[eidx(chain_off + (t < nel ? 8 * t : 0))];
+                double rsum = e[0];
+#pragma unroll
+                for (int t = 1; t < 16; ++t) rsum = t < nel ? rsum + e[t] : rsum;
+                racc[tid] = rsum;
             }
             __syncthreads();
             // ---- phase C2 + C3 (one wave): block sums, then the additions of the split tree level by level
             if (tid < 64) {
                 for (int idx = tid; idx < 2 * A.leaves; idx += 64) {
                     const int arr = idx / A.leaves, leaf = idx - arr * A.leaves;
-                    const int off = A.leaf_off[leaf], len = A.leaf_len[leaf];
+                    const int off = s_leaf_off[leaf], len = s_leaf_len[leaf];
                     const double* a = arr ? d2 : d1;
+                    const int i0 = len < 8 ? 0 : len - (len % 8), ntail = len - i0;  // np_block's tail: at most 7 elements, added one by one
+                    double tail[7];
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) tail[t] = a[eidx(off + (t < ntail ? i0 + t : 0))];
                     double res;
-                    int i;
                     if (len < 8) {
                         res = -0.0;
-                        i = 0;
                     } else {
                         const double* r8 = racc + (arr * A.leaves + leaf) * 8;
                         res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-                        i = len - (len % 8);
                     }
-                    for (; i < len; ++i) res += a[eidx(off + i)];
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) res = t < ntail ? res + tail[t] : res;
                     val[arr * A.nodes + leaf] = res;
                 }
                 __builtin_amdgcn_wave_barrier();
                 for (int lv = 0; lv < A.levels; ++lv) {
-                    const int s0 = A.lvl_start[lv], s1 = A.lvl_start[lv + 1];
+                    const int s0 = s_lvl_start[lv], s1 = s_lvl_start[lv + 1];
                     for (int idx = tid; idx < 2 * (s1 - s0); idx += 64) {
                         const int arr = idx / (s1 - s0), node = s0 + idx - arr * (s1 - s0);
-                        val[arr * A.nodes + node] = val[arr * A.nodes + A.lvl_a[node]] + val[arr * A.nodes + A.lvl_b[node]];
+                        val[arr * A.nodes + node] = val[arr * A.nodes + s_lvl_a[node]] + val[arr * A.nodes + s_lvl_b[node]];
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -880,10 +928,11 @@ void admm_destroy(AdmmDecoder* d) {
 // LDS-resident path of admm_decode: returns 1 where the code is not eligible (checks of unequal degree, a frame beyond the LDS, a code
 // too small to fill a workgroup -- the streaming kernels serve those), else LDPC_OK / an error.  LDPC_ADMM_BACKEND=stream forces the
 // streaming kernels (A/B and the parity tests of both).
-template <int L, int DVMAX, int VPL, int NW>
+template <int L, int DVMAX, int VPL, int NW, int CPL>
 static int admm_launch_lds(const AdmmLdsArgs& a, size_t lds_bytes, int grid, hipStream_t st) {
-    LDPC_HIP_TRY(hipFuncSetAttribute((const void*)k_admm_lds<L, DVMAX, VPL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((k_admm_lds<L, DVMAX, VPL, NW>), dim3(grid), dim3(64 * NW), lds_bytes, st, a);
+    static_assert(CPL <= 2, "phase B selects between the first and the last pass's index registers");
+    LDPC_HIP_TRY(hipFuncSetAttribute((const void*)k_admm_lds<L, DVMAX, VPL, NW, CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((k_admm_lds<L, DVMAX, VPL, NW, CPL>), dim3(grid), dim3(64 * NW), lds_bytes, st, a);
     return LDPC_OK;
 }
 
@@ -893,10 +942,15 @@ static int admm_decode_lds(AdmmDecoder* d, const double* gamma, int64_t B, doubl
     if (const char* e = std::getenv("LDPC_ADMM_BACKEND"))
         if (std::string(e) == "stream") return 1;
     if (c->min_dc != c->max_dc || c->max_dc != 6 || c->max_dv > 3 || c->min_dv < 1) return 1;  // built: (3,6)-type codes (every check six edges, variables up to three)
-    const int nw = (c->m + 63) / 64;
-    if (nw != 4 && nw != 8 && nw != 10) return 1;
-    if (c->n > 2 * 64 * nw) return 1;
-    const size_t lds_bytes = ((size_t)5 * c->E + c->n + (size_t)2 * d->leaves * 8 + (size_t)2 * d->nodes) * 8 + 64;
+    // waves per frame: 4 or 8 with one check per lane (m <= 256 / 512); beyond (n = 1200: m = 600) eight waves take the checks in TWO passes
+    // -- ten waves at one check each were measured no faster (three wave-projections per SIMD either way) and leave the compiler 170
+    // registers where the projection wants 200 (49 spilled)
+    const int rows = (c->m + 63) / 64;
+    const int nw = rows <= 4 ? 4 : 8, cpl = rows <= 8 ? 1 : 2;
+    if (rows > 16 || c->n > (cpl == 1 ? 2 : 3) * 64 * nw) return 1;
+    if (2 * d->leaves * 8 > 64 * nw) return 1;  // one accumulator chain of the stopping sums per lane
+    const size_t lds_bytes = ((size_t)5 * c->E + c->n + (size_t)2 * d->leaves * 8 + (size_t)2 * d->nodes) * 8 + 64 +
+                             ((size_t)2 * d->nodes + d->levels + 1 + (size_t)2 * d->leaves) * 4 + 16;  // + the schedule tables (ints)
     if (lds_bytes > (size_t)160 * 1024) return 1;
     AdmmLdsArgs a;
     a.gamma = gamma; a.x_out = x_out; a.iters = iters; a.converged = converged;
@@ -913,11 +967,9 @@ static int admm_decode_lds(AdmmDecoder* d, const double* gamma, int64_t B, doubl
     const int64_t want = (int64_t)prop.multiProcessorCount * per_cu;
     const int grid = (int)(B < want ? B : want);
     int rc = LDPC_OK;
-    switch (nw) {
-        case 4: rc = admm_launch_lds<6, 3, 2, 4>(a, lds_bytes, grid, st); break;
-        case 8: rc = admm_launch_lds<6, 3, 2, 8>(a, lds_bytes, grid, st); break;
-        default: rc = admm_launch_lds<6, 3, 2, 10>(a, lds_bytes, grid, st); break;
-    }
+    if (nw == 4) rc = admm_launch_lds<6, 3, 2, 4, 1>(a, lds_bytes, grid, st);
+    else if (cpl == 1) rc = admm_launch_lds<6, 3, 2, 8, 1>(a, lds_bytes, grid, st);
+    else rc = admm_launch_lds<6, 3, 3, 8, 2>(a, lds_bytes, grid, st);
     if (rc) return rc;
     LDPC_HIP_TRY(hipGetLastError());
     d->last_repacks = 0;
