@@ -85,6 +85,9 @@ struct BecShape {
     static constexpr int CNE = CRW * DC;
     static constexpr int CNW = (CNE + 1) / 2, VNW = (VNK + 1) / 2;
     static constexpr uint32_t SUM_BASE = (uint32_t)NW * VNK * 512u, SYS_BASE = SUM_BASE + (uint32_t)CR * 512u;
+    // gather tables: 16-bit BYTE offsets while the slab fits 64 KB (one instruction per gather address: mask or shift of the packed word),
+    // element indices (x 8: one more shift) beyond -- becs_build_plan writes them by the same rule
+    static constexpr bool BYTE_TAB = SYS_BASE + 1024u <= 65536u;
     // the variable's own last outgoing messages stay in registers where the budget allows, else they are re-read from its rows
     // (lane-contiguous, 2 LDS cycles a row): the Monte-Carlo kernel of the four-wave shape would spill 19 registers with them
     static constexpr bool OWN_REGS = VNK <= 16 && !MC_;
@@ -100,7 +103,7 @@ struct BecShape {
 template <class SH>
 __device__ __forceinline__ void becs_check_phase(const unsigned char* smem, const uint32_t (&cn_idx)[SH::CNW], uint32_t sum_vaddr, int w, uint32_t keep) {
     constexpr int DC = SH::DC, CRW = SH::CRW, NW = SH::NW, CR = SH::CR;
-    auto cn_addr = [&](int k) -> uint32_t { return half_of<SH::CNE>(cn_idx, k) << 3; };
+    auto cn_addr = [&](int k) -> uint32_t { return SH::BYTE_TAB ? half_of<SH::CNE>(cn_idx, k) : half_of<SH::CNE>(cn_idx, k) << 3; };
     P2 mg[2][DC];
 #pragma unroll
     for (int j = 0; j < DC; ++j) mg[0][j] = lds_ld2(smem, cn_addr(j));
@@ -136,7 +139,7 @@ __device__ __forceinline__ void becs_var_phase(const unsigned char* smem, const 
                                                uint32_t& chg, uint32_t& era, uint32_t& wrong) {
     constexpr int DV = SH::DV, VRW = SH::VRW, VRX = SH::VRX, DVX = SH::DVX, VN0 = SH::VN0;
     constexpr bool OWN_REGS = SH::OWN_REGS;
-    auto vn_addr = [&](int k) -> uint32_t { return half_of<SH::VNK>(vn_idx, k) << 3; };
+    auto vn_addr = [&](int k) -> uint32_t { return SH::BYTE_TAB ? half_of<SH::VNK>(vn_idx, k) : half_of<SH::VNK>(vn_idx, k) << 3; };
     // own_at(q): first own-message row of variable round q.  Where the wave re-reads its own last messages from its rows (Monte-Carlo kernel),
     // those reads travel with the summary gathers of the round -- one round ahead -- instead of in front of their first use
     auto own_row0 = [&](int q) -> int { return q < VRX ? q * DVX : VN0 + (q - VRX) * DV; };

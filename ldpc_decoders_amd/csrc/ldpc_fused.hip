@@ -340,7 +340,10 @@ static int becs_build_plan(Decoder* d, FusedPlan* p, const ShapeEntry& shape, co
     std::vector<uint32_t> cn_tab((size_t)NW * CNW * 64, 0), vn_tab((size_t)NW * VNW * 64, 0);
     std::vector<int32_t> var_of_slot((size_t)NPAD, -1);
     for (int v = 0; v < c->n; ++v) var_of_slot[L.var_slot[v]] = v;
-    auto put16 = [](std::vector<uint32_t>& tab, int words_per_wave, int wv, int k, int lane, uint32_t val) {
+    // table entries: byte offsets while the slab fits 64 KB, element indices beyond (BecShape::BYTE_TAB, the kernels' rule)
+    const uint32_t tab_scale = (sys_base * 8u + 1024u <= 65536u) ? 8u : 1u;
+    auto put16 = [tab_scale](std::vector<uint32_t>& tab, int words_per_wave, int wv, int k, int lane, uint32_t val) {
+        val *= tab_scale;
         uint32_t& w = tab[((size_t)wv * words_per_wave + (k >> 1)) * 64 + lane];
         w = (k & 1) ? ((w & 0x0000ffffu) | (val << 16)) : ((w & 0xffff0000u) | val);
     };
