@@ -480,3 +480,50 @@ def test_bench_workload_selectors_and_cpu_baseline_dispatch():
             assert c["scipy"].get("value", 0) > 0, c["scipy"]
     args = bench.parse_args(["--decoder", "SPA", "--channel", "bec", "--total-batch", "1000", "--gpus", "2"])
     assert args.decoder == "SPA" and args.channel == "bec" and args.total_batch == 1000 and args.param is None and args.points is None
+
+
+def test_bench_selectors_of_the_admm_and_ml_decoders():
+    # bench.py --decoder ADMM | ML: selectors, byte models, CPU baselines (oracle/admm_oracle.c, oracle/ml_oracle.py) on
+    # the (7,4) Hamming code with a fraction of a second of CPU work
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.resolve_workload("ADMM", "biawgn", 2.2, 1.0) == ("ADMM", "biawgn", 2.2)
+    assert bench.resolve_workload("ML", "bsc", None, 1.0) == ("ML", "bsc", 0.07)
+    code = bench.load_code("7_4_hamming")
+    assert bench.bytes_per_frame_sweep(code, "ADMM", "f64") == 8 * (9 * code.E + 2 * code.n)
+    assert bench.bytes_per_frame_sweep(code, "ML", "f32") == 4 * code.n
+    a = bench.cpu_baseline(code, "ADMM", "biawgn", 2.0, 50, "f64", 0.1)
+    assert a["kind"] == "port" and a["value"] > 0 and a["cores"] >= 1 and "admm_oracle.c" in a["sample"] and "skipped" in a["scipy"]
+    m = bench.cpu_baseline(code, "ML", "biawgn", 2.0, 0, "f32", 0.2)
+    assert m["kind"] == "port" and m["value"] > 0 and m["cores"] == 1 and "16 codewords" in m["sample"]
+    args = bench.parse_args(["--decoder", "ADMM", "--param", "2.2", "--max-iter", "300"])
+    assert args.decoder == "ADMM" and not bench.is_default_workload(args)
+
+
+def test_counter_entries_are_checked_against_the_kernel_code_of_the_built_library():
+    # profiles/roofline_counters.json keys an LDS-resident kernel by NAME; a kernel body can change under an unchanged name.  Every entry
+    # therefore carries a hash of the machine code it was measured on (tools/kernel_resources.py: ELF symbol bytes + kernel descriptor,
+    # no GPU needed) and bench.py refuses to price a timing with counters of another body: counters_stale, frac null.
+    import sys
+
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
+    import bench
+    import kernel_resources
+
+    hashes = kernel_resources.kernel_code_hashes()
+    headline = "k_fused_f64<0, 6, 3, 3, 5, 4, true, 0, 3>"
+    assert len(hashes) > 200 and headline in hashes and "k_cn<float, 0, 6, 6, 2, false>" in hashes and "k_admm_lds<6, 3, 3, 8, 2>" in hashes
+    assert all(len(h) == 16 for h in hashes.values())
+    assert hashes[headline] != hashes["k_fused_f64<0, 6, 3, 3, 5, 4, false, 0, 3>"]      # the decode and the simulate variant differ
+    assert kernel_resources.kernel_code_hashes() == hashes                               # a pure function of the file
+    entry = {"lds_idx_active_per_frame_sweep": 600.0, "bank_conflict_per_frame_sweep": 30.0, "valu_active_cycles_per_frame_sweep": 1500.0,
+             "insts_valu_per_frame_sweep": 700.0, "insts_lds_per_frame_sweep": 220.0, "lds_path_cycles_per_frame_sweep": 780.0}
+    fresh = bench.fused_roofline(headline, 6.0e8, 256, {headline: dict(entry, kernel_code_sha=hashes[headline], head="abc")})
+    assert fresh["counters_stale"] is False and fresh["frac"] is not None and fresh["binding_unit"] == "lds_store_path"
+    stale = bench.fused_roofline(headline, 6.0e8, 256, {headline: dict(entry, kernel_code_sha="0123456789abcdef")})
+    assert stale["counters_stale"] is True and stale["frac"] is None and stale["achieved"] is None and "STALE" in stale["counters_check"]
+    unverified = bench.fused_roofline(headline, 6.0e8, 256, {headline: entry})
+    assert unverified["counters_stale"] is None and unverified["frac"] is not None and "unverified" in unverified["counters_check"]
