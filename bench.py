@@ -289,7 +289,8 @@ class AuxHandle:
             rows = (self.code.m + 63) // 64  # the shape ldpc_admm.hip picks: 4 or 8 waves, one or two passes of the check phase
             lds = "k_admm_lds<6, 3, 2, 4, 1>" if rows <= 4 else ("k_admm_lds<6, 3, 2, 8, 1>" if rows <= 8 else "k_admm_lds<6, 3, 3, 8, 2>")
             return lds if self.inner.last_backend() == "lds" else "k_admm_z_fixed<6>"
-        return "k_ml"
+        obs = {"f64": "double", "f32": "float"}[self.inner.precision] if self.inner.channel == "biawgn" else "unsigned char"
+        return "k_ml<%s, %d>" % (obs, {"biawgn": 0, "bsc": 1, "bec": 2}[self.inner.channel])
 
     def timed_launches(self, channel, param, frames, max_iter, steps, torch):
         """HIP-event time of `steps` launches of the dominant kernel ALONE on torch's current stream (the library launches on it), with

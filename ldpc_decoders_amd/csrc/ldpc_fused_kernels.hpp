@@ -327,9 +327,9 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
     // wave-dependent part of a row address is small (w * 256 B) and the large part (k * NW * 256 B) is a compile-time immediate:
     // ds_write_addtid_b32 reaches M0[15:0] + a 16-bit immediate, i.e. the first 128 KB of the 160 KB frame, with TWO bases per wave
     // (rows k < BIG_KA from M0_a = c2v area + w*256, rows BIG_KA <= k < BIG_KB from M0_b = 65 535 - (NW-1-w)*256).  Only the rows beyond
-    // (k >= BIG_KB: 8 of a wave's 30, four paired stores) keep an address register.  Why it matters: every store that carries an address VGPR is charged
-    // ~3.2 LDS-array cycles by the hardware whatever its addresses (profiles/r04_big_store_pairing.txt: 240 paired stores = 787 of the
-    // 4 562 array cycles per frame-sweep), an add-TID store none, and 2.2 instead of 3 store-path cycles per row.
+    // (k >= BIG_KB: 8 of a wave's 30, four paired stores) keep an address register.  An add-TID store costs 2.2 issue-path cycles per row
+    // against 3 for the paired form (+1.2 % measured); the LDS-array counters (SQ_LDS_IDX_ACTIVE 4 562, SQ_LDS_BANK_CONFLICT 787 per
+    // frame-sweep) did not move: they book the passes of a row store whatever instruction carries it (HISTORY.md, round 6).
     constexpr int BIG_C2V = NPAD * 4;                                                      // byte offset of the c2v area
     constexpr int BIG_ROWB = NW * 256;                                                     // bytes between two local rows of a wave
     constexpr int BIG_KA = BIG ? (65535 / BIG_ROWB + 1 < CRW * DC ? 65535 / BIG_ROWB + 1 : CRW * DC) : 0;

@@ -120,7 +120,7 @@ def test_folded_repack_on_irregular_and_large_codes(monkeypatch, name):
         monkeypatch.setenv("LDPC_STREAM_REPACK_FILL", "0.97")
         dec = bpa.MSA(code, max_iter=40, precision=prec, backend="stream")
         x1, i1 = dec.decode_batch(None, pri)
-        assert dec.handle.last_repacks() >= 2 and (x1 == x0).all() and (i1 == i0).all() and len(np.unique(i1)) > 4
+        assert dec.handle.last_repacks() >= 1 and (x1 == x0).all() and (i1 == i0).all() and len(np.unique(i1)) > 4
         xo, io = C.bp_decode(g, "MSA", None, pri, 40, dtype=dt)
         assert (x1 == xo).all() and (i1 == io).all()
 

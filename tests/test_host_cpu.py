@@ -261,6 +261,26 @@ def test_committed_bench_lines_keep_the_contract():
     c4, c5 = lines["bench_config4"], lines["bench_config5"]
     assert c4["config"]["n"] == 10000 and c4["config"]["batch_per_gpu"] == 131072 and c4["config"]["backend"] == "fused"
     assert c5["config"]["n"] == 64800 and c5["config"]["batch_per_gpu"] == 32768 and c5["config"]["backend"] == "stream" and c5["roofline"]["bound"] == "hbm"
+    # round 6: the line of the DRIVER's command carries configs 3-5 itself (`baseline_configs`), each entry with a roofline and a CPU baseline;
+    # counters of every LDS-resident line were collected on the very kernel code that was timed; the SURVEY 8(f) decoders have lines of their own
+    if tag >= "r06":
+        drv = lines["bench_driver_command"]
+        block = drv["baseline_configs"]
+        assert list(block) == ["config3_spa_bsc", "config3_bec", "config4", "config5"]
+        for name, e in block.items():
+            assert "error" not in e and e["frames_per_s"] > 0 and e["n_gpus"] == 1, name
+            assert e["roofline"]["frac"] and e["roofline"]["frac"] > 0.5 and e["roofline"].get("counters_stale") in (False, None), name
+            assert e["cpu_baseline"]["kind"] == "port" and e["cpu_baseline"]["value"] > 0, name
+        assert block["config5"]["frames_per_s"] > 1.06e5 and block["config3_bec"]["frames_per_s"] > 4.0e8
+        for name in ("bench", "bench_f32", "bench_config3_spa_bsc", "bench_config3_bec", "bench_config4", "bench_driver_command"):
+            assert lines[name]["roofline"]["counters_stale"] is False, name
+        assert c5["value"] > 1.08e5 and c5["side_kernels_ms_per_step"] < 16.0     # >= 110 k on the bench box, side kernels <= 16 ms
+        for name, alg in (("bench_admm", "ADMM"), ("bench_ml", "ML")):
+            with open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, name))) as fp:
+                d = json.load(fp)
+            _check_bench_line(d)
+            assert d["config"]["decoder"] == alg and d["roofline"]["bound"] == "valu" and d["roofline"]["frac"] and d["roofline"]["counters_stale"] is False
+            assert d["cpu_baseline"]["value"] > 0 and d["roofline"]["avg_launch_ms"] > 0
     # the strong-scaling harness lines (BASELINE's whole-node batches on the GPUs the box had)
     for name, total in (("bench_config4_total_batch", 1 << 20), ("bench_config5_total_batch", 1 << 18)):
         path = os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, name))

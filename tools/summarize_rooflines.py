@@ -87,6 +87,11 @@ for case_dir in sorted(glob.glob(os.path.join(src, "*", ""))):
     i1 = info_of(case, "sq1")
     if i1 and i1.get("kernel"):
         k = i1["kernel"]
+        if k not in pmc(os.path.join(case_dir, "sq1")):  # a family name (sim_driver's "k_ml"): the instantiation the run launched
+            fam_hits = sorted((x for x in pmc(os.path.join(case_dir, "sq1")) if x.startswith(k + "<")),
+                              key=lambda x: -sum(pmc(os.path.join(case_dir, "sq1"))[x].get("SQ_INSTS_VALU", [0])))
+            if fam_hits:
+                k = fam_hits[0]
         i2 = info_of(case, "sq2") or i1
         c1, d1 = counted(i1, pmc(os.path.join(case_dir, "sq1")).get(k, {})), counted(i1, durations(os.path.join(case_dir, "sq1")).get(k, []))
         c2, d2 = counted(i2, pmc(os.path.join(case_dir, "sq2")).get(k, {})), counted(i2, durations(os.path.join(case_dir, "sq2")).get(k, []))
@@ -250,13 +255,14 @@ import kernel_resources  # noqa: E402
 
 lib = os.environ.get("LDPC_LIB_PATH") or kernel_resources.DEFAULT_LIB
 hashes, lib_sha = kernel_resources.kernel_code_hashes(lib), kernel_resources.lib_sha256(lib)
-try:
-    import subprocess
+head = os.environ.get("LDPC_HEAD")  # .git does not travel to the GPU box: tools/round_measure.sh passes the HEAD it was started from
+if not head:
+    try:
+        import subprocess
 
-    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
-except OSError:
-    head = None
-head = head or os.environ.get("LDPC_HEAD")  # .git does not travel to the GPU box: tools/round_measure.sh passes the HEAD it was started from
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        head = None
 for key, ent in entries.items():
     ent["kernel_code_sha"] = hashes.get(ent["kernel"])
     ent["lib_sha256"] = lib_sha
