@@ -211,77 +211,6 @@ class DeviceSimulator:
         """Decode global frames [frame0, frame0+frames_total) split over ranks; returns the reduced counters (numpy)."""
         return self.finish_round(self.launch_round(param, stream_id, frame0, frames_total, flags))
 
-    # ---- max_iter <= 0: "no cap" upstream (src/bpa.py:28 loops until the syndrome is satisfied); here bounded at 100 000 sweeps.  A frame
-    # caught in a trapping set runs all of them -- 41 ms in fp64 -- on ONE workgroup, and a round that holds such a frame lasts that long
-    # however fast the other 65 535 frames were (the four --max-iter=0 lines of the REG_BAD table: 137 of 159 s of the whole experiment
-    # set).  Rounds therefore travel in BLOCKS: every round is decoded with a cap of UNCAPPED_FIRST sweeps (channel kernel -> priors in HBM ->
-    # ldpc_decode), the frames that reach it are collected -- priors and all -- from the whole block and decoded again FROM SCRATCH without the
-    # cap in ONE compact side launch (one workgroup each, all in parallel), their results are written back, and the rounds are counted in
-    # order (ldpc_count_errors, one all-reduce per round) under the usual stopping rule; rounds behind the stop are discarded like any
-    # speculative round.  Decoding is deterministic per frame, so every counter equals the one-launch-per-round path's (tests/test_gpu_montecarlo.py).
-    UNCAPPED_FIRST = 2000
-    UNCAPPED_BLOCK = 8
-
-    def _uncapped_blocks_apply(self):
-        h = self.h
-        return (self.max_iter <= 0 and self.device == "cuda" and self.prior_grid is None and self.codeword in (0, 1)
-                and getattr(h, "alg", None) in ("MSA", "SPA") and hasattr(h, "channel_device") and hasattr(h, "decode_device"))
-
-    def _run_point_uncapped(self, param, stream_id, min_wec, batch_per_rank, on_progress, max_frames):
-        torch, h = self.torch, self.h
-        lib = _lib.load()
-        n, k = h.code.n, 4 + self.hist_bins
-        per_round = int(batch_per_rank) * self.comm.world
-        tot = np.zeros(k, dtype=np.int64)
-
-        def more():
-            return tot[_lib.CNT_WEC] < min_wec and (max_frames is None or tot[_lib.CNT_TOT] < max_frames)
-
-        frame0 = 0
-        block = 1  # the first round on its own (most points of the tables end inside it), then UNCAPPED_BLOCK rounds at a time
-        while more():
-            rounds = []
-            for _r in range(block):
-                start, cnt = self.comm.shard(frame0, per_round)
-                frame0 += per_round
-                if cnt == 0:
-                    rounds.append(None)
-                    continue
-                pri, y0 = h.channel_device(self.channel, param, self.codeword, self.seed, stream_id, start, cnt)
-                xh, it = h.decode_device(pri, y0, self.UNCAPPED_FIRST)
-                idx = (it >= self.UNCAPPED_FIRST).nonzero().flatten()
-                rounds.append(dict(xh=xh, it=it, idx=idx, pri=pri.index_select(0, idx) if idx.numel() else None,
-                                   y0=y0.index_select(0, idx) if (y0 is not None and idx.numel()) else None))
-                del pri, y0
-            late = [r for r in rounds if r is not None and r["idx"].numel()]
-            if late:  # the frames still sweeping at the first cap, of the whole block, in one side launch without the cap
-                pri = torch.cat([r["pri"] for r in late])
-                y0 = torch.cat([r["y0"] for r in late]) if late[0]["y0"] is not None else None
-                xh2, it2 = h.decode_device(pri.contiguous(), None if y0 is None else y0.contiguous(), 0)
-                pos = 0
-                for r in late:
-                    m_ = r["idx"].numel()
-                    r["xh"].index_copy_(0, r["idx"], xh2[pos:pos + m_])
-                    r["it"].index_copy_(0, r["idx"], it2[pos:pos + m_])
-                    pos += m_
-            st = torch.cuda.current_stream().cuda_stream
-            for r in rounds:
-                cnt_dev = torch.zeros(k, dtype=torch.int64, device="cuda")
-                if r is not None:
-                    _lib.check(lib.ldpc_count_errors(r["xh"].data_ptr(), None, int(self.codeword), r["it"].data_ptr(), r["xh"].shape[0], n,
-                                                     self.hist_bins, cnt_dev.data_ptr(), st))
-                self.comm.all_reduce_sum(cnt_dev)
-                row = cnt_dev.cpu().numpy()
-                if more():  # rows behind the stop are discarded: counters stay a function of the round size alone
-                    tot += row
-                    if on_progress:
-                        on_progress(int(tot[0]), int(tot[1]), int(tot[2]), tot[4:].copy() if self.hist_bins else None)
-            block = self.UNCAPPED_BLOCK
-        out = dict(tot=int(tot[0]), wec=int(tot[1]), bec=int(tot[2]), iter_sum=int(tot[3]), capped=bool(tot[_lib.CNT_WEC] < min_wec))
-        if self.hist_bins:
-            out["hist"] = tot[4:].tolist()
-        return out
-
     def pipeline_depth(self):
         """Rounds worth keeping in flight.  Only the fused in-kernel path returns from ``simulate`` without a host wait; the
         streaming kernels, the ADMM composition and ``--codeword -1`` poll / synchronise inside ``simulate``, so a second round in
@@ -298,8 +227,6 @@ class DeviceSimulator:
         round is already running; that round is drained and DISCARDED, so the counters are exactly those of the synchronous loop
         (a function of the round size only, not of the pipeline depth or the number of ranks).  ``on_progress(tot, wec, bec, hist)``
         receives the reduced counters after every counted round (``hist`` = the histogram bins or None)."""
-        if self._uncapped_blocks_apply():
-            return self._run_point_uncapped(param, stream_id, min_wec, batch_per_rank, on_progress, max_frames)
         tot = np.zeros(4 + self.hist_bins, dtype=np.int64)
         frame0 = 0
         per_round = int(batch_per_rank) * self.comm.world

@@ -63,24 +63,6 @@ def test_pipelined_rounds_equal_the_synchronous_loop():
     assert got["hist"] == tot[4:].tolist() and got["tot"] >= 3 * 512  # several rounds, so the pipeline really overlapped
 
 
-@pytest.mark.parametrize("alg,prec,channel,param,backend", [("MSA", "f64", "biawgn", 1.7, "auto"), ("MSA", "f32", "bsc", 0.075, "auto"),
-                                                            ("SPA", "f32", "biawgn", 1.4, "auto"), ("MSA", "f32", "biawgn", 1.7, "stream")])
-def test_uncapped_rounds_travel_in_blocks_with_identical_counters(monkeypatch, alg, prec, channel, param, backend):
-    # --max-iter 0 = "no cap" upstream (src/bpa.py:28), bounded here at 100 000 sweeps.  The block form (first cap, then ONE compact side
-    # launch for the frames still sweeping, rounds counted in order) must give exactly the counters of one in-kernel launch per round --
-    # with a first cap of 25 sweeps many frames take the side launch: frames that converge later, frames that never do.
-    from ldpc_decoders_amd.montecarlo import DeviceSimulator
-
-    monkeypatch.setattr(DeviceSimulator, "UNCAPPED_FIRST", 25)
-    monkeypatch.setattr(DeviceSimulator, "UNCAPPED_BLOCK", 3)
-    h = _handle(alg, prec, backend)
-    new = DeviceSimulator(h, channel, 0, 0, 99).run_point(param, 4, min_wec=70, batch_per_rank=256)
-    monkeypatch.setattr(DeviceSimulator, "_uncapped_blocks_apply", lambda self: False)
-    old = DeviceSimulator(h, channel, 0, 0, 99).run_point(param, 4, min_wec=70, batch_per_rank=256)
-    assert new == old, (new, old)
-    assert new["wec"] >= 70 and new["tot"] >= 2 * 256 and new["iter_sum"] > 25 * new["wec"]  # several rounds; frames ran far beyond the first cap
-
-
 WORKER = r'''
 import json, os, sys
 sys.path[:0] = [%(root)r, %(root)r + "/tests", %(root)r + "/oracle"]
