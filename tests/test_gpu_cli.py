@@ -148,3 +148,29 @@ def test_max_frames_stops_a_low_error_point(tmp_path, monkeypatch):
                   "--batch", "8192", "--max-frames", "20000", "--data_dir", str(tmp_path), "--console"])
     r = res[0.2]
     assert r["tot"] == 3 * 8192 and r["wec"] < 100000  # whole rounds: the first total at or above the cap
+
+
+def test_bench_lines_of_the_admm_and_ml_decoders():
+    # bench.py --decoder ADMM | ML: a gradeable line each -- whole-step frames/s, the dominant kernel timed alone with
+    # HIP events, its name (the LDS-resident ADMM kernel where the code is eligible), counters against published rates
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def line(flags):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + flags + ["--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rows = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(rows) == 1
+        return json.loads(rows[0])
+
+    a = line(["--decoder", "ADMM", "--code", "512_3_6_rand_ldpc_2", "--param", "2.6", "--max-iter", "80", "--batch", "4096", "--steps", "2", "--warmup", "1",
+              "--repeats", "1"])
+    assert a["config"]["decoder"] == "ADMM" and a["config"]["backend"] == "admm-lds" and a["dtype"] == "f64" and a["frames_counted"] == 2 * 4096
+    assert a["roofline"]["kernel"] == "k_admm_lds<6, 3, 2, 4, 1>" and a["roofline"]["avg_launch_ms"] > 0 and a["roofline"]["unit_of_work"] == "frame-iteration"
+    assert 1 < a["mean_sweeps"] < 80 and 0 < a["wer"] < 1 and "baseline_configs" not in a
+    m = line(["--decoder", "ML", "--code", "7_4_hamming", "--param", "2.0", "--precision", "f32", "--batch", "1048576", "--steps", "3", "--warmup", "1",
+              "--repeats", "1", "--max-iter", "0"])
+    assert m["config"]["decoder"] == "ML" and m["roofline"]["kernel"] == "k_ml<float, 0>" and m["frames_counted"] == 3 * 1048576
+    assert abs(m["wer"] - 0.0910) < 0.004     # ML word-error rate of Hamming(7,4) at 2 dB (published curve: tests/golden/published_curves.json)
