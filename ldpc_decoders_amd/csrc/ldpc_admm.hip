@@ -942,6 +942,7 @@ static int admm_decode_lds(AdmmDecoder* d, const double* gamma, int64_t B, doubl
     if (const char* e = std::getenv("LDPC_ADMM_BACKEND"))
         if (std::string(e) == "stream") return 1;
     if (c->min_dc != c->max_dc || c->max_dc != 6 || c->max_dv > 3 || c->min_dv < 1) return 1;  // built: (3,6)-type codes (every check six edges, variables up to three)
+    if (c->m < 128) return 1;  // a frame must fill a workgroup: tiny codes keep the streaming kernels (64 frames per wave)
     // waves per frame: 4 or 8 with one check per lane (m <= 256 / 512); beyond (n = 1200: m = 600) eight waves take the checks in TWO passes
     // -- ten waves at one check each were measured no faster (three wave-projections per SIMD either way) and leave the compiler 170
     // registers where the projection wants 200 (49 spilled)
