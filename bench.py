@@ -128,7 +128,7 @@ def cpu_baseline(code, alg, channel, param, max_iter, precision="f64", budget_s=
       "port"   oracle/bp_oracle.c -- a plain-C port of the reference algorithm (min-sum, sum-product, erasure decoder; sparse, so it
                also runs the codes the reference's dense H cannot hold), OpenMP over frames, every host thread;
       "scipy"  oracle/scipy_baseline.py -- per-frame scipy.sparse decoding, the reference's class of implementation, one
-               process per host core (LLR decoders); with the calibration measured where the true reference can run
+               process per physical host core (LLR decoders); with the calibration measured where the true reference can run
                (tests/golden/reference_timing.json: reference frames/s / scipy-baseline frames/s on identical frames) it estimates the
                reference's own rate on this host."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -182,7 +182,9 @@ def cpu_baseline(code, alg, channel, param, max_iter, precision="f64", budget_s=
         return out
     # per-frame scipy.sparse baseline, one process per core, each decoding its own frame stream for about budget_s seconds
     try:
-        procs = cores  # one single-thread process per host core; forked BEFORE this process initialises a GPU runtime
+        # one single-thread process per PHYSICAL core ("one process per host core"; with one per hardware thread two processes
+        # share a core and the per-process rate is not the reference's); forked BEFORE this process initialises a GPU runtime
+        procs = physical_cores() or cores
         task = (code.m, code.n, code.edge_chk, code.edge_var, alg, channel, param, max_iter)
         with mp.get_context("fork").Pool(procs) as pool:
             # a short pass of every process sizes the sample (the rate per process UNDER LOAD, not that of one process alone)
@@ -198,8 +200,7 @@ def cpu_baseline(code, alg, channel, param, max_iter, precision="f64", budget_s=
         sc = {"value": round(frames / wall, 2), "unit": "frames/s", "cores": procs, "physical_cores": physical_cores(), "kind": "scipy",
               "per_core_frames_per_s": round(frames / wall / procs, 3),
               "sample": "%d frames (%d per process), same H / %s over %s at %s / max_iter %d, fp64 per-frame scipy.sparse decoder "
-                        "(oracle/scipy_baseline.py), %d single-thread processes (one per hardware thread: with SMT the per-process rate is that "
-                        "of a shared core), %.1f s, mean %.1f sweeps/frame" % (
+                        "(oracle/scipy_baseline.py), %d single-thread processes (one per physical core), %.1f s, mean %.1f sweeps/frame" % (
                             frames, frames_each, alg, channel, param_label(channel, param), max_iter, procs, wall,
                             sum(r["iters"] for r in res) / max(frames, 1))}
         with open(os.path.join(ROOT, "tests", "golden", "reference_timing.json")) as fp:
@@ -211,7 +212,7 @@ def cpu_baseline(code, alg, channel, param, max_iter, precision="f64", budget_s=
                               tj["host"], pt["frames"], pt["frames_per_s"], pt["baseline_frames_per_s"]),
                           reference_estimate_frames_per_s=round(frames / wall * pt["calibration"], 2),
                           reference_estimate_note="scipy-baseline rate on this host x calibration: what the reference's own Python would "
-                                                  "reach here with one process per hardware thread (it is single-threaded)")
+                                                  "reach here with one process per physical core (it is single-threaded)")
         out["scipy"] = sc
     except Exception as e:  # the baseline is a report, never a reason to lose the benchmark line
         out["scipy"] = {"error": repr(e)}
