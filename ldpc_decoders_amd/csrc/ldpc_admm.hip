@@ -36,6 +36,7 @@ struct AdmmDecoder {
     int32_t* d_lvl_a = nullptr;
     int32_t* d_lvl_b = nullptr;
     int32_t* d_lvl_start = nullptr;
+    int8_t* d_fold_partner = nullptr;  // the same tree as lane-to-lane additions inside one wave (k_admm_lds; <= 32 blocks)
     int levels = 0, nodes = 0;
     unsigned long long* d_ticket = nullptr;  // frame dispenser of the LDS-resident kernel
     int last_backend = 0;                    // 0: streaming kernels, 1: LDS-resident kernel
@@ -609,6 +610,7 @@ struct AdmmLdsArgs {
     int32_t* iters;
     uint8_t* converged;
     const int32_t *col_ptr, *col_edge, *edge_var, *leaf_off, *leaf_len, *lvl_a, *lvl_b, *lvl_start;
+    const int8_t* fold_partner;  // [levels][64]: lane arr * 32 + leaf adds the value of that lane at that level (-1: none); null: more than 32 blocks
     int m, n, E, leaves, levels, nodes;
     long long B;
     double mu, thresh;
@@ -669,6 +671,10 @@ __global__ __launch_bounds__(64 * NW) void k_admm_lds(const AdmmLdsArgs A) {
     const bool has_chain = tid < 2 * A.leaves * 8;
     const int chain_off = has_chain ? A.leaf_off[chain_rem >> 3] + (chain_rem & 7) : 0;
     const int chain_len = has_chain ? A.leaf_len[chain_rem >> 3] : 0;
+    // wave 0: the lanes this lane adds in at each level of the split tree (lane arr * 32 + block holds that block's / subtree's sum)
+    int fold_p[8];
+#pragma unroll
+    for (int lv = 0; lv < 8; ++lv) fold_p[lv] = (A.fold_partner && tid < 64 && lv < A.levels) ? (int)A.fold_partner[lv * 64 + tid] : -1;
 
     for (;;) {
         // ---- next frame
@@ -757,7 +763,38 @@ __global__ __launch_bounds__(64 * NW) void k_admm_lds(const AdmmLdsArgs A) {
             }
             __syncthreads();
             // ---- phase C2 + C3 (one wave): block sums, then the additions of the split tree level by level
-            if (tid < 64) {
+            if (tid < 64 && A.fold_partner) {
+                // <= 32 blocks: lane arr * 32 + block holds the block sum; the tree is folded lane to lane (two ds_bpermute per level instead
+                // of an LDS round trip per index, value and result)
+                const int arr = tid >> 5, leaf = tid & 31;
+                double res = 0.0;
+                if (leaf < A.leaves) {
+                    const int off = s_leaf_off[leaf], len = s_leaf_len[leaf];
+                    const double* a = arr ? d2 : d1;
+                    const int i0 = len < 8 ? 0 : len - (len % 8), ntail = len - i0;  // np_block's tail: at most 7 elements, added one by one
+                    double tail[7];
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) tail[t] = a[eidx(off + (t < ntail ? i0 + t : 0))];
+                    if (len < 8) {
+                        res = -0.0;
+                    } else {
+                        const double* r8 = racc + (arr * A.leaves + leaf) * 8;
+                        res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
+                    }
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) res = t < ntail ? res + tail[t] : res;
+                }
+#pragma unroll
+                for (int lv = 0; lv < 8; ++lv) {
+                    if (lv < A.levels) {  // wave-uniform
+                        const double other = __shfl(res, fold_p[lv] >= 0 ? fold_p[lv] : tid, 64);
+                        res = fold_p[lv] >= 0 ? res + other : res;
+                    }
+                }
+                const bool far = (leaf == 0) && !((0.0 + res) < A.thresh);  // lanes 0 and 32 hold the two totals (src/admm.py:21)
+                const bool any_far = __ballot(far) != 0ull;
+                if (tid == 0) word[2] = any_far ? 0 : 1;
+            } else if (tid < 64) {
                 for (int idx = tid; idx < 2 * A.leaves; idx += 64) {
                     const int arr = idx / A.leaves, leaf = idx - arr * A.leaves;
                     const int off = s_leaf_off[leaf], len = s_leaf_len[leaf];
@@ -849,6 +886,7 @@ int admm_create(Code* code, AdmmDecoder** out) {
     d->prog_len = (int)prog.size();
     // the same tree as a level schedule (k_admm_lds): replay the stack program, every addition becomes a node one level above its deeper child
     std::vector<int32_t> lvl_a, lvl_b, lvl_start;
+    std::vector<int8_t> fold;
     {
         const int leaves = d->leaves;
         std::vector<int> stack, node_level((size_t)leaves, 0), ea, eb;  // additions in program order
@@ -886,6 +924,16 @@ int admm_create(Code* code, AdmmDecoder** out) {
         lvl_start.push_back(next);
         d->levels = maxl;
         d->nodes = next;
+        // and as a fold inside ONE wave: a node's value lives in the lane of its leftmost block (lane arr * 32 + block); at the node's level
+        // that lane adds the value of its right child's lane
+        if (leaves <= 32 && maxl <= 8) {
+            std::vector<int> home((size_t)leaves + ea.size());
+            for (int i = 0; i < leaves; ++i) home[i] = i;
+            for (size_t i = 0; i < ea.size(); ++i) home[leaves + i] = home[ea[i]];
+            fold.assign((size_t)std::max(maxl, 1) * 64, (int8_t)-1);
+            for (size_t i = 0; i < ea.size(); ++i)
+                for (int arr = 0; arr < 2; ++arr) fold[(size_t)(node_level[leaves + i] - 1) * 64 + arr * 32 + home[ea[i]]] = (int8_t)(arr * 32 + home[eb[i]]);
+        }
     }
     hipError_t e = hipSetDevice(code->device);
     if (e == hipSuccess) e = hipHostMalloc(&d->pinned, 64);
@@ -899,6 +947,8 @@ int admm_create(Code* code, AdmmDecoder** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&d->d_lvl_b, lvl_b.size() * 4 + 4);
     if (e == hipSuccess) e = hipMalloc((void**)&d->d_lvl_start, lvl_start.size() * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&d->d_ticket, 64);
+    if (e == hipSuccess && !fold.empty()) e = hipMalloc((void**)&d->d_fold_partner, fold.size());
+    if (e == hipSuccess && !fold.empty()) e = hipMemcpy(d->d_fold_partner, fold.data(), fold.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_lvl_a, lvl_a.data(), lvl_a.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_lvl_b, lvl_b.data(), lvl_b.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_lvl_start, lvl_start.data(), lvl_start.size() * 4, hipMemcpyHostToDevice);
@@ -919,7 +969,7 @@ void admm_destroy(AdmmDecoder* d) {
     for (DevBuf* b : {&d->z, &d->lam, &d->d1, &d->d2, &d->x, &d->gam, &d->live, &d->flags, &d->part, &d->z2, &d->lam2, &d->x2, &d->gam2, &d->live2, &d->fmap, &d->fmap2,
                       &d->rbase})
         b->release();
-    for (void* q : {(void*)d->d_leaf_off, (void*)d->d_leaf_len, (void*)d->d_prog, (void*)d->d_lvl_a, (void*)d->d_lvl_b, (void*)d->d_lvl_start, (void*)d->d_ticket})
+    for (void* q : {(void*)d->d_leaf_off, (void*)d->d_leaf_len, (void*)d->d_prog, (void*)d->d_lvl_a, (void*)d->d_lvl_b, (void*)d->d_lvl_start, (void*)d->d_ticket, (void*)d->d_fold_partner})
         if (q) (void)hipFree(q);
     if (d->pinned) (void)hipHostFree(d->pinned);
     delete d;
@@ -957,6 +1007,7 @@ static int admm_decode_lds(AdmmDecoder* d, const double* gamma, int64_t B, doubl
     a.gamma = gamma; a.x_out = x_out; a.iters = iters; a.converged = converged;
     a.col_ptr = c->d_col_ptr; a.col_edge = c->d_col_edge; a.edge_var = c->d_edge_var;
     a.leaf_off = d->d_leaf_off; a.leaf_len = d->d_leaf_len; a.lvl_a = d->d_lvl_a; a.lvl_b = d->d_lvl_b; a.lvl_start = d->d_lvl_start;
+    a.fold_partner = d->d_fold_partner;
     a.m = c->m; a.n = c->n; a.E = (int)c->E; a.leaves = d->leaves; a.levels = d->levels; a.nodes = d->nodes;
     a.B = B; a.mu = mu; a.thresh = (eps * eps) * (double)c->E;
     a.max_iter = max_iter; a.cap = max_iter > 0 ? max_iter : 100000;
