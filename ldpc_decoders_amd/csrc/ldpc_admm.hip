@@ -611,7 +611,7 @@ struct AdmmLdsArgs {
     uint8_t* converged;
     const int32_t *col_ptr, *col_edge, *edge_var, *leaf_off, *leaf_len, *lvl_a, *lvl_b, *lvl_start;
     const int8_t* fold_partner;  // [levels][64]: lane arr * 32 + leaf adds the value of that lane at that level (-1: none); null: more than 32 blocks
-    int m, n, E, leaves, levels, nodes;
+    int m, n, E, leaves, levels, nodes, val_doubles;  // val_doubles: size of the `val` area (>= 2 * nodes, >= 64)
     long long B;
     double mu, thresh;
     int max_iter, cap;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(64 * NW) void k_admm_lds(const AdmmLdsArgs A) {
     double* const x = d2 + E;
     double* const racc = x + n;                        // [2][leaves][8] accumulator chains
     double* const val = racc + 2 * A.leaves * 8;        // [2][nodes] block sums and the tree above them
-    volatile int* const word = reinterpret_cast<volatile int*>(val + 2 * A.nodes);  // [0] frame hand-out (lo), [1] (hi), [2] verdict
+    volatile int* const word = reinterpret_cast<volatile int*>(val + A.val_doubles);  // [0] frame hand-out (lo), [1] (hi), [2] verdict
     // the schedule of the stopping sums, copied into the LDS once per workgroup (a global load per tree level on the one wave that
     // folds the tree was a third of the iteration): additions of the tree (lvl_a, lvl_b per node), level boundaries, blocks (offset, length)
     int* const s_lvl_a = const_cast<int*>(reinterpret_cast<volatile int*>(word)) + 16;
@@ -748,6 +748,7 @@ __global__ __launch_bounds__(64 * NW) void k_admm_lds(const AdmmLdsArgs A) {
             }
             __syncthreads();
             // ---- phase C1: the eight strided accumulators of every block (np_block), one lane per chain
+            double rsum = 0.0;
             if (has_chain && chain_len >= 8) {
                 // a block has at most 128 elements, 16 per accumulator: every load of the chain is issued before the first add (the adds stay in
                 // np_block's order); element positions past the chain read the chain's first element and are not added
@@ -756,34 +757,36 @@ __global__ __launch_bounds__(64 * NW) void k_admm_lds(const AdmmLdsArgs A) {
                 double e[16];
 #pragma unroll
                 for (int t = 0; t < 16; ++t) e[t] = a[eidx(chain_off + (t < nel ? 8 * t : 0))];
-                double rsum = e[0];
+                rsum = e[0];
 #pragma unroll
                 for (int t = 1; t < 16; ++t) rsum = t < nel ? rsum + e[t] : rsum;
-                racc[tid] = rsum;
+                if (!A.fold_partner) racc[tid] = rsum;
+            }
+            if (A.fold_partner) {
+                // the eight accumulators of a block sit on eight consecutive lanes of one wave: ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) by three
+                // lane shifts, then the block's tail (np_block) on the lane of accumulator 0, which hands the block sum to wave 0
+                const double p1 = rsum + __shfl_down(rsum, 1, 64);
+                const double p2 = p1 + __shfl_down(p1, 2, 64);
+                const double p4 = p2 + __shfl_down(p2, 4, 64);
+                if (has_chain && (chain_rem & 7) == 0) {
+                    const double* a = chain_arr ? d2 : d1;
+                    const int i0 = chain_len < 8 ? 0 : chain_len - (chain_len % 8), ntail = chain_len - i0;  // at most 7 elements, added one by one
+                    double tail[7];
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) tail[t] = a[eidx(chain_off + (t < ntail ? i0 + t : 0))];
+                    double res = chain_len < 8 ? -0.0 : p4;
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) res = t < ntail ? res + tail[t] : res;
+                    val[chain_arr * 32 + (chain_rem >> 3)] = res;
+                }
             }
             __syncthreads();
             // ---- phase C2 + C3 (one wave): block sums, then the additions of the split tree level by level
             if (tid < 64 && A.fold_partner) {
                 // <= 32 blocks: lane arr * 32 + block holds the block sum; the tree is folded lane to lane (two ds_bpermute per level instead
                 // of an LDS round trip per index, value and result)
-                const int arr = tid >> 5, leaf = tid & 31;
-                double res = 0.0;
-                if (leaf < A.leaves) {
-                    const int off = s_leaf_off[leaf], len = s_leaf_len[leaf];
-                    const double* a = arr ? d2 : d1;
-                    const int i0 = len < 8 ? 0 : len - (len % 8), ntail = len - i0;  // np_block's tail: at most 7 elements, added one by one
-                    double tail[7];
-#pragma unroll
-                    for (int t = 0; t < 7; ++t) tail[t] = a[eidx(off + (t < ntail ? i0 + t : 0))];
-                    if (len < 8) {
-                        res = -0.0;
-                    } else {
-                        const double* r8 = racc + (arr * A.leaves + leaf) * 8;
-                        res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
-                    }
-#pragma unroll
-                    for (int t = 0; t < 7; ++t) res = t < ntail ? res + tail[t] : res;
-                }
+                const int leaf = tid & 31;
+                double res = leaf < A.leaves ? val[tid] : 0.0;
 #pragma unroll
                 for (int lv = 0; lv < 8; ++lv) {
                     if (lv < A.levels) {  // wave-uniform
@@ -1000,7 +1003,8 @@ static int admm_decode_lds(AdmmDecoder* d, const double* gamma, int64_t B, doubl
     const int nw = rows <= 4 ? 4 : 8, cpl = rows <= 8 ? 1 : 2;
     if (rows > 16 || c->n > (cpl == 1 ? 2 : 3) * 64 * nw) return 1;
     if (2 * d->leaves * 8 > 64 * nw) return 1;  // one accumulator chain of the stopping sums per lane
-    const size_t lds_bytes = ((size_t)5 * c->E + c->n + (size_t)2 * d->leaves * 8 + (size_t)2 * d->nodes) * 8 + 64 +
+    const int val_doubles = std::max(2 * d->nodes, 64);
+    const size_t lds_bytes = ((size_t)5 * c->E + c->n + (size_t)2 * d->leaves * 8 + (size_t)val_doubles) * 8 + 64 +
                              ((size_t)2 * d->nodes + d->levels + 1 + (size_t)2 * d->leaves) * 4 + 16;  // + the schedule tables (ints)
     if (lds_bytes > (size_t)160 * 1024) return 1;
     AdmmLdsArgs a;
@@ -1008,7 +1012,7 @@ static int admm_decode_lds(AdmmDecoder* d, const double* gamma, int64_t B, doubl
     a.col_ptr = c->d_col_ptr; a.col_edge = c->d_col_edge; a.edge_var = c->d_edge_var;
     a.leaf_off = d->d_leaf_off; a.leaf_len = d->d_leaf_len; a.lvl_a = d->d_lvl_a; a.lvl_b = d->d_lvl_b; a.lvl_start = d->d_lvl_start;
     a.fold_partner = d->d_fold_partner;
-    a.m = c->m; a.n = c->n; a.E = (int)c->E; a.leaves = d->leaves; a.levels = d->levels; a.nodes = d->nodes;
+    a.m = c->m; a.n = c->n; a.E = (int)c->E; a.leaves = d->leaves; a.levels = d->levels; a.nodes = d->nodes; a.val_doubles = val_doubles;
     a.B = B; a.mu = mu; a.thresh = (eps * eps) * (double)c->E;
     a.max_iter = max_iter; a.cap = max_iter > 0 ? max_iter : 100000;
     a.ticket = d->d_ticket;
