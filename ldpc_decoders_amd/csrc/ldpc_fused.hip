@@ -44,10 +44,10 @@ struct FusedPlan {
     int msync_off[4] = {0, 0, 0, 0};   // NW > 1: byte offset of a padded marginal slot owned by wave w (end-of-sweep hand-off)
     int zero_row = 0;                  // 1: the c2v area ends with an always-zero row
     int sys_off = 0;                   // NW = 16: byte offset of the system row
-    uint32_t certain_entry = 0xffffffffu;  // gather-table entry of the certain slot (short check rows), none otherwise
+    uint32_t certain_entry = 0xffffffffu;  // gather-table entry of one of the certain slots (short check rows), none otherwise
     size_t lds_bytes = 0;
     int groups_per_cu = 0, num_cu = 0;
-    double extra_identity = 0, extra_planned = 0, base_cycles = 0;
+    double extra_identity = 0, extra_planned = 0, extra_built = -1, base_cycles = 0;
     bool plan_from_store = false;      // layout read from a stored plan file instead of annealed now
 };
 
@@ -135,7 +135,8 @@ int fused_info(const Decoder* d, double* out8) {
     out8[0] = p->NW;              // wavefronts per frame (0 = fused backend not available)
     out8[1] = p->base_cycles;     // conflict-free LDS cycles of the gathers per sweep
     out8[2] = p->extra_identity;  // extra bank-conflict cycles per sweep, trivial placement
-    out8[3] = p->extra_planned;   // ... with the planned placement
+    out8[3] = p->extra_built >= 0 ? p->extra_built : p->extra_planned;  // ... with the planned placement: of the gather tables as built (every lane's final
+                                                                        // address, padding included) where the plan builder evaluates them, else the planner's figure (real edges)
     out8[4] = p->groups_per_cu * p->NW;  // resident waves per CU
     out8[5] = (double)p->lds_bytes;      // LDS bytes per frame
     out8[6] = p->CR;
@@ -459,14 +460,31 @@ int fused_plan_create(Decoder* d) {
     const int tab_shift = esz == 8 ? (frame_bytes > 65536 ? 3 : 0) : (BIG ? 2 : 0);
     std::vector<int64_t> cn_addr((size_t)CR * DC * 64, -1), vn_addr((size_t)vr.total_gathers() * 64, -1);  // byte offsets, -1 = padded lane
     for (int v = 0; v < c->n; ++v) var_of_slot[var_slot[v]] = v;
-    // short check rows are padded with reads of one "certain" variable slot (marked -2): +-inf marginal, see the kernel
-    int certain_slot = -1;
+    // Short check rows are padded with reads of a "certain" variable slot (marked -2: +inf marginal, see the kernel); a variable with
+    // fewer edges than its round gathers reads a zero word for the missing ones.  Neither costs an LDS cycle when the word sits on a bank
+    // that no real lane of the same half-wave gather uses (all such lanes of the half-wave then read ONE address: a broadcast) -- so there
+    // is a certain slot and a zero word on as many of the 32 banks as the frame has room for, and every half-wave takes the one whose bank
+    // is free.  (Rounds 3-5 had ONE of each: on the irregular n = 10 000 code 770 of the 16-wave kernel's 787 measured bank-conflict
+    // cycles per frame-sweep were these two words, the planner's 65 the rest.)
+    constexpr int64_t SHORT_ROW = -2, MISSING_EDGE = -3;  // resolved per half-wave below; -1 = padded lane
+    std::vector<int64_t> certain_addr, zero_words;
     if (short_rows) {
-        for (int s = vr.usable_slots() - 1; s >= 0 && certain_slot < 0; --s)
-            if (var_of_slot[s] == -1) certain_slot = s;
-        if (certain_slot < 0) return LDPC_OK;
-        var_of_slot[certain_slot] = -2;
-        p->certain_entry = (uint32_t)(((int64_t)certain_slot * esz) >> tab_shift);
+        bool bank_has[32] = {};
+        for (int s = vr.usable_slots() - 1; s >= 0 && certain_addr.size() < 32; --s)
+            if (var_of_slot[s] == -1 && !bank_has[s & 31]) {
+                bank_has[s & 31] = true;
+                var_of_slot[s] = -2;
+                p->certain_entry = (uint32_t)(((int64_t)s * esz) >> tab_shift);
+                certain_addr.push_back((int64_t)s * esz);
+            }
+        if (certain_addr.empty()) return LDPC_OK;
+    }
+    if (SYS) {  // the free words of the system row (the kernels zero them: fp32 words 33..63; fp64 doubles 17..31 in the irregular shapes, double 17 otherwise)
+        bool wide_rounds = false;
+        for (int q = 0; q < VR; ++q) wide_rounds |= vr.width(q) > DV;
+        for (int i = (esz == 8 ? 17 : 33); i < (esz == 8 ? (wide_rounds ? 32 : 18) : 64); ++i) zero_words.push_back((int64_t)p->sys_off + (int64_t)i * esz);
+    } else if (p->zero_row) {  // the always-zero row behind the c2v area
+        for (int l = 0; l < 64; ++l) zero_words.push_back((int64_t)c2v_base + (int64_t)(CR * DC * 64 + l) * esz);
     }
     for (int cc = 0; cc < c->m; ++cc) {
         const int R = chk_slot[cc] / 64, lane = chk_slot[cc] % 64;
@@ -477,15 +495,13 @@ int fused_plan_create(Decoder* d) {
             used |= 1u << edge_pos[k];
         }
         for (int j = 0; j < DC; ++j)
-            if (!((used >> j) & 1u)) cn_addr[(size_t)(R * DC + j) * 64 + lane] = (int64_t)certain_slot * esz;
+            if (!((used >> j) & 1u)) cn_addr[(size_t)(R * DC + j) * 64 + lane] = SHORT_ROW;
     }
-    // where a missing edge reads its 0: the always-zero row behind the c2v area (one word per lane), or the zero word of the system row
-    auto zero_addr = [&](int lane) -> int64_t { return SYS ? (int64_t)p->sys_off + (esz == 8 ? 136 : 132) : (int64_t)c2v_base + (int64_t)(CR * DC * 64 + lane) * esz; };
     for (int v = 0; v < c->n; ++v) {
         const int Q = var_slot[v] / 64, lane = var_slot[v] % 64;
         // a real variable with fewer edges than its round gathers sums zeros for the missing ones
-        if (p->zero_row || SYS)
-            for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = zero_addr(lane);
+        if (!zero_words.empty())
+            for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = MISSING_EDGE;
         for (int pidx = c->col_ptr[v]; pidx < c->col_ptr[v + 1]; ++pidx) {
             const int k = c->col_edge[pidx], cs = chk_slot[c->edge_chk[k]];
             // row of the message of (check row Rg = cs / 64, edge position j): Rg * DC + j; the 16-wave shape interleaves the waves' rows
@@ -495,10 +511,34 @@ int fused_plan_create(Decoder* d) {
             vn_addr[(size_t)(vr.first_gather(Q) + var_pos[k]) * 64 + lane] = c2v_base + (int64_t)(row * 64 + cs % 64) * esz;
         }
     }
-    if (certain_slot >= 0) {  // the certain slot sums nothing: every gather reads the zero row
-        const int Q = certain_slot / 64, lane = certain_slot % 64;
-        for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = zero_addr(lane);
+    for (int64_t a : certain_addr) {  // a certain slot sums nothing: every gather reads a zero word
+        const int slot = (int)(a / esz), Q = slot / 64, lane = slot % 64;
+        for (int j = 0; j < vr.width(Q); ++j) vn_addr[(size_t)(vr.first_gather(Q) + j) * 64 + lane] = MISSING_EDGE;
     }
+    // per half-wave: the word (of `words`) on the bank the fewest distinct real addresses of this gather use -- none at all whenever there
+    // is a choice, since a half-wave with k such lanes leaves at least k banks free
+    auto resolve = [esz](std::vector<int64_t>& addr, int64_t mark, const std::vector<int64_t>& words) {
+        for (size_t g0 = 0; g0 < addr.size(); g0 += 32) {
+            bool any = false;
+            for (int l = 0; l < 32; ++l) any |= addr[g0 + l] == mark;
+            if (!any) continue;
+            int load[32] = {};
+            for (int l = 0; l < 32; ++l) {
+                const int64_t a = addr[g0 + l];
+                if (a < 0) continue;
+                bool dup = false;
+                for (int i = 0; i < l; ++i) dup |= addr[g0 + i] == a;
+                if (!dup) ++load[(a / esz) & 31];
+            }
+            int64_t best = words[0];
+            for (int64_t wd : words)
+                if (load[(wd / esz) & 31] < load[(best / esz) & 31]) best = wd;
+            for (int l = 0; l < 32; ++l)
+                if (addr[g0 + l] == mark) addr[g0 + l] = best;
+        }
+    };
+    if (!certain_addr.empty()) resolve(cn_addr, SHORT_ROW, certain_addr);
+    if (!zero_words.empty()) resolve(vn_addr, MISSING_EDGE, zero_words);
     // padded lanes may read anything: let them repeat an address of their own half-wave (LDS broadcast, no extra cycle)
     auto fill_padding = [](std::vector<int64_t>& addr, int64_t fallback) {
         for (size_t g0 = 0; g0 < addr.size(); g0 += 32) {
@@ -510,38 +550,36 @@ int fused_plan_create(Decoder* d) {
         }
     };
     // Padded check lanes repeat an address of their own half-wave (broadcast, no extra LDS cycle); the kernels mask them out of the
-    // syndrome (cn_valid).  The 16-wave shape has no register for that mask: there a padded lane reads ONE marginal dc times (even dc:
-    // even sign parity, invisible in the syndrome) -- per half-wave the slot that collides least with the real reads.
-    if (BIG && DC % 2 == 0) {
-        for (int R = 0; R < CR; ++R)
-            for (int h = 0; h < 2; ++h) {
-                bool any_pad = false;
-                for (int l = 0; l < 32; ++l) any_pad |= cn_addr[(size_t)(R * DC) * 64 + h * 32 + l] < 0;
-                if (!any_pad) continue;
-                int best_slot = 0, best_cost = 1 << 30;
-                for (int slot = 0; slot < NPAD && best_cost > 0; ++slot) {
-                    int cost = 0;
-                    for (int j = 0; j < DC; ++j) {
-                        bool clash = false, same = false;
-                        for (int l = 0; l < 32; ++l) {
-                            const int64_t a = cn_addr[(size_t)(R * DC + j) * 64 + h * 32 + l];
-                            if (a < 0) continue;
-                            if (a == (int64_t)slot * esz) same = true;
-                            else if (((a / esz) & 31) == (slot & 31)) clash = true;
-                        }
-                        cost += (clash && !same) ? 1 : 0;
-                    }
-                    if (cost < best_cost) { best_cost = cost; best_slot = slot; }
-                }
-                for (int j = 0; j < DC; ++j)
-                    for (int l = 0; l < 32; ++l) {
-                        int64_t& a = cn_addr[(size_t)(R * DC + j) * 64 + h * 32 + l];
-                        if (a < 0) a = (int64_t)best_slot * esz;
-                    }
-            }
-    }
+    // syndrome (cn_valid).  The 16-wave fp32 shape has no register for that mask: there a padded lane reads zero words -- sign bit 0 in
+    // every position, invisible in the syndrome, and its messages stay 0 -- again the one on the bank its half-wave leaves free.  (Rounds
+    // 3-5 let it read ONE real marginal dc times, on whichever bank collided least over the dc gathers: with 31 real lanes on 31 banks in
+    // each of them that was ~3 extra cycles for nearly every half-wave that holds a padded lane.)
+    if (BIG && esz == 4) resolve(cn_addr, -1, zero_words);
     fill_padding(cn_addr, 0);
     fill_padding(vn_addr, c2v_base);
+    {  // bank-conflict cycles per sweep of the tables AS BUILT (every lane's final address; the planner's figure covers real edges only)
+        auto built_cost = [&](const std::vector<int64_t>& addr) {
+            long extra = 0;
+            for (size_t g0 = 0; g0 < addr.size(); g0 += 32) {
+                int mx = 1;
+                for (int b = 0; b < 32; ++b) {
+                    int distinct = 0;
+                    int64_t seen[32];
+                    for (int l = 0; l < 32; ++l) {
+                        const int64_t a = addr[g0 + l] / esz;
+                        if ((a & 31) != b) continue;
+                        bool dup = false;
+                        for (int i = 0; i < distinct; ++i) dup |= seen[i] == a;
+                        if (!dup) seen[distinct++] = a;
+                    }
+                    mx = std::max(mx, distinct);
+                }
+                extra += mx - 1;
+            }
+            return extra;
+        };
+        p->extra_built = (double)(built_cost(cn_addr) + built_cost(vn_addr));
+    }
     for (int K = 0; K < CR * DC; ++K)
         for (int lane = 0; lane < 64; ++lane) put16(cn_tab, CNW, CRW * DC, K, lane, (uint32_t)(cn_addr[(size_t)K * 64 + lane] >> tab_shift));
     for (int K = 0; K < vr.total_gathers(); ++K)

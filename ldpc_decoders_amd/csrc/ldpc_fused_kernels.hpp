@@ -192,7 +192,7 @@ struct FusedArgs {
     unsigned long long bsc_thr;     // BSC: flip <=> Philox word < thr   (src/bsc.py:16)
     float bsc_llr;                  // BSC: prior = llr * (1 - 2y)        (src/bsc.py:21,25), llr > 0 here
     double sim_mean_d, sim_sigma_d, sim_k_d, bsc_llr_d;  // the same constants for the fp64 kernels (k_biawgn<double> / k_discrete<double>)
-    uint32_t certain_entry;         // gather-table entry of the "certain" variable slot that pads short check rows (0xffffffff: none)
+    uint32_t certain_entry;         // gather-table entry of one of the "certain" variable slots that pad short check rows (0xffffffff: no short rows)
     unsigned long long* counters;   // [4 + hist_bins] tot, wec, bec, iter_sum, histogram of sweeps
     int flush_every;                // SIM: frames a workgroup counts in 32-bit lanes before adding them to `counters`
     // several rounds per launch (erasure Monte-Carlo kernel, ldpc_simulate_rounds): `rounds` rounds of B frames each; round r covers
@@ -320,7 +320,8 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
     const uint32_t sign_mask = 0x80000000u;
     auto sysw = [&](int i) { return lds_word(smem + A.sys_off) + i; };
     if constexpr (SYS) {
-        if (threadIdx.x == 0) *sysw(33) = 0u;  // published by the barrier at the top of the frame loop
+        if (threadIdx.x < 31) *sysw(33 + threadIdx.x) = 0u;  // the zero words missing edges gather (one per bank 1..31: the half-wave's free one,
+                                                             // ldpc_fused.hip); published by the barrier at the top of the frame loop
     }
 
     // BIG: the c2v rows of the 16 waves are INTERLEAVED -- local row k = r*DC + j of wave w is row k*NW + w of the c2v area -- so that the
@@ -329,7 +330,9 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
     // (rows k < BIG_KA from M0_a = c2v area + w*256, rows BIG_KA <= k < BIG_KB from M0_b = 65 535 - (NW-1-w)*256).  Only the rows beyond
     // (k >= BIG_KB: 8 of a wave's 30, four paired stores) keep an address register.  An add-TID store costs 2.2 issue-path cycles per row
     // against 3 for the paired form (+1.2 % measured); the LDS-array counters (SQ_LDS_IDX_ACTIVE 4 562, SQ_LDS_BANK_CONFLICT 787 per
-    // frame-sweep) did not move: they book the passes of a row store whatever instruction carries it (HISTORY.md, round 6).
+    // frame-sweep) did not move -- row stores are conflict-free either way: those 787 cycles were the GATHERS of padding positions (one
+    // certain slot, one zero word for every half-wave), found with store-less / linear-gather probe builds and fixed in the table
+    // builder (ldpc_fused.hip; HISTORY.md, round 6).
     constexpr int BIG_C2V = NPAD * 4;                                                      // byte offset of the c2v area
     constexpr int BIG_ROWB = NW * 256;                                                     // bytes between two local rows of a wave
     constexpr int BIG_KA = BIG ? (65535 / BIG_ROWB + 1 < CRW * DC ? 65535 / BIG_ROWB + 1 : CRW * DC) : 0;
@@ -615,9 +618,8 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                         vx ^= __float_as_uint(v[j]);
                     }
                     // bit 31 only is tested: the sign parity of a REAL check of this round.  (BIG: 128 registers hold no extra mask; there a
-                    // padded lane still reads ONE marginal dc times -- even parity for the even dc this shape has, ldpc_fused.hip)
+                    // padded lane reads zero words in every position -- sign bit 0 -- ldpc_fused.hip)
                     if constexpr (BIG) {
-                        static_assert(!BIG || DC % 2 == 0, "the 16-wave shape relies on even check degree for its padded lanes");
                         synd |= mx;
                     } else {
                         synd |= mx & (cn_valid << (31 - r));
@@ -884,7 +886,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
     constexpr bool WIDE = (size_t)(VR * 64 + CRT * DC * 64) * 8 > 65536;
     const int my_rows = RAGGED ? (CRT - w * CRW < 0 ? 0 : (CRT - w * CRW < CRW ? CRT - w * CRW : CRW)) : CRW;  // wave-uniform
     auto gat = [&](uint32_t entry) { return *reinterpret_cast<const double*>(smem + (WIDE ? (entry << 3) : entry)); };
-    if (threadIdx.x == 0) {  // the always-zero double (system-row bytes 136..143) that missing edges gather
+    if constexpr (VRX > 0) {  // irregular shapes: doubles 17..31 of the system row (bytes 136..255), one always-zero word per bank for the missing
+        if (threadIdx.x < 30) *sysw(34 + threadIdx.x) = 0u;  // edges of a half-wave to gather from the bank its real lanes leave free (ldpc_fused.hip)
+    } else if (threadIdx.x == 0) {  // the always-zero double (system-row bytes 136..143) that missing edges gather
         *sysw(34) = 0u;
         *sysw(35) = 0u;
     }
@@ -914,9 +918,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
     // (upstream has no such edge: tanh(inf/2) = 1 contributes log 1 = 0 to the row sum and leaves the parity alone).
     u64 padpos = 0;
     if constexpr (ALG == ALG_SPA) {
-        if (A.certain_entry != 0xffffffffu) {
+        if (A.certain_entry != 0xffffffffu) {  // (there is a certain slot on every bank the frame has room for: var_of_slot == -2 marks them)
 #pragma unroll
-            for (int k = 0; k < CRW * DC; ++k) padpos |= half_of<CRW * DC>(cn_idx, k) == A.certain_entry ? (1ull << k) : 0ull;
+            for (int k = 0; k < CRW * DC; ++k) {
+                const uint32_t e = half_of<CRW * DC>(cn_idx, k);
+                padpos |= A.var_of_slot[WIDE ? e : (e >> 3)] == -2 ? (1ull << k) : 0ull;
+            }
         }
     }
     // counting mode (SIM, or A.counters != null): the Monte-Carlo counters of main.test (src/main.py:41-45) are accumulated here instead

@@ -41,6 +41,22 @@ def test_config4_irregular_n10000_msa():
     assert info["waves_per_frame"] == 16 and info["lds_bytes_per_frame"] == 160 * 1024
 
 
+def test_config4_shipped_plan_builds_tables_with_few_conflicts(monkeypatch, tmp_path):
+    # bench.py's config-4 code with its shipped plan: bank-conflict cycles per sweep of the gather tables AS BUILT -- every lane's final
+    # address, i.e. the padding reads of short check rows, of variables below their round's width and of padded check lanes included (a
+    # "certain" slot / a zero word on every bank, each half-wave reading the one on the bank it leaves free: rounds 3-5 had ONE word of
+    # each kind and the PMC pass of the 16-wave kernel measured SQ_LDS_BANK_CONFLICT 787 per frame-sweep; 106 with these tables)
+    import bench
+    from ldpc_decoders_amd import bpa
+
+    monkeypatch.setenv("LDPC_FUSED_PLAN_SAVE", "none")
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "empty"))
+    code = bench.load_code("gen:irg:10000")
+    info = bpa.MSA(code, max_iter=50, precision="f32", backend="fused").handle.fused_info()
+    assert info["waves_per_frame"] == 16
+    assert info["conflict_cycles_planned"] < 0.05 * info["lds_gather_cycles_min"], info
+
+
 def test_config4_fused_layout_independent(monkeypatch):
     # the trivial placement and a short annealing run give the same bits as the stored plan (placement only moves data)
     from ldpc_decoders_amd import bpa, codes
