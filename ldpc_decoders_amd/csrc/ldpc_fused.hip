@@ -479,10 +479,10 @@ int fused_plan_create(Decoder* d) {
             }
         if (certain_addr.empty()) return LDPC_OK;
     }
-    if (SYS) {  // the free words of the system row (the kernels zero them: fp32 words 33..63; fp64 doubles 17..31 in the irregular shapes, double 17 otherwise)
+    if (SYS) {  // the free words of the system row (the kernels zero them: fp32 words 33..63; fp64 doubles 9..31 in the irregular shapes, double 17 otherwise)
         bool wide_rounds = false;
         for (int q = 0; q < VR; ++q) wide_rounds |= vr.width(q) > DV;
-        for (int i = (esz == 8 ? 17 : 33); i < (esz == 8 ? (wide_rounds ? 32 : 18) : 64); ++i) zero_words.push_back((int64_t)p->sys_off + (int64_t)i * esz);
+        for (int i = (esz == 8 ? (wide_rounds ? 9 : 17) : 33); i < (esz == 8 ? (wide_rounds ? 32 : 18) : 64); ++i) zero_words.push_back((int64_t)p->sys_off + (int64_t)i * esz);
     } else if (p->zero_row) {  // the always-zero row behind the c2v area
         for (int l = 0; l < 64; ++l) zero_words.push_back((int64_t)c2v_base + (int64_t)(CR * DC * 64 + l) * esz);
     }

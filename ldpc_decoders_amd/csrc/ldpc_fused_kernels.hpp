@@ -886,9 +886,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
     constexpr bool WIDE = (size_t)(VR * 64 + CRT * DC * 64) * 8 > 65536;
     const int my_rows = RAGGED ? (CRT - w * CRW < 0 ? 0 : (CRT - w * CRW < CRW ? CRT - w * CRW : CRW)) : CRW;  // wave-uniform
     auto gat = [&](uint32_t entry) { return *reinterpret_cast<const double*>(smem + (WIDE ? (entry << 3) : entry)); };
-    if constexpr (VRX > 0) {  // irregular shapes: doubles 17..31 of the system row (bytes 136..255), one always-zero word per bank for the missing
-        if (threadIdx.x < 30) *sysw(34 + threadIdx.x) = 0u;  // edges of a half-wave to gather from the bank its real lanes leave free (ldpc_fused.hip)
-    } else if (threadIdx.x == 0) {  // the always-zero double (system-row bytes 136..143) that missing edges gather
+    // system row (32 doubles): words 0..NW-1 sweep verdicts, SYS_ERR.. error counts, SYS_TICKET the frame hand-off, then always-zero doubles for
+    // missing edges to gather.  Regular shapes: one (double 17, bytes 136..143).  Irregular shapes (VRX > 0) pack the words and keep doubles
+    // 9..31 zero: one word per bank, every half-wave gathers the one on the bank its real lanes leave free (ldpc_fused.hip)
+    constexpr int SYS_ERR = VRX > 0 ? 8 : 16, SYS_TICKET = VRX > 0 ? 16 : 32;
+    static_assert(NW <= 8, "system-row words of k_fused_f64");
+    if constexpr (VRX > 0) {
+        if (threadIdx.x < 46) *sysw(18 + threadIdx.x) = 0u;
+    } else if (threadIdx.x == 0) {
         *sysw(34) = 0u;
         *sysw(35) = 0u;
     }
@@ -983,10 +988,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
             __syncthreads();
             if (w == 0) {
                 const long long f0 = next_frame();
-                if (lane == 0) *sysw(32) = (uint32_t)(int32_t)f0;
+                if (lane == 0) *sysw(SYS_TICKET) = (uint32_t)(int32_t)f0;
             }
             __syncthreads();
-            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*sysw(32));
+            fr_s = (long long)(int32_t)__builtin_amdgcn_readfirstlane(*sysw(SYS_TICKET));
         }
         if (fr_s < 0) break;
         const u64 fr = (u64)fr_s;
@@ -1259,9 +1264,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
 #pragma unroll
             for (int q = 0; q < VRW; ++q) err += __popcll(__ballot((wrong >> q) & 1u));
             if constexpr (NW > 1) {  // channel B of the system row (the sweep loop's last exchange used channel A)
-                if (lane == 0) *sysw(16 + w) = (uint32_t)err;
+                if (lane == 0) *sysw(SYS_ERR + w) = (uint32_t)err;
                 __syncthreads();
-                int sum = lane < NW ? (int)*sysw(16 + (lane & (NW - 1))) : 0;
+                int sum = lane < NW ? (int)*sysw(SYS_ERR + (lane & (NW - 1))) : 0;
 #pragma unroll
                 for (int o = NW / 2; o; o >>= 1) sum += __shfl_xor(sum, o);
                 err = sum;
