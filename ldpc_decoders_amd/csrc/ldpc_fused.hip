@@ -191,9 +191,15 @@ ShapeChoice choose_shape(const Code* c, int alg, int dtype) {
         if (s.VRX == 0) {
             if (short_rows || c->max_dv > s.DV) continue;
         } else {
-            int wide = 0;
-            for (int v = 0; v < c->n; ++v) wide += (c->col_ptr[v + 1] - c->col_ptr[v]) > s.DV;
-            if (c->max_dv > s.DVX || wide > s.VRX * s.NW * 64) continue;
+            // a variable fits a round that gathers at least as many messages as it has edges: those above DV need a wide round, those above
+            // two a wide or a DV round (shapes with pair rounds)
+            int wide = 0, above2 = 0;
+            for (int v = 0; v < c->n; ++v) {
+                wide += (c->col_ptr[v + 1] - c->col_ptr[v]) > s.DV;
+                above2 += (c->col_ptr[v + 1] - c->col_ptr[v]) > 2;
+            }
+            if (c->max_dv > s.DVX || wide > wide_rounds(s.VRX) * s.NW * 64) continue;
+            if (pair_rounds(s.VRX) > 0 && above2 > (s.VRW - pair_rounds(s.VRX)) * s.NW * 64) continue;
         }
         if (s.NW > 1 && !big && (!full_dv || c->max_dv != s.DV || CR * 64 - c->m < s.NW)) continue;  // needs padded check slots for the hand-off
         out.si = i;
@@ -203,7 +209,7 @@ ShapeChoice choose_shape(const Code* c, int alg, int dtype) {
     out.esz = shape.esz;
     out.SYS = shape.NW > 4 || (shape.NW > 1 && shape.VRX > 0) || shape.esz == 8;  // system row (see the kernels)
     VarRounds& vr = out.vr;
-    vr.VR = shape.VRW * shape.NW; vr.DV = shape.DV; vr.vrx = shape.VRX; vr.dvx = shape.DVX; vr.nw = shape.NW; vr.reserved = out.SYS ? 1 : 0;
+    vr.VR = shape.VRW * shape.NW; vr.DV = shape.DV; vr.vrx = wide_rounds(shape.VRX); vr.vr2 = pair_rounds(shape.VRX); vr.dvx = shape.DVX; vr.nw = shape.NW; vr.reserved = out.SYS ? 1 : 0;
     vr.reserved_half = shape.esz == 8;  // the fp64 kernels' system words (36 dwords) fit the upper half of the last marginal row
     // fp64 sum-product sums log|tanh| over a row in the reference's order (ascending variable): its plans keep the edge order
     vr.fixed_edge_order = alg == ALG_SPA && dtype == DT_F64;

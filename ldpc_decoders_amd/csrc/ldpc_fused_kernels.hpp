@@ -37,7 +37,8 @@ namespace ldpc {
 
 // One instantiated kernel shape: what the host-side plan builder (ldpc_fused.hip) chooses from.
 struct ShapeEntry {
-    int alg, DC, DV, CRW, VRW, NW, VRX, DVX;  // VRX wide variable rounds of DVX gathers (irregular codes), 0 for regular
+    int alg, DC, DV, CRW, VRW, NW, VRX, DVX;  // VRX: variable rounds of other widths than DV (irregular codes), 0 for regular -- low four bits: the
+                                              // wave's FIRST rounds gather DVX messages ("wide"), the bits above: its LAST rounds gather two ("pair" rounds)
     const void* kernel;      // decode: priors in, decisions out
     const void* kernel_sim;  // simulate: noise in the kernel, counters out (null: decode only)
     int esz = 4;             // bytes per LDS element: 4 (fp32 kernels), 8 (fp64 kernels)
@@ -49,6 +50,11 @@ struct ShapeEntry {
 // Rows of 64 check slots a frame holds in the LDS.  Normally CRW per wave.  The fp64 shapes of four and more waves for regular codes
 // keep only the rows a code can fill -- E = m DC <= n DV, hence m <= VR 64 DV / DC -- and the last wave(s) run fewer rows: the (3,6)
 // n = 1200 frame is 10 check rows + 20 marginal rows = 40 KB, four frames per CU, with FOUR waves each (rows 3 + 3 + 3 + 1) instead of two.
+// A wave's variable rounds: the first wide_rounds(VRX) gather DVX messages per variable, the last pair_rounds(VRX) two, those between DV.  (The
+// two counts share one template argument so that the kernels of all other shapes keep their names: PMC counters are filed under them.)
+constexpr int wide_rounds(int vrx_arg) { return vrx_arg & 15; }
+constexpr int pair_rounds(int vrx_arg) { return vrx_arg >> 4; }
+constexpr int vrx_arg(int wide, int pairs) { return wide + 16 * pairs; }
 constexpr int fused_check_rows(int esz, int DC, int DV, int CRW, int VRW, int NW, int VRX) {
     const int all = CRW * NW, fill = (VRW * NW * DV + DC - 1) / DC;
     return (esz == 8 && VRX == 0 && NW >= 4 && fill < all) ? fill : all;
@@ -256,9 +262,11 @@ __device__ __forceinline__ void sim_flush(unsigned& accv, int lane, int hist_bin
 }
 
 // (the body of k_fused_bp / k_fused_bp_grid: the kernels themselves follow it)
-template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX, bool GRID>
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRXA, int DVX, bool GRID>
 __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
     static_assert(!GRID || ALG == ALG_MSA, "the exactness guard belongs to min-sum: only add / subtract / compare");
+    constexpr int VRX = wide_rounds(VRXA), VR2 = pair_rounds(VRXA);  // the wave's first VRX rounds gather DVX messages, its last VR2 rounds two
+    static_assert(VR2 == 0 || (VRX > 0 && DV > 2 && VRX + VR2 <= VRW), "pair rounds belong to the irregular shapes");
     // BIG: a frame takes the whole LDS of a CU (160 KB) and a 16-wave workgroup.  Table entries are dword indices, c2v stores
     // use an address register, and the LAST marginal row is a system row that no sweep writes: dwords [0,16) hand-off
     // channel A (one word per wave), [16,32) channel B, [32] frame hand-out, [33] always zero (target of missing edges).
@@ -266,12 +274,15 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
     // SYS: the system row (hand-off words + zero word in the last marginal row) is also what lets SEVERAL waves share an
     // irregular frame of the small shapes (they have no always-zero row and may have no padded slot per wave)
     constexpr bool SYS = BIG || (NW > 1 && VRX > 0);
-    constexpr int VNK = VRX * DVX + (VRW - VRX) * DV;  // gathers of a variable phase: wide rounds first, then narrow ones
+    constexpr int VNK = VRX * DVX + (VRW - VRX - VR2) * DV + VR2 * 2;  // gathers of a variable phase: wide rounds first, then narrow ones, pair rounds last
     constexpr int VN0 = VRX * DVX;                      // first gather index of the narrow rounds
     constexpr int CR = CRW * NW, VR = VRW * NW;
     constexpr int NPAD = VR * 64;
     constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
-    constexpr int VRN = VRW - VRX;  // narrow variable rounds (DV gathers); they follow the VRX wide rounds
+    constexpr int VRN = VRW - VRX;  // narrow variable rounds (DV gathers; the last VR2 of them two); they follow the VRX wide rounds
+    // narrow round u: its width and the index of its first gather
+    auto nar_w = [](int u) constexpr { return u < VRN - VR2 ? DV : 2; };
+    auto nar_0 = [](int u) constexpr { return VN0 + (u < VRN - VR2 ? u * DV : (VRN - VR2) * DV + (u - (VRN - VR2)) * 2); };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int w = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
@@ -748,7 +759,7 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                 for (int u = 0; u < VG; ++u)
 #pragma unroll
                     for (int j = 0; j < DV; ++j)
-                        if (u < VRN) cv[0][u][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, VN0 + u * DV + j);
+                        if (u < VRN && j < nar_w(u)) cv[0][u][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, nar_0(u) + j);
                 static_for<0, NVG>([&](auto G_) {
                     constexpr int g = decltype(G_)::value;
                     if constexpr (g + 1 < NVG) {
@@ -756,8 +767,8 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                         for (int u = 0; u < VG; ++u)
 #pragma unroll
                             for (int j = 0; j < DV; ++j)
-                                if ((g + 1) * VG + u < VRN)
-                                    cv[(g + 1) & 1][u][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, VN0 + ((g + 1) * VG + u) * DV + j);
+                                if ((g + 1) * VG + u < VRN && j < nar_w((g + 1) * VG + u))
+                                    cv[(g + 1) & 1][u][j] = gat_tab<BIG, VNK, MAD>(smem, vn_idx, nar_0((g + 1) * VG + u) + j);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     static_for<0, VG>([&](auto U_) {
@@ -765,7 +776,8 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
                         if constexpr (g * VG + u < VRN) {
                             float sn = 0.0f + cv[g & 1][u][0];
 #pragma unroll
-                            for (int j = 1; j < DV; ++j) sn += cv[g & 1][u][j];
+                            for (int j = 1; j < DV; ++j)
+                                if (j < nar_w(g * VG + u)) sn += cv[g & 1][u][j];
                             finish_var(std::integral_constant<int, VRX + g * VG + u>{}, sn);
                         }
                     });
@@ -834,7 +846,7 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
 }
 
 #define LDPC_FUSED_BP_BOUNDS __launch_bounds__(64 * NW, NW == 1 ? (CRW <= 4 ? 4 : 2) : ((NW == 4 || DVX > 8 || (NW == 2 && DC >= 7)) ? 3 : 4))
-template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>  // (VRX: wide rounds + 16 * pair rounds, see ShapeEntry)
 __global__ LDPC_FUSED_BP_BOUNDS void k_fused_bp(const FusedArgs A) {
     fused_bp_body<ALG, DC, DV, CRW, VRW, NW, SIM, VRX, DVX, false>(A);
 }
@@ -860,14 +872,18 @@ __global__ LDPC_FUSED_BP_BOUNDS void k_fused_bp_grid(const FusedArgs A) {
 // register budget is 128 (tables stay packed, see the opaque words at the top of the sweep).
 // SIM: channel + LLR in the kernel (Philox noise, the inline functions of the stand-alone channel kernels: bit-identical
 // priors) and error counting in the kernel -- priors and decisions never exist in HBM.
-template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRX, int DVX>
+template <int ALG, int DC, int DV, int CRW, int VRW, int NW, bool SIM, int VRXA, int DVX>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const FusedArgs A) {
     static_assert(ALG == ALG_MSA || ALG == ALG_SPA, "LLR decoders");
+    constexpr int VRX = wide_rounds(VRXA), VR2 = pair_rounds(VRXA);  // as in fused_bp_body
+    static_assert(VR2 == 0 || (VRX > 0 && DV > 2 && VRX + VR2 <= VRW), "pair rounds belong to the irregular shapes");
     constexpr int VR = VRW * NW, NPAD = VR * 64;
     constexpr int CRT = fused_check_rows(8, DC, DV, CRW, VRW, NW, VRX);  // check rows of the frame; < CRW * NW: the last waves run fewer rows
     constexpr bool RAGGED = CRT != CRW * NW;
-    constexpr int VNK = VRX * DVX + (VRW - VRX) * DV;  // gathers of a wave's variable phase: VRX wide rounds (irregular codes) first
+    constexpr int VNK = VRX * DVX + (VRW - VRX - VR2) * DV + VR2 * 2;  // gathers of a wave's variable phase: VRX wide rounds (irregular codes) first, pair rounds last
     constexpr int VN0 = VRX * DVX, VRN = VRW - VRX;
+    auto nar_w = [](int u) constexpr { return u < VRN - VR2 ? DV : 2; };
+    auto nar_0 = [](int u) constexpr { return VN0 + (u < VRN - VR2 ? u * DV : (VRN - VR2) * DV + (u - (VRN - VR2)) * 2); };
     constexpr int CNW = (CRW * DC + 1) / 2, VNW = (VNK + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -1187,7 +1203,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                     for (int u = 0; u < VG; ++u)
 #pragma unroll
                         for (int j = 0; j < DV; ++j)
-                            if (u < VRN) cv[0][u][j] = gat(half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                            if (u < VRN && j < nar_w(u)) cv[0][u][j] = gat(half_of<VNK>(vn_idx, nar_0(u) + j));
                     __builtin_amdgcn_sched_barrier(0);
                     unsat = __ballot(vw != 0u) != 0;
                 } else {
@@ -1231,7 +1247,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                     for (int u = 0; u < VG; ++u)
 #pragma unroll
                         for (int j = 0; j < DV; ++j)
-                            if (u < VRN) cv[0][u][j] = gat(half_of<VNK>(vn_idx, VN0 + u * DV + j));
+                            if (u < VRN && j < nar_w(u)) cv[0][u][j] = gat(half_of<VNK>(vn_idx, nar_0(u) + j));
                 }
                 static_for<0, NVG>([&](auto G_) {
                     constexpr int g = decltype(G_)::value;
@@ -1240,7 +1256,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                         for (int u = 0; u < VG; ++u)
 #pragma unroll
                             for (int j = 0; j < DV; ++j)
-                                if ((g + 1) * VG + u < VRN) cv[(g + 1) & 1][u][j] = gat(half_of<VNK>(vn_idx, VN0 + ((g + 1) * VG + u) * DV + j));
+                                if ((g + 1) * VG + u < VRN && j < nar_w((g + 1) * VG + u)) cv[(g + 1) & 1][u][j] = gat(half_of<VNK>(vn_idx, nar_0((g + 1) * VG + u) + j));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     static_for<0, VG>([&](auto U_) {
@@ -1248,7 +1264,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void k_fused_f64(const Fu
                         if constexpr (g * VG + u < VRN) {
                             double sn = 0.0 + cv[g & 1][u][0];
 #pragma unroll
-                            for (int j = 1; j < DV; ++j) sn += cv[g & 1][u][j];
+                            for (int j = 1; j < DV; ++j)
+                                if (j < nar_w(g * VG + u)) sn += cv[g & 1][u][j];
                             finish_var(std::integral_constant<int, VRX + g * VG + u>{}, sn);
                         }
                     });

@@ -14,6 +14,7 @@ const ShapeEntry* fused_shapes_f64_dc6(int* count) {
         // SIMD), and the min-sum sibling of the shape above (LDPC_FUSED_NW=2).  Four waves on TWELVE check rows (46 KB, 3 frames per CU)
         // were slower than this one: 6.87 vs 6.66 ms per 65 536 frames (round 2)
         LDPC_LLR_ALGS(6, 3, 5, 10, 2),
+        LDPC_LLR_ALGS(6, 3, 5, 10, 2, vrx_arg(2, 6), 8),  // irregular n <= 1215, first choice: two wide and six pair rounds per wave (see the fp32 table)
         LDPC_LLR_ALGS(6, 3, 5, 10, 2, 2, 8),  // irregular n <= 1215: two wide variable rounds per wave, short check rows padded
         LDPC_LLR_ALGS(6, 3, 3, 6, 8),         // (3,6)-regular n <= 3008 (Margulis n = 2640): 96 KB per frame, one frame = 8 waves per CU
     };

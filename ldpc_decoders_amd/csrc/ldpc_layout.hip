@@ -36,17 +36,23 @@ void identity_layout(const Code& c, int DC, const VarRounds& vr, FusedLayout* L)
     L->var_slot.resize(c.n);
     std::iota(L->chk_slot.begin(), L->chk_slot.end(), 0);
     // variables: those that need a wide round first into the wide slots, the others into the narrow slots in index order
-    // (spilling into left-over wide slots when the narrow ones are full); reserved rounds stay empty
-    std::vector<int> wide_free, narrow_free;
+    // (spilling into left-over wide slots when the narrow ones are full); reserved rounds stay empty.  With pair rounds: three classes --
+    // more than DV edges, three..DV edges, at most two -- each into its own rounds first, left-overs into the wider ones
+    std::vector<int> free_of[3];  // usable slots of the wide / DV / pair rounds
     for (int q = 0; q < vr.VR; ++q) {
         for (int l = 0; l < 64; ++l)
-            if (vr.usable_slot(q * 64 + l)) (vr.width(q) > vr.DV ? wide_free : narrow_free).push_back(q * 64 + l);
+            if (vr.usable_slot(q * 64 + l)) free_of[vr.width(q) > vr.DV ? 0 : (vr.width(q) == vr.DV ? 1 : 2)].push_back(q * 64 + l);
     }
-    size_t next_wide = 0, next_narrow = 0;
-    for (int v = 0; v < c.n; ++v)
-        if (c.col_ptr[v + 1] - c.col_ptr[v] > vr.DV) L->var_slot[v] = wide_free[next_wide++];
-    for (int v = 0; v < c.n; ++v)
-        if (c.col_ptr[v + 1] - c.col_ptr[v] <= vr.DV) L->var_slot[v] = next_narrow < narrow_free.size() ? narrow_free[next_narrow++] : wide_free[next_wide++];
+    size_t next[3] = {0, 0, 0};
+    auto take = [&](int cls) {  // a slot of class `cls`, or of the next wider class that still has one
+        for (int k = cls; k >= 0; --k)
+            if (next[k] < free_of[k].size()) return free_of[k][next[k]++];
+        return -1;
+    };
+    auto class_of = [&](int v) { const int d = c.col_ptr[v + 1] - c.col_ptr[v]; return d > vr.DV ? 0 : ((vr.vr2 == 0 || d > 2) ? 1 : 2); };
+    for (int cls = 0; cls < 3; ++cls)
+        for (int v = 0; v < c.n; ++v)
+            if (class_of(v) == cls) L->var_slot[v] = take(cls);
     L->edge_pos.assign(c.E, 0);
     L->var_pos.assign(c.E, 0);
     for (int cc = 0; cc < c.m; ++cc)
@@ -381,6 +387,7 @@ uint64_t layout_key(const Code& c, int DC, int CR, const VarRounds& vr, int NW) 
     if (vr.reserved) h = fnv(h, &vr.reserved, sizeof(vr.reserved));
     if (vr.reserved && vr.reserved_half) h = fnv(h, "half-row", 8);
     if (vr.fixed_edge_order) h = fnv(h, "fixed-edge-order", 16);
+    if (vr.vr2) h = fnv(h, &vr.vr2, sizeof(vr.vr2));
     h = fnv(h, c.edge_chk.data(), c.edge_chk.size() * sizeof(int32_t));
     h = fnv(h, c.edge_var.data(), c.edge_var.size() * sizeof(int32_t));
     return h;

@@ -39,21 +39,23 @@ struct FusedLayout {
     double base_cycles = 0;  // conflict-free LDS cycles of the gathers per sweep (one per half-wave instruction)
 };
 
-// Variable rounds come in two widths: each wave owns VR/nw consecutive rounds, the first `vrx` of them gather `dvx` messages
-// per variable ("wide" rounds, for the high-degree variables of irregular codes), the others gather DV.  vrx = 0 for regular
-// codes.  `reserved` trailing rounds hold no variables (the system row of the 16-wave shape, ldpc_fused.hip); with `reserved_half`
+// Variable rounds come in up to three widths: each wave owns VR/nw consecutive rounds, the first `vrx` of them gather `dvx` messages
+// per variable ("wide" rounds, for the high-degree variables of irregular codes), the last `vr2` gather two ("pair" rounds: most
+// variables of the reference's irregular ensembles have two edges), the others gather DV.  vrx = vr2 = 0 for regular codes.  `reserved`
+// trailing rounds hold no variables (the system row of the 16-wave shape, ldpc_fused.hip); with `reserved_half`
 // only the upper 32 slots of that last round are reserved (the fp64 shapes: their system words fit 32 eight-byte slots).
 struct VarRounds {
     int VR = 0, DV = 0, vrx = 0, dvx = 0;
     int nw = 1, reserved = 0;
     bool reserved_half = false;
     bool fixed_edge_order = false;  // every check keeps its edges in ascending-variable order (fp64 sum-product: the row sum of logs is order dependent)
+    int vr2 = 0;
     int vrw() const { return VR / nw; }
-    int per_wave() const { return vrx * dvx + (vrw() - vrx) * DV; }
-    int width(int q) const { return (q % vrw()) < vrx ? dvx : DV; }
+    int per_wave() const { return vrx * dvx + (vrw() - vrx - vr2) * DV + vr2 * 2; }
+    int width(int q) const { const int l = q % vrw(); return l < vrx ? dvx : (l >= vrw() - vr2 ? 2 : DV); }
     int first_gather(int q) const {  // index of (q, position 0) in the frame's list of variable-phase gathers
-        const int w = q / vrw(), l = q % vrw();
-        return w * per_wave() + (l < vrx ? l * dvx : vrx * dvx + (l - vrx) * DV);
+        const int w = q / vrw(), l = q % vrw(), mid = vrw() - vrx - vr2;
+        return w * per_wave() + (l < vrx ? l * dvx : (l < vrx + mid ? vrx * dvx + (l - vrx) * DV : vrx * dvx + mid * DV + (l - vrx - mid) * 2));
     }
     int total_gathers() const { return nw * per_wave(); }
     int usable_slots() const { return VR * 64 - (reserved ? (reserved_half ? 32 : reserved * 64) : 0); }
@@ -63,8 +65,8 @@ struct VarRounds {
 // exact conflict model: sum over gather instructions and half-waves of (max distinct-address multiplicity - 1)
 double layout_extra_cycles(const Code& c, int DC, int CR, const VarRounds& vr, const FusedLayout& L);
 
-// trivial placement: checks in index order; variables in index order, except that variables with more than DV edges are
-// moved into the wide rounds (the only placement constraint)
+// trivial placement: checks in index order; variables in index order, except that a variable only fits a round that gathers at least
+// as many messages as it has edges (the only placement constraint)
 void identity_layout(const Code& c, int DC, const VarRounds& vr, FusedLayout* L);
 // `moves` = annealing steps (about 1.7 M per second on one host core); the result is a deterministic function of the arguments
 constexpr long kDefaultPlanMoves = 4000000;

@@ -35,7 +35,9 @@ def test_stored_plan_and_parity(name, monkeypatch, tmp_path):
     snr = 2.0
     y = -1 + rng.normal(0, np.sqrt(O.biawgn_noise_var(snr)), (48, code.n))
     pri = O.biawgn_priors(y, snr)
-    limit = 60 if name.startswith("512_") else 40  # n = 512: one wave per frame, 96 gather cycles per sweep
+    # n = 512: one wave per frame, 96 gather cycles per sweep.  The irregular codes run on the shapes with pair rounds: 256 gather cycles per
+    # sweep instead of 280, for which their tighter slot classes cost ~20 more conflict cycles than the two-width shapes' plans (14-30)
+    limit = 60 if name.startswith("512_") or "rho" in name else 40
     for prec, dt in (("f64", np.float64), ("f32", np.float32)):
         dec = bpa.MSA(code, max_iter=40, precision=prec, backend="fused")
         fi = dec.handle.fused_info()

@@ -359,6 +359,13 @@ def test_host_only_layout_planning_and_plan_store(tmp_path):
         assert 0 < info[3] < 0.75 * info[2]
         files = os.listdir(out)
         assert len(files) == 1 and files[0].endswith(".plan") and os.path.getsize(out / files[0]) > 4 * (code.m + code.n + 2 * code.E)
+    # an irregular code of the reference's rate-1/2 ensemble goes onto the shape with PAIR rounds (per wave two rounds of eight gathers, two
+    # of three, six of two: 2 x (60 + 2 x 34) conflict-free cycles per sweep instead of 2 x (60 + 2 x 40)); a variable sits in a round at
+    # least as wide as its degree
+    irr = codes.load_parity_mtx(os.path.join(CODES_DIR, "1200_rho_x5_rand_ldpc_3.txt"))
+    _lib.check(lib.ldpc_plan_layout(irr.m, irr.n, irr.E, np.ascontiguousarray(irr.edge_chk, dtype=np.int32).ctypes.data,
+                                    np.ascontiguousarray(irr.edge_var, dtype=np.int32).ctypes.data, 0, 0, 200000, None, info))
+    assert info[0] == 2 and info[1] == 256 and 0 < info[3] < info[2]
     # a graph no fused shape exists for: reported as such, nothing written
     big = codes.rand_reg_ldpc(20000, 3, 6, np.random.RandomState(1))
     _lib.check(lib.ldpc_plan_layout(big.m, big.n, big.E, np.ascontiguousarray(big.edge_chk, dtype=np.int32).ctypes.data,

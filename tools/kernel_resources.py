@@ -109,7 +109,9 @@ def _elf_functions(co):
 def kernel_code_hashes(lib=DEFAULT_LIB):
     """{kernel name as rocprofv3 prints it: first 16 hex digits of sha256(machine code + kernel descriptor)} for every kernel of the built
     library -- what profiles/roofline_counters.json records beside a kernel's PMC counters, so that bench.py can tell when the kernel it
-    times is no longer the kernel the counters were collected on.  Pure file parsing: no GPU, no HIP call."""
+    times is no longer the kernel the counters were collected on.  The descriptor's kernel_code_entry_byte_offset (bytes 16..23: where the
+    code sits relative to the descriptor) is left out: it moves whenever ANOTHER kernel of the same translation unit is added or changes
+    size, with this kernel's instructions and resources untouched.  Pure file parsing: no GPU, no HIP call."""
     import hashlib
 
     blob = open(lib, "rb").read()
@@ -120,7 +122,8 @@ def kernel_code_hashes(lib=DEFAULT_LIB):
         funcs, kds = _elf_functions(co)
         for nm, body in funcs:
             if nm in kds:
-                raw[nm] = hashlib.sha256(body + kds[nm]).hexdigest()[:16]
+                kd = kds[nm]
+                raw[nm] = hashlib.sha256(body + kd[:16] + b"\0" * 8 + kd[24:]).hexdigest()[:16]
     names = list(raw)
     if not names:
         return {}
