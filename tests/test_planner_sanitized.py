@@ -29,6 +29,7 @@ int main(int argc, char** argv) {
     const int CR = atoi(argv[2]), VR = atoi(argv[3]);
     VarRounds vr; vr.VR = VR; vr.DV = 3; vr.vrx = atoi(argv[4]); vr.dvx = vr.vrx ? 8 : 3;
     if (argc > 8) { vr.nw = atoi(argv[8]); vr.reserved = atoi(argv[9]); }  // per-wave wide rounds / reserved system row
+    if (argc > 10) vr.vr2 = atoi(argv[10]);                                 // pair rounds: a wave's last rounds gather two messages
     FusedLayout L; plan_fused_layout(c, 6, CR, vr, 0x1200, 1200000, &L);
     {   // plan store: round trip, and a damaged file is refused
         const uint64_t key = layout_key(c, 6, CR, vr, 1);
@@ -93,6 +94,33 @@ def test_layout_planner_under_asan(tmp_path, code_name, cr, vr, vrx, nw):
     stored = float(lines[0].split()[1])  # conflict cycles of the shipped plan (ldpc_decoders_amd/plans), recomputed on load
     base, ident, planned = (float(v) for v in lines[1].split())
     assert base == 2.0 * (cr * 6 + vrx * 8 + (vr - vrx) * 3) and planned < 0.6 * ident and stored < planned
+
+
+@pytest.mark.timeout(600)
+def test_layout_planner_under_asan_pair_rounds(tmp_path):
+    # the irregular two-wave shape with three round widths (per wave 2 x 8, 2 x 3, 6 x 2 gathers; last row reserved): every variable in a
+    # round at least as wide as its degree, plan-store round trip, and the shipped plan of this code / shape loads and beats a short run
+    if shutil.which("g++") is None:
+        pytest.skip("no host C++ compiler")
+    src = tmp_path / "harness.cpp"
+    src.write_text(HARNESS)
+    exe = str(tmp_path / "harness")
+    cmd = ["/opt/rocm/bin/hipcc", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", CSRC, "-x", "hip",
+           "--offload-arch=gfx950", "--cuda-host-only", str(src), os.path.join(CSRC, "ldpc_layout.hip"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        if "error:" in r.stderr and "ldpc_" in r.stderr:
+            pytest.fail("planner harness does not compile: " + r.stderr[-1500:])
+        pytest.skip("sanitized host build unavailable here: " + r.stderr[-300:])
+    code_file = os.path.join(ROOT, "ldpc_decoders_amd", "data", "codes", "1200_rho_x5_rand_ldpc_5.txt")
+    plans = os.path.join(ROOT, "ldpc_decoders_amd", "plans")
+    out = subprocess.run([exe, code_file, "10", "20", "2", str(tmp_path), plans, "2", "2", "1", "6"], capture_output=True, text=True,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"), timeout=500)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    stored = float(lines[0].split()[1])
+    base, ident, planned = (float(v) for v in lines[1].split())
+    assert base == 2.0 * (10 * 6 + 2 * (2 * 8 + 2 * 3 + 6 * 2)) and stored < planned < 0.6 * ident
 
 
 @pytest.mark.timeout(900)
