@@ -236,9 +236,11 @@ constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
 // the guarded (exact-in-fp32) variants carry one more live register (the guard's running maximum): more table words stay packed
 // (measured, round 5, tools/ab_grid2.sh / ab_grid.sh: the regular two-wave shape of n = 1200 -- whose guard no longer watches marginals --
 // is fastest with the plain kernel's own 0 + 2 packed words: 3.00-3.04 ms per 65 536 frames against 3.17 (8 + 8) and 3.33 (15 + 15); the
-// irregular and the 16-wave shapes are fastest with all of them packed)
-constexpr int grid_opaque_cn(int nw, int vrx) { return (nw == 2 && vrx == 0) ? 0 : 15; }
-constexpr int grid_opaque_vn(int nw, int vrx) { return (nw == 2 && vrx == 0) ? 2 : 15; }
+// irregular shapes are fastest with all of them packed -- re-measured in round 6 on the shapes with pair rounds: two waves 3.33-3.43 ms for
+// 0 / 4 / 8 / 12 packed words against 3.35 with all; the 16-wave shape, now with the one-instruction unpack (MAD in the kernel): 18.27-18.30
+// ms per 32 768 frames with 12 + 12 packed words, 18.34-18.57 with 4 ... 10, 18.65 with all, 20.13 with all and the shift + add unpack)
+constexpr int grid_opaque_cn(int nw, int vrx) { return nw > 4 ? 12 : ((nw == 2 && vrx == 0) ? 0 : 15); }
+constexpr int grid_opaque_vn(int nw, int vrx) { return nw > 4 ? 12 : ((nw == 2 && vrx == 0) ? 2 : 15); }
 constexpr int SIM_ACC_LANE0 = 60;  // hist_bins <= 60 (fused_simulate_supported)
 __device__ __forceinline__ void sim_count(unsigned& accv, int lane, int err, int it, int hist_bins) {
     const int bin = it < hist_bins ? it : hist_bins - 1;  // no histogram: -1, no lane
@@ -323,8 +325,9 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
     // the 16-wave shape's gathers: one-instruction unpack (gat_tab) -- except in the min-sum Monte-Carlo kernel, where the compiler's own
     // choice is measurably better still: it unpacks the variable-phase addresses once, spills 19 of them and reloads 13 per sweep from its
     // private segment (13 scratch_load_dword on an otherwise idle vector-memory pipe instead of 47 unpack instructions): 17.86 ms against
-    // 18.70 (one-instruction unpack, no spill) and 19.10 (shift + add unpack, no spill) per 32 768 frames, profiles/r03C_spill_or_unpack.txt
-    constexpr bool MAD = BIG && !(ALG == ALG_MSA && SIM);
+    // 18.70 (one-instruction unpack, no spill) and 19.10 (shift + add unpack, no spill) per 32 768 frames, profiles/r03C_spill_or_unpack.txt.
+    // The GUARDED min-sum kernel keeps most table words packed (grid_opaque_cn) and does take the one-instruction unpack: +10 % (round 6).
+    constexpr bool MAD = BIG && (GRID || !(ALG == ALG_MSA && SIM));
     const bool own_last = !(SYS && w == NW - 1);  // with a system row, wave NW-1 never writes its last marginal row
     // the sign of an outgoing message is merged with ONE v_and_or_b32 (inline asm; the compiler emits v_and_b32 + v_or_b32 for the same
     // expression in this kernel): the IEEE sign bit lives in a scalar register
