@@ -222,13 +222,20 @@ constexpr int GRID_REDO_CAP = 4095;
 // sweep loop, or table entries that are reloaded from scratch in every sweep.  An opaque word keeps its two unpacking instructions
 // in the sweep instead.  Counts found by compiling each shape over a grid of values (tools/kernel_resources.py; the CPU test
 // tests/test_host_cpu.py::test_simulate_kernels_do_not_spill pins the result): the smallest counts with no spilled register.
-constexpr int sim_opaque_cn(int alg, int nw, int vrx) {
+constexpr int sim_opaque_cn(int alg, int nw, int vrx_arg_) {
+    const int vrx = wide_rounds(vrx_arg_);
+    // two-wave irregular min-sum on the shape with pair rounds (34 instead of 40 variable-phase gathers): 4 + 4 packed words, two spilled
+    // registers -- 2.84 ms per 65 536 frames at 1.0 dB against 3.03 (15 + 8, the two-width shape's setting), 2.85 (0 + 0, 2 + 2), 2.91 (6 + 6),
+    // 2.95 (8 + 8); at 2.0 dB 1.317 against 1.393 (round 6, two codes, six interleaved runs)
+    if (nw == 2 && pair_rounds(vrx_arg_) > 0 && alg == ALG_MSA) return 4;
     if (nw > 4) return alg == ALG_MSA ? 0 : 15;           // one frame per CU (16 waves): min-sum by the compiler's own allocation (see MAD in the kernel)
     if (vrx == 0) return alg == ALG_MSA ? 0 : 6;          // regular shapes: min-sum 0 + 2; sum-product 6 + 8 (round 5: the pair-tree rule needs
                                                           // fewer registers than prefix / suffix did -- 15 + 15 before; tools/ab_spa.sh: +5.7 %)
     return 15;                                            // irregular shapes (wide variable rounds)
 }
-constexpr int sim_opaque_vn(int alg, int nw, int vrx) {
+constexpr int sim_opaque_vn(int alg, int nw, int vrx_arg_) {
+    const int vrx = wide_rounds(vrx_arg_);
+    if (nw == 2 && pair_rounds(vrx_arg_) > 0 && alg == ALG_MSA) return 4;
     if (nw > 4) return alg == ALG_SPA ? 15 : 0;
     if (vrx == 0) return alg == ALG_SPA ? 8 : 2;
     return alg == ALG_MSA ? 8 : 15;
@@ -313,9 +320,9 @@ __device__ __forceinline__ void fused_bp_body(const FusedArgs& A) {
     auto opaque_tables = [&]() {  // see sim_opaque_cn
         if constexpr (SIM) {
 #pragma unroll
-            for (int i = 0; i < (GRID ? grid_opaque_cn(NW, VRX) : sim_opaque_cn(ALG, NW, VRX)) && i < CNW; ++i) asm volatile("" : "+v"(cn_idx[i]));
+            for (int i = 0; i < (GRID ? grid_opaque_cn(NW, VRX) : sim_opaque_cn(ALG, NW, VRXA)) && i < CNW; ++i) asm volatile("" : "+v"(cn_idx[i]));
 #pragma unroll
-            for (int i = 0; i < (GRID ? grid_opaque_vn(NW, VRX) : sim_opaque_vn(ALG, NW, VRX)) && i < VNW; ++i) asm volatile("" : "+v"(vn_idx[i]));
+            for (int i = 0; i < (GRID ? grid_opaque_vn(NW, VRX) : sim_opaque_vn(ALG, NW, VRXA)) && i < VNW; ++i) asm volatile("" : "+v"(vn_idx[i]));
         }
     };
     auto vmap_of = [&](int q) -> int {
