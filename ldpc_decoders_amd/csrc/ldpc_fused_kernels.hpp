@@ -227,7 +227,7 @@ constexpr int sim_opaque_cn(int alg, int nw, int vrx_arg_) {
     // two-wave irregular min-sum on the shape with pair rounds (34 instead of 40 variable-phase gathers): 4 + 4 packed words, two spilled
     // registers -- 2.84 ms per 65 536 frames at 1.0 dB against 3.03 (15 + 8, the two-width shape's setting), 2.85 (0 + 0, 2 + 2), 2.91 (6 + 6),
     // 2.95 (8 + 8); at 2.0 dB 1.317 against 1.393 (round 6, two codes, six interleaved runs)
-    if (nw == 2 && pair_rounds(vrx_arg_) > 0 && alg == ALG_MSA) return 4;
+    if (nw == 2 && pair_rounds(vrx_arg_) > 0) return alg == ALG_MSA ? 4 : 8;  // (sum-product: 8 + 8 -> 4.95 ms against 5.08 with 15 + 15, 5.00 with 12 + 12, 5.08 with 4 + 4)
     if (nw > 4) return alg == ALG_MSA ? 0 : 15;           // one frame per CU (16 waves): min-sum by the compiler's own allocation (see MAD in the kernel)
     if (vrx == 0) return alg == ALG_MSA ? 0 : 6;          // regular shapes: min-sum 0 + 2; sum-product 6 + 8 (round 5: the pair-tree rule needs
                                                           // fewer registers than prefix / suffix did -- 15 + 15 before; tools/ab_spa.sh: +5.7 %)
@@ -235,7 +235,7 @@ constexpr int sim_opaque_cn(int alg, int nw, int vrx_arg_) {
 }
 constexpr int sim_opaque_vn(int alg, int nw, int vrx_arg_) {
     const int vrx = wide_rounds(vrx_arg_);
-    if (nw == 2 && pair_rounds(vrx_arg_) > 0 && alg == ALG_MSA) return 4;
+    if (nw == 2 && pair_rounds(vrx_arg_) > 0) return alg == ALG_MSA ? 4 : 8;
     if (nw > 4) return alg == ALG_SPA ? 15 : 0;
     if (vrx == 0) return alg == ALG_SPA ? 8 : 2;
     return alg == ALG_MSA ? 8 : 15;
