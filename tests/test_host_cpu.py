@@ -421,7 +421,14 @@ SIM_KERNELS_WITHOUT_SPILLS = [
 # slower than the compiler's own allocation, which unpacks gather addresses once per frame, spills some and reloads them per sweep on the
 # otherwise idle vector-memory pipe (same-box, same plans, profiles/r03C_spill_or_unpack.txt).  Bounded here so that a regression shows.
 SIM_KERNELS_WITH_A_SPILL_BUDGET = {
-    "k_fused_bp<0, 6, 3, 5, 10, 16, true, 3, 8>": 24,  # config 4, one frame per CU: 19 spilled, 17.86 ms against 18.70 (spill-free) per 32 768 frames
+    "k_fused_bp<0, 6, 3, 5, 10, 16, true, 3, 8>": 24,  # the two-width 16-wave shape (fallback since round 6): 19 spilled, 17.86 ms against 18.70 (spill-free) per 32 768 frames
+    # round 6, shapes with pair rounds (VRX argument 98 = 2 wide + 16 x 6 pair rounds): config 4's kernel (6 spilled; every spill-free setting
+    # measured 3-10 % slower), its guarded sibling (12 + 12 packed table words, one-instruction unpack), and the two-wave kernels of the
+    # reference's irregular n = 1200 codes (4 + 4 / 8 + 8 packed words: HISTORY.md round 6)
+    "k_fused_bp<0, 6, 3, 5, 10, 16, true, 98, 8>": 8,
+    "k_fused_bp_grid<6, 3, 5, 10, 16, true, 98, 8>": 12,
+    "k_fused_bp<0, 6, 3, 5, 10, 2, true, 98, 8>": 4,
+    "k_fused_bp<1, 6, 3, 5, 10, 2, true, 98, 8>": 16,
     # config 3, fp32 sum-product (BSC / BI-AWGN), round 5: with the pair-tree rule the kernel is fastest with 6 + 8 of its gather-table words
     # kept packed and 6 registers spilled (2.21 ms per 65 536 frames at p = 0.07); every spill-free setting (15 + 15: 2.34 ms) is 5.7 %
     # slower, 0 + 0 / 4 + 4 / 8 + 8 / 10 + 10 lie in between -- same box, round 5 (HISTORY.md)
